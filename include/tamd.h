@@ -1,0 +1,250 @@
+/* tamd.h -- C ABI of libtamd.so: the MI355X (gfx950) transformer-block kernels.
+ *
+ * This is the drop-in boundary ("B3"): plain pointers,
+ * sizes, strides, scalars and a hipStream_t -- no torch types.  The Python
+ * host side (transformers_amd/ops.py) binds these with ctypes and registers
+ * them as torch.ops.tamd.*; any other host (C++, a `kernels`-style Hub
+ * package) can bind the same symbols.
+ *
+ * Contract for every entry point:
+ *   - returns 0 on success; <0 = TAMD_E_* argument error (nothing launched);
+ *     >0 = the hipError_t of a failed launch;
+ *   - never allocates, frees, synchronises or owns memory: all buffers
+ *     (including workspaces, sized by the *_workspace_bytes helpers) belong
+ *     to the caller and must stay alive until the stream has passed the call;
+ *   - launches asynchronously on `stream` (the caller's current stream);
+ *   - re-entrant, no global mutable state (autograd worker threads call in);
+ *   - device pointers must be 16-byte aligned and row strides multiples of
+ *     8 elements unless a parameter says otherwise.
+ *
+ * Each declaration cites the reference call site it replaces
+ * (paths relative to /root/reference/src/transformers).
+ */
+#ifndef TAMD_H_
+#define TAMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAMD_ABI_VERSION 1
+
+typedef void* tamd_stream_t; /* hipStream_t */
+
+enum tamd_dtype { TAMD_BF16 = 0, TAMD_F16 = 1, TAMD_F32 = 2 };
+
+enum tamd_error {
+  TAMD_OK = 0,
+  TAMD_E_DTYPE = -1,     /* unsupported dtype for this op */
+  TAMD_E_SHAPE = -2,     /* unsupported / inconsistent shape */
+  TAMD_E_ALIGN = -3,     /* pointer or stride alignment */
+  TAMD_E_NULL = -4,      /* required pointer is NULL */
+  TAMD_E_WORKSPACE = -5, /* workspace too small */
+  TAMD_E_ARG = -6        /* other invalid argument */
+};
+
+enum tamd_act { /* activations.py:58-66 (gelu_new), :69-89 (gelu), :92-103 (silu), :116-123 (quick_gelu) */
+  TAMD_ACT_NONE = 0,
+  TAMD_ACT_GELU_ERF = 1,
+  TAMD_ACT_GELU_TANH = 2,
+  TAMD_ACT_QUICK_GELU = 3,
+  TAMD_ACT_SILU = 4
+};
+
+int tamd_abi_version(void);
+const char* tamd_error_string(int code);
+
+/* ------------------------------------------------------------------ norms */
+
+/* LlamaRMSNorm.forward, models/llama/modeling_llama.py:62-67, optionally fused
+ * with the residual add of LlamaDecoderLayer.forward :317/:323.
+ *   h   = residual ? round(x + residual) : x            (h_out written iff residual)
+ *   y   = w * round(h * rsqrt(mean(h^2) + eps))          (fp32 statistics)
+ * rstd [rows] fp32 is saved for the backward.  x,residual,y,h_out: [rows, cols]
+ * contiguous; w: [cols]. */
+int tamd_rmsnorm_fwd(const void* x, const void* residual, const void* w, void* y, void* h_out, float* rstd,
+                     int64_t rows, int64_t cols, float eps, int dtype, tamd_stream_t stream);
+
+size_t tamd_norm_bwd_workspace_bytes(int64_t rows, int64_t cols);
+
+/* Backward of the above (autograd of modeling_llama.py:62-67):
+ *   dx = (dres ? dres : 0) + rstd * (g - xhat * mean(g * xhat)),  g = dy * w,  xhat = h * rstd
+ *   dw = sum_rows dy * round(xhat)
+ * h is the tensor that was normalised (h_out, or x when there was no residual).
+ * workspace: tamd_norm_bwd_workspace_bytes(rows, cols) bytes of scratch. */
+int tamd_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dres, void* dx,
+                     void* dw, void* workspace, size_t workspace_bytes, int64_t rows, int64_t cols, int dtype,
+                     tamd_stream_t stream);
+
+/* nn.LayerNorm as used by BertSelfOutput/BertOutput (models/bert/modeling_bert.py:289-293, :347-351),
+ * BertEmbeddings (:106), GPT2Block (models/gpt2/modeling_gpt2.py:252-254), CLIPEncoderLayer
+ * (models/clip/modeling_clip.py:358-360).  Optional fused residual add:
+ *   h = residual ? round(x + residual) : x ;  y = (h - mean) * rstd * w + b
+ * mean, rstd: [rows] fp32 saved for backward; b may be NULL. */
+int tamd_layernorm_fwd(const void* x, const void* residual, const void* w, const void* b, void* y, void* h_out,
+                       float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int dtype,
+                       tamd_stream_t stream);
+
+/* dx = (dres?dres:0) + rstd*(g - mean(g) - xhat*mean(g*xhat)); dw = sum dy*xhat; db = sum dy (db may be NULL). */
+int tamd_layernorm_bwd(const void* dy, const void* h, const void* w, const float* mean, const float* rstd,
+                       const void* dres, void* dx, void* dw, void* db, void* workspace, size_t workspace_bytes,
+                       int64_t rows, int64_t cols, int dtype, tamd_stream_t stream);
+
+/* ------------------------------------------------------------------ rotary */
+
+/* apply_rotary_pos_emb + rotate_half, models/llama/modeling_llama.py:130-160, applied IN PLACE to
+ * `nheads` consecutive heads of every token row of a [tokens, row_stride] buffer (the fused QKV
+ * projection output: q heads then k heads), with the reference's intermediate roundings:
+ *   out = round(round(x*cos) + round(rotate_half(x)*sin)).
+ * cos/sin: [cos_batch, seq, head_dim] in `dtype` (cos_batch is 1 or tokens/seq).
+ * conj != 0 applies the transposed rotation (the backward, SURVEY §8a "Rope"). */
+int tamd_rope_inplace(void* x, const void* cos, const void* sin, int64_t tokens, int64_t seq, int64_t row_stride,
+                      int64_t nheads, int64_t head_dim, int64_t cos_batch, int conj, int dtype,
+                      tamd_stream_t stream);
+
+/* ------------------------------------------------------------------ embedding */
+
+/* nn.Embedding forward (models/llama/modeling_llama.py:381; BERT :99-104): out[t,:] = table[ids[t],:].
+ * ids int64; bit-exact row copy.  Returns TAMD_E_ARG-free: out-of-range ids are clamped to row 0 and
+ * flagged in *oob_flag (int32 device word, may be NULL). */
+int tamd_embedding_fwd(const int64_t* ids, const void* table, void* out, int64_t ntokens, int64_t vocab,
+                       int64_t dim, int32_t* oob_flag, int dtype, tamd_stream_t stream);
+
+/* embedding_dense_backward: dtable[v,:] = sum_{t: ids[t]==v} dout[t,:] (fp32 accumulation), rows of
+ * dtable not referenced are left untouched (caller zero-fills).  sorted_ids/perm: ids sorted ascending
+ * and the permutation that sorts them (int64).  padding_idx < 0 = none (BERT padding_idx=0 gets no grad,
+ * models/bert/modeling_bert.py:58). */
+int tamd_embedding_bwd(const int64_t* sorted_ids, const int64_t* perm, const void* dout, void* dtable,
+                       int64_t ntokens, int64_t vocab, int64_t dim, int64_t padding_idx, int dtype,
+                       tamd_stream_t stream);
+
+/* BertEmbeddings.forward, models/bert/modeling_bert.py:68-108: word + token_type + position gathers,
+ * adds (each rounded like the reference's three bf16 adds), LayerNorm.  pre_ln (nullable) receives the
+ * summed embeddings for the backward. */
+int tamd_bert_embeddings_fwd(const int64_t* input_ids, const int64_t* token_type_ids, const int64_t* position_ids,
+                             const void* word, const void* type, const void* pos, const void* ln_w,
+                             const void* ln_b, void* out, void* pre_ln, float* mean, float* rstd, int64_t ntokens,
+                             int64_t dim, int64_t vocab, int64_t type_vocab, int64_t max_pos, float eps,
+                             int dtype, tamd_stream_t stream);
+
+/* ------------------------------------------------------------------ MLP element-wise */
+
+/* LlamaMLP.forward inner product, models/llama/modeling_llama.py:174-176:
+ *   act[t, j] = round(round(silu(gate[t,j])) * up[t,j]);  gate/up are column blocks of one
+ * [tokens, ld] buffer (the fused gate|up projection output) or two buffers. */
+int tamd_swiglu_fwd(const void* gate, const void* up, void* act, int64_t tokens, int64_t inter, int64_t ld_gate_up,
+                    int64_t ld_act, int dtype, tamd_stream_t stream);
+/* d_gate = dact*up*silu'(gate), d_up = dact*silu(gate); also re-materialises act when act_out != NULL. */
+int tamd_swiglu_bwd(const void* gate, const void* up, const void* dact, void* dgate, void* dup, void* act_out,
+                    int64_t tokens, int64_t inter, int64_t ld_gate_up, int64_t ld_act, int dtype,
+                    tamd_stream_t stream);
+
+/* y = act(x [+ bias]) for BertIntermediate (models/bert/modeling_bert.py:334-337), GPT2MLP
+ * (models/gpt2/modeling_gpt2.py:238-243), CLIPMLP (models/clip/modeling_clip.py:346-350). bias may be NULL. */
+int tamd_bias_act_fwd(const void* x, const void* bias, void* y, int64_t rows, int64_t cols, int act, int dtype,
+                      tamd_stream_t stream);
+/* dx = dy * act'(x [+ bias]) */
+int tamd_bias_act_bwd(const void* x, const void* bias, const void* dy, void* dx, int64_t rows, int64_t cols,
+                      int act, int dtype, tamd_stream_t stream);
+
+/* out = round(a + b) elementwise (residual adds, modeling_llama.py:317,323), n elements. */
+int tamd_add(const void* a, const void* b, void* out, int64_t n, int dtype, tamd_stream_t stream);
+
+/* column sums of a [rows, cols] matrix with fp32 accumulation (bias gradients db = sum_rows dY). */
+size_t tamd_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int tamd_colsum(const void* x, void* out, void* workspace, size_t workspace_bytes, int64_t rows, int64_t cols,
+                int64_t ld, int dtype, tamd_stream_t stream);
+
+/* out[c, r] = in[r, c]: [rows, cols] (row stride ld_in) -> [cols, rows] (row stride ld_out). */
+int tamd_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int dtype,
+                   tamd_stream_t stream);
+
+/* ------------------------------------------------------------------ loss */
+
+/* ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:32-71, on already-shifted labels:
+ *   lse[t] = logsumexp(float(logits[t,:]));  row_loss[t] = label[t]==ignore ? 0 : lse[t] - logits[t,label[t]]
+ * logits: [tokens, vocab] (row stride ld) in `dtype`, upcast in-register (never materialised in fp32).
+ * lse, row_loss: [tokens] fp32.  The caller reduces row_loss (deterministic) and divides by the number of
+ * non-ignored labels (reduction="mean") or by num_items_in_batch (reduction="sum", loss_utils.py:39-45). */
+int tamd_cross_entropy_fwd(const void* logits, const int64_t* labels, float* lse, float* row_loss, int64_t tokens,
+                           int64_t vocab, int64_t ld, int64_t ignore_index, int dtype, tamd_stream_t stream);
+/* dlogits[t,j] = (exp(logits[t,j]-lse[t]) - [j==label[t]]) * (*gscale)   (0 for ignored rows);
+ * gscale: device fp32 scalar = upstream grad / normaliser. */
+int tamd_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* lse, const float* gscale,
+                           void* dlogits, int64_t tokens, int64_t vocab, int64_t ld, int64_t ignore_index,
+                           int dtype, tamd_stream_t stream);
+
+/* ------------------------------------------------------------------ GEMM (MFMA) */
+
+enum tamd_gemm_flags {
+  TAMD_GEMM_A_KM = 1, /* A stored [K, M] (k-major rows) instead of [M, K] */
+  TAMD_GEMM_B_KN = 2  /* B stored [K, N] instead of [N, K]               */
+};
+enum tamd_gemm_epilogue {
+  TAMD_EPI_NONE = 0,
+  TAMD_EPI_BIAS = 1,      /* C = round(acc + bias[n])                        nn.Linear with bias           */
+  TAMD_EPI_RESIDUAL = 2,  /* C = round(round(acc [+bias]) + R[m,n])          o_proj/down_proj + residual   */
+  TAMD_EPI_BIAS_ACT = 3,  /* C = round(act(round(acc + bias)))               BertIntermediate              */
+  TAMD_EPI_ACCUM = 4      /* C = round(acc + C_old[m,n])  (gradient accumulation into an existing .grad)   */
+};
+
+/* C[M,N] = A[M,K] . B[N,K]^T  with fp32 MFMA accumulation: nn.Linear forward
+ * (modeling_llama.py:254-256,280; :174-176; modeling_bert.py:175-177,289,334,347; pytorch_utils.py:117-121)
+ * and, through the layout flags, its two backward products dX = dY.W and dW = dY^T.X.
+ * bf16/f16 only.  Requirements: K % 8 == 0, N % 8 == 0, lda/ldb/ldc/ldr % 8 == 0.
+ * bias: [N] or NULL; R: [M, ldr] or NULL (for TAMD_EPI_ACCUM, R is ignored and C is read). */
+int tamd_gemm(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N,
+              int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act,
+              int dtype, tamd_stream_t stream);
+
+/* ------------------------------------------------------------------ attention (MFMA, flash-style) */
+
+/* Scaled-dot-product attention replacing eager_attention_forward / repeat_kv
+ * (models/llama/modeling_llama.py:179-213), the BERT/CLIP/GPT-2 eager variants
+ * (models/bert/modeling_bert.py:111-136, models/clip/modeling_clip.py:259-277,
+ * models/gpt2/modeling_gpt2.py:54-72) and integrations/sdpa_attention.py:158-167.
+ *
+ *   O[b,s,h,:] = softmax_k( scale * Q[b,s,h,:] . K[b,k,h/g,:]  masked ) . V[b,k,h/g,:]
+ *
+ * q/k/v/o are addressed by element strides (batch, seq, head); head_dim contiguous.
+ * causal: key k visible to query s iff k <= s + (seq_k - seq_q)  (masking_utils.py:76-81).
+ * key_valid: optional [batch, seq_k] uint8 padding mask (1 = attend); NULL = no padding.
+ * lse [batch, heads_q, seq_q] fp32 (natural-log sum-exp of the scaled scores) is written for
+ * the backward; may be NULL for inference.  head_dim in {64, 128}; bf16/f16. */
+struct tamd_attn_params {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  const uint8_t* key_valid;
+  int64_t batch, heads_q, heads_kv, seq_q, seq_k, head_dim;
+  int64_t q_stride_b, q_stride_s, q_stride_h;
+  int64_t k_stride_b, k_stride_s, k_stride_h;
+  int64_t v_stride_b, v_stride_s, v_stride_h;
+  int64_t o_stride_b, o_stride_s, o_stride_h;
+  float scale;
+  int causal;
+  int dtype;
+};
+int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream);
+
+/* Backward (SURVEY §8a "Attention"): delta = rowsum(dO*O); dV = P^T dO; dS = P*(dP - delta);
+ * dQ = scale dS K; dK = scale dS^T Q; GQA sums dK/dV over the query heads of a group. */
+struct tamd_attn_bwd_params {
+  struct tamd_attn_params fwd; /* q,k,v,o,lse as in the forward */
+  const void* dout;            /* strides = o strides */
+  void* dq;                    /* strides = q strides */
+  void* dk;                    /* strides = k strides */
+  void* dv;                    /* strides = v strides */
+  float* delta;                /* workspace [batch, heads_q, seq_q] fp32 */
+};
+int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMD_H_ */

@@ -1,0 +1,76 @@
+"""Build libtamd.so (the gfx950 C-ABI kernel library) in-tree with hipcc.
+
+`python -m transformers_amd.build [--force]` or `transformers_amd.build.build()`.
+hipcc cross-compiles for gfx950 without a GPU; the resulting `.so` sits next to this
+file (git-ignored, but it travels with the tree to the GPU box).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+INCLUDE = HERE.parent / "include"
+LIB = HERE / "libtamd.so"
+OBJ_DIR = HERE / "_build"
+SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+         "-Wno-unused-result", "-I", str(CSRC), "-I", str(INCLUDE)]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X kernels cannot be built")
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(hipcc: str, src: Path, obj: Path, verbose: bool) -> None:
+    cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 and link libtamd.so.  Returns the library path."""
+    srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
+    deps = srcs + sorted(CSRC.glob("*.h")) + [INCLUDE / "tamd.h"]
+    stamp = OBJ_DIR / "stamp"
+    digest = _digest(deps)
+    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == digest:
+        return LIB
+    hipcc = _hipcc()
+    OBJ_DIR.mkdir(exist_ok=True)
+    objs = [OBJ_DIR / (s.stem + ".o") for s in srcs]
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        list(ex.map(lambda so: _compile(hipcc, so[0], so[1], verbose), zip(srcs, objs)))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    stamp.write_text(digest)
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,372 @@
+// attention.hip -- flash-style scaled-dot-product attention (forward + backward) for gfx950.
+//
+// Replaces, behind AttentionInterface (src/transformers/modeling_utils.py:5092-5130):
+//   eager_attention_forward + repeat_kv   models/llama/modeling_llama.py:179-213 (fp32 softmax, GQA)
+//   eager_attention_forward               models/bert/modeling_bert.py:111-136, models/clip/modeling_clip.py:259-277,
+//                                         models/gpt2/modeling_gpt2.py:54-72
+//   sdpa_attention_forward                integrations/sdpa_attention.py:84-170
+// Never materialises the [S,S] score matrix; GQA is native (no repeat_kv); causal tiles above the
+// diagonal are skipped; output is written directly in the [B,S,H,D] layout the callers reshape.
+//
+// Forward structure (per workgroup = 4 waves = 128 query rows of one (batch, head); 64-key K/V tiles):
+//   * K and V tiles stream global -> LDS with global_load_lds_dwordx4, double buffered; the LDS image is
+//     lane-linear so the bank swizzle lives on the source address (cdna_hip_programming.md rule 21):
+//       [64][D] tile, 16-byte slot' = slot ^ row_swz(row): conflict-free for BOTH the ds_read_b128 row
+//       fragments (K in QK^T) and the ds_read_b64_tr_b16 transposing reads (V in PV, K/Q/dO in backward)
+//   * S^T = K.Q^T is computed "swapped" (MFMA A=K fragment, B=Q fragment held in registers), so a lane owns
+//     one query column: the softmax row max / sum are lane-local plus ONE v_permlane32_swap, and the
+//     exponentiated P registers are, without any data movement, the B operand of O^T += V^T.P^T
+//     (the key order of the P registers is matched by the addresses of the transposing V reads);
+//   * fp32 online softmax in the exp2 domain (scale*log2e folded), fp32 accumulators, P rounded to the
+//     storage dtype before PV exactly as the reference rounds softmax(...).to(query.dtype);
+//   * the O tile is normalised, rounded, staged through LDS and written as full rows.
+#include "common.h"
+
+namespace tamd {
+
+constexpr int kAttnThreads = 256;
+constexpr int kQB = 128;   // query rows per workgroup (32 per wave)
+constexpr int kKB = 64;    // keys per tile
+
+__device__ __attribute__((aligned(16))) static const unsigned int g_zero16a[4] = {0u, 0u, 0u, 0u};
+
+struct AttnArgs {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  float* lse;
+  const uint8_t* key_valid;
+  int batch, heads_q, heads_kv, seq_q, seq_k;
+  int64_t qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh;
+  float scale_log2;  // scale * log2(e)
+  int nqt;           // query tiles per (b, h)
+  int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
+};
+
+// One swizzle serves both read patterns of a [rows][D] tile (rows = keys or queries):
+//   ds_read_b128 of 16 distinct rows at one logical slot  -> needs a bijection of the row bits onto slots,
+//   ds_read_b64_tr_b16 of 4 consecutive rows x 64 B       -> needs the low row bits on the 64-byte window bits.
+template <int D>
+__device__ __forceinline__ int row_swz(int row) {
+  return D == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
+}
+
+// one [64][D] tile: global rows `key0 + r` (stride `stride` elements) -> LDS at tile_off, swizzled by SWZ
+template <typename T, int D>
+__device__ __forceinline__ void issue_kv_tile(const T* __restrict__ base, int64_t stride, int key0, int nkeys,
+                                              char* smem, unsigned tile_off, int wave, int lane) {
+  constexpr int ROWB = D * 2;            // bytes per row
+  constexpr int SLOTS = ROWB / 16;       // 16-byte slots per row
+  constexpr int RPI = 1024 / ROWB;       // rows per wave instruction
+  constexpr int NI = (kKB * ROWB) / 1024 / 4;  // instructions per wave (4 waves)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int inst = wave * NI + i;
+    const int r = inst * RPI + lane / SLOTS;
+    const int p = lane % SLOTS;
+    const int s = p ^ row_swz<D>(r);
+    const int key = key0 + r;
+    const void* src = (key < nkeys) ? (const void*)(base + (int64_t)key * stride + s * 8) : (const void*)g_zero16a;
+    glds16(src, smem, tile_off + (unsigned)inst * 1024u);
+  }
+}
+
+template <typename T, int D, bool CAUSAL, bool HAS_MASK>
+__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
+  constexpr int ROWB = D * 2;
+  constexpr int TILEB = kKB * ROWB;       // one K or V tile
+  constexpr int KS = D / 16;              // QK^T k-steps
+  constexpr int DT = D / 32;              // output d-tiles
+  constexpr int OROWB = ROWB + 16;        // padded staging row
+  TAMD_DYN_SMEM(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // ---- work decode: (b, h, query tile); heavy (late) causal tiles first, K/V-sharing blocks on one XCD
+  const int group = a.heads_q / a.heads_kv;
+  int b, h, qt;
+  {
+    const int bid = blockIdx.x;
+    const int per_grp = a.nqt * group;
+    int g, within;
+    if (a.xcd_map) {
+      const int xcd = bid & 7, j = bid >> 3;
+      g = (j / per_grp) * 8 + xcd;
+      within = j % per_grp;
+    } else {
+      g = bid / per_grp;
+      within = bid % per_grp;
+    }
+    b = g / a.heads_kv;
+    const int hkv = g % a.heads_kv;
+    h = hkv * group + within % group;
+    qt = a.nqt - 1 - within / group;
+  }
+  const int hkv = h / group;
+  const int q0 = qt * kQB;
+  const int off = a.seq_k - a.seq_q;  // causal: key k visible to query s iff k <= s + off
+  const T* Q = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.qsb + (int64_t)h * a.qsh;
+  const T* K = reinterpret_cast<const T*>(a.k) + (int64_t)b * a.ksb + (int64_t)hkv * a.ksh;
+  const T* V = reinterpret_cast<const T*>(a.v) + (int64_t)b * a.vsb + (int64_t)hkv * a.vsh;
+
+  // ---- Q fragments (MFMA B operand): Q[q = qw0 + l31][d = ks*16 + hi*8 .. +7]
+  const int qw0 = q0 + wave * 32;
+  const int qrow = qw0 + l31;
+  u32x4 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = (qrow < a.seq_q) ? ld16(Q + (int64_t)qrow * a.qss + ks * 16 + hi * 8) : u32x4{0, 0, 0, 0};
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int kend = a.seq_k;
+  if (CAUSAL) {
+    const int lim = q0 + kQB - 1 + off + 1;  // keys visible to the last query row of the block
+    kend = lim < kend ? lim : kend;
+    if (kend < 0) kend = 0;
+  }
+  const int nkt = (kend + kKB - 1) / kKB;
+
+  auto issue = [&](int t, int buf) {
+    const unsigned k_off = (unsigned)buf * 2u * TILEB, v_off = k_off + TILEB;
+    issue_kv_tile<T, D>(K, a.kss, t * kKB, a.seq_k, smem, k_off, wave, lane);
+    issue_kv_tile<T, D>(V, a.vss, t * kKB, a.seq_k, smem, v_off, wave, lane);
+  };
+  if (nkt > 0) issue(0, 0);
+  wait_vmcnt0();
+  block_sync();
+
+  for (int t = 0; t < nkt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nkt) issue(t + 1, cur ^ 1);
+    const unsigned k_off = (unsigned)cur * 2u * TILEB, v_off = k_off + TILEB;
+    const int kt0 = t * kKB;
+    // wave-uniform skip: every key of the tile is above the diagonal for all 32 rows of this wave
+    const bool wave_active = !CAUSAL || (kt0 <= qw0 + 31 + off);
+    if (wave_active) {
+      // ---- S^T tile [64 keys][32 q] = K . Q^T   (two 32-key sub-tiles)
+      f32x16 s[2];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+        const int krow = sub * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int slot = (ks * 2 + hi) ^ row_swz<D>(krow);
+          const u32x4 kf = lds_read16(smem, k_off + (unsigned)krow * ROWB + (unsigned)slot * 16u);
+          s[sub] = mfma32<T>(kf, qf[ks], s[sub]);
+        }
+      }
+      // ---- scale to the log2 domain, mask
+      unsigned long long vmask = ~0ull;
+      if (HAS_MASK) {
+        const int kp = kt0 + lane;
+        const bool ok = kp < a.seq_k && a.key_valid[(int64_t)b * a.seq_k + kp] != 0;
+        vmask = ballot64(ok);
+      }
+      const bool need_mask = HAS_MASK || (kt0 + kKB > a.seq_k) || (CAUSAL && (kt0 + kKB - 1 > qw0 + off));
+      float mx = -INFINITY;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float x = s[sub][r] * a.scale_log2;
+          if (need_mask) {
+            const int kl = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // key index inside the tile
+            const int kp = kt0 + kl;
+            bool vis = kp < a.seq_k;
+            if (CAUSAL) vis = vis && (kp <= qrow + off);
+            if (HAS_MASK) vis = vis && ((vmask >> kl) & 1ull);
+            x = vis ? x : -INFINITY;
+          }
+          s[sub][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      mx = fmaxf(mx, swap32_f32(mx));  // the other half-wave holds the other 32 keys of this query
+      const float m_new = fmaxf(m_run, mx);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at 0
+      const float alpha = fast_exp2(m_run - m_use);            // m_run = -inf -> 0
+      m_run = m_new;
+      float psum = 0.f;
+      u32x4 pf[4];  // P^T as MFMA B operand: step j covers registers 8*(j&1).. of sub-tile j>>1
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // the reference rounds softmax probabilities to the storage dtype before P.V; the row sum
+          // uses the unrounded fp32 values like softmax(dtype=float32) does.
+          p[r] = fast_exp2(s[sub][r] - m_use);
+          psum += p[r];
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+          pf[sub * 2 + st] = u32x4{pack2<T>(p[8 * st + 0], p[8 * st + 1]), pack2<T>(p[8 * st + 2], p[8 * st + 3]),
+                                   pack2<T>(p[8 * st + 4], p[8 * st + 5]), pack2<T>(p[8 * st + 6], p[8 * st + 7])};
+      }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]
+      // step (sub, st): P registers r = 8*st + j  <->  key = sub*32 + 16*st + 8*(j>>2) + 4*hi + (j&3)
+      const int kq = (lane & 15) >> 2;  // row of the 4-key block this lane addresses
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int col = dt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+        const unsigned inner = (unsigned)(col & 7) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kb = (j >> 1) * 32 + (j & 1) * 16 + 4 * hi + kq;
+          const int s0 = (col >> 3) ^ row_swz<D>(kb);
+          const int s1 = (col >> 3) ^ row_swz<D>(kb + 8);
+          const u32x2 lo = lds_read8_tr16(smem, v_off + (unsigned)kb * ROWB + (unsigned)s0 * 16u + inner);
+          const u32x2 hi2 = lds_read8_tr16(smem, v_off + (unsigned)(kb + 8) * ROWB + (unsigned)s1 * 16u + inner);
+          oacc[dt] = mfma32<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]}, pf[j], oacc[dt]);
+        }
+      }
+    }
+    wait_vmcnt0();
+    block_sync();
+  }
+
+  // ---- finalise: l over both half-waves, normalise, LSE, stage O through LDS, row-wise stores
+  l_run += swap32_f32(l_run);
+  const float inv_l = (l_run > 0.f) ? 1.f / l_run : 0.f;
+  if (a.lse != nullptr && hi == 0 && qrow < a.seq_q) {
+    const float lse = (l_run > 0.f) ? (m_run + fast_log2(l_run)) * 0.69314718055994530942f : INFINITY;
+    a.lse[((int64_t)b * a.heads_q + h) * a.seq_q + qrow] = lse;
+  }
+  const unsigned st_off = (unsigned)wave * (32u * OROWB);
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int d0 = dt * 32 + 8 * qd + 4 * hi;
+      const u32x2 pk = {pack2<T>(oacc[dt][qd * 4 + 0] * inv_l, oacc[dt][qd * 4 + 1] * inv_l),
+                        pack2<T>(oacc[dt][qd * 4 + 2] * inv_l, oacc[dt][qd * 4 + 3] * inv_l)};
+      lds_write8(smem, st_off + (unsigned)l31 * OROWB + (unsigned)d0 * 2u, pk);
+    }
+  wave_lockstep_point();
+  T* O = reinterpret_cast<T*>(a.o) + (int64_t)b * a.osb + (int64_t)h * a.osh;
+  constexpr int SLOTS = ROWB / 16;      // 16 (D=128) or 8 (D=64) lanes per row
+  constexpr int RPI = 64 / SLOTS;       // rows per wave instruction
+#pragma unroll
+  for (int it = 0; it < 32 / RPI; ++it) {
+    const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
+    const int qr = qw0 + row;
+    const u32x4 v = lds_read16(smem, st_off + (unsigned)row * OROWB + (unsigned)slot * 16u);
+    if (qr < a.seq_q) st16(O + (int64_t)qr * a.oss + slot * 8, v);
+  }
+}
+
+}  // namespace tamd
+
+#include "attention_bwd.inc"
+
+using namespace tamd;
+
+namespace {
+
+template <typename T, int D>
+int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
+  const size_t smem = (size_t)4 * kKB * D * 2;  // 2 buffers x (K + V); also covers the O staging (4 x 32 x (2D+16))
+  dim3 grid((unsigned)(a.nqt * a.heads_q * a.batch)), block(kAttnThreads);
+  const bool mask = a.key_valid != nullptr;
+  if (causal) {
+    if (mask)
+      hipLaunchKernelGGL((attn_fwd_kernel<T, D, true, true>), grid, block, smem, s, a);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<T, D, true, false>), grid, block, smem, s, a);
+  } else {
+    if (mask)
+      hipLaunchKernelGGL((attn_fwd_kernel<T, D, false, true>), grid, block, smem, s, a);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<T, D, false, false>), grid, block, smem, s, a);
+  }
+  return launch_status();
+}
+
+int attn_check(const tamd_attn_params* p) {
+  if (!p || !p->q || !p->k || !p->v || !p->o) return TAMD_E_NULL;
+  if (p->head_dim != 64 && p->head_dim != 128) return TAMD_E_SHAPE;
+  if (p->batch <= 0 || p->heads_q <= 0 || p->heads_kv <= 0 || p->seq_q <= 0 || p->seq_k <= 0) return TAMD_E_SHAPE;
+  if (p->heads_q % p->heads_kv != 0) return TAMD_E_SHAPE;
+  if (p->dtype != TAMD_BF16 && p->dtype != TAMD_F16) return TAMD_E_DTYPE;
+  const int64_t strides[] = {p->q_stride_b, p->q_stride_s, p->q_stride_h, p->k_stride_b, p->k_stride_s, p->k_stride_h,
+                             p->v_stride_b, p->v_stride_s, p->v_stride_h, p->o_stride_b, p->o_stride_s, p->o_stride_h};
+  for (int64_t st : strides)
+    if (st % 8 != 0) return TAMD_E_ALIGN;
+  if (!aligned16(p->q) || !aligned16(p->k) || !aligned16(p->v) || !aligned16(p->o)) return TAMD_E_ALIGN;
+  return TAMD_OK;
+}
+
+AttnArgs make_args(const tamd_attn_params* p) {
+  AttnArgs a;
+  a.q = p->q;
+  a.k = p->k;
+  a.v = p->v;
+  a.o = p->o;
+  a.lse = p->lse;
+  a.key_valid = p->key_valid;
+  a.batch = (int)p->batch;
+  a.heads_q = (int)p->heads_q;
+  a.heads_kv = (int)p->heads_kv;
+  a.seq_q = (int)p->seq_q;
+  a.seq_k = (int)p->seq_k;
+  a.qsb = p->q_stride_b;
+  a.qss = p->q_stride_s;
+  a.qsh = p->q_stride_h;
+  a.ksb = p->k_stride_b;
+  a.kss = p->k_stride_s;
+  a.ksh = p->k_stride_h;
+  a.vsb = p->v_stride_b;
+  a.vss = p->v_stride_s;
+  a.vsh = p->v_stride_h;
+  a.osb = p->o_stride_b;
+  a.oss = p->o_stride_s;
+  a.osh = p->o_stride_h;
+  a.scale_log2 = p->scale * 1.44269504088896340736f;
+  a.nqt = (int)ceil_div(p->seq_q, kQB);
+  a.xcd_map = ((p->batch * p->heads_kv) % 8 == 0) ? 1 : 0;
+  return a;
+}
+
+}  // namespace
+
+extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream) {
+  const int chk = attn_check(p);
+  if (chk != TAMD_OK) return chk;
+  const AttnArgs a = make_args(p);
+  hipStream_t s = TAMD_STREAM(stream);
+  if (p->head_dim == 128) {
+    TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 128>(a, p->causal != 0, s)));
+  } else {
+    TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 64>(a, p->causal != 0, s)));
+  }
+  return TAMD_E_DTYPE;
+}
+
+extern "C" int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream) {
+  if (!p) return TAMD_E_NULL;
+  const int chk = attn_check(&p->fwd);
+  if (chk != TAMD_OK) return chk;
+  if (!p->dout || !p->dq || !p->dk || !p->dv || !p->delta || !p->fwd.lse) return TAMD_E_NULL;
+  if (!aligned16(p->dout) || !aligned16(p->dq) || !aligned16(p->dk) || !aligned16(p->dv)) return TAMD_E_ALIGN;
+  const AttnArgs a = make_args(&p->fwd);
+  hipStream_t s = TAMD_STREAM(stream);
+  if (p->fwd.head_dim == 128) {
+    TAMD_DISPATCH_HALF(p->fwd.dtype, return (attn_bwd_launch<T, 128>(a, p, p->fwd.causal != 0, s)));
+  } else {
+    TAMD_DISPATCH_HALF(p->fwd.dtype, return (attn_bwd_launch<T, 64>(a, p, p->fwd.causal != 0, s)));
+  }
+  return TAMD_E_DTYPE;
+}

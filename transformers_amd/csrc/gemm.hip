@@ -1,0 +1,315 @@
+// gemm.hip -- bf16/f16 MFMA GEMM for gfx950 with fused epilogues.
+//
+//   C[M,N] = epilogue( A[M,K] . B[N,K]^T )        fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16}
+//
+// replaces every nn.Linear on the hot path (reference call sites, src/transformers/):
+//   models/llama/modeling_llama.py:254-256 (q/k/v), :280 (o_proj), :174-176 (gate/up/down),
+//   models/bert/modeling_bert.py:175-177, :289, :334, :347, pytorch_utils.py:117-121 (GPT-2 Conv1D),
+//   models/clip/modeling_clip.py:304-333, :346-350, models/llava/modeling_llava.py:102-106,
+// and, through the two layout flags, both backward products of a linear layer
+//   dX[M,K'] = dY[M,N'] . W[N',K']      -> TAMD_GEMM_B_KN  (B stored [K,N])
+//   dW[N',K'] = dY[M,N']^T . X[M,K']    -> TAMD_GEMM_A_KM | TAMD_GEMM_B_KN (both stored k-major)
+// so no operand is ever transposed through HBM.
+//
+// Structure (cdna_hip_programming.md §5, "glds, 2 LDS buffers, BK=64" tier):
+//   * 256x256 output tile per 512-thread workgroup (8 waves as 2(M) x 4(N), 128x64 per wave,
+//     8 accumulators of 32x32 = 128 acc registers), BK = 64, one barrier per K tile;
+//   * both operand tiles stream HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip),
+//     double buffered (2 x 64 KiB);
+//   * LDS images are lane-linear (a glds requirement), so the bank-conflict swizzle is applied to
+//     the per-lane SOURCE address and undone on the fragment read (guide rule 21):
+//       k-contiguous operand  [256 rows][64 k]: 16-B slot' = slot ^ ((row>>1)&7)   -> ds_read_b128 conflict-free
+//       k-major operand       [64 k][256 cols]: 16-B slot' = slot ^ ((k&3)<<2)     -> ds_read_b64_tr_b16 conflict-free
+//   * the MFMA is issued "swapped" (A-operand = B/W fragment, B-operand = A/X fragment) so each lane
+//     ends up with 4 consecutive output columns of one output row; the epilogue rounds to the storage
+//     dtype, stages the wave's 128x64 tile in LDS and writes full 128-byte row segments;
+//   * workgroup ids are remapped XCD-aware (8 XCDs, private L2s): each XCD owns a contiguous chunk
+//     of a grouped (8 M-tiles wide) tile order, so concurrently resident tiles share A/B panels in L2.
+#include "common.h"
+
+namespace tamd {
+
+constexpr int kBM = 256, kBN = 256, kBK = 64;
+constexpr int kGemmThreads = 512;
+constexpr int kTileBytes = 256 * 64 * 2;             // one operand tile, 32 KiB
+constexpr int kBufBytes = 2 * kTileBytes;            // A tile + B tile
+constexpr int kStageRowBytes = 64 * 2 + 16;          // epilogue staging row (64 cols + 16 B pad)
+constexpr int kStageWaveBytes = 128 * kStageRowBytes;
+constexpr int kGemmSmem = (2 * kBufBytes > 8 * kStageWaveBytes) ? 2 * kBufBytes : 8 * kStageWaveBytes;
+
+__device__ __attribute__((aligned(16))) static const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  void* C;
+  const void* bias;
+  const void* R;
+  int64_t M, N, K, lda, ldb, ldc, ldr;
+  int tiles_m, tiles_n;
+};
+
+// ---- operand tile loaders -------------------------------------------------------------------
+// K-contiguous operand: global [rows, K] (row stride ld); LDS [256][64] with slot swizzle.
+template <typename T>
+__device__ __forceinline__ void issue_tile_rowmajor(const T* __restrict__ G, int64_t ld, int64_t row0, int64_t nrows,
+                                                    int64_t k0, int64_t K, char* smem, unsigned tile_off, int wave,
+                                                    int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int p = lane & 7;
+    const int s = p ^ ((r >> 1) & 7);
+    const int64_t gr = row0 + r, gk = k0 + s * 8;
+    const void* src = (gr < nrows && gk < K) ? (const void*)(G + gr * ld + gk) : (const void*)g_zero16;
+    glds16(src, smem, tile_off + (unsigned)(wave * 4 + i) * 1024u);
+  }
+}
+// K-major operand: global [K, cols] (row stride ld); LDS [64][256] with slot swizzle.
+template <typename T>
+__device__ __forceinline__ void issue_tile_kmajor(const T* __restrict__ G, int64_t ld, int64_t col0, int64_t ncols,
+                                                  int64_t k0, int64_t K, char* smem, unsigned tile_off, int wave,
+                                                  int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kr = (wave * 4 + i) * 2 + (lane >> 5);
+    const int p = lane & 31;
+    const int s = p ^ ((kr & 3) << 2);
+    const int64_t gk = k0 + kr, gc = col0 + s * 8;
+    const void* src = (gk < K && gc < ncols) ? (const void*)(G + gk * ld + gc) : (const void*)g_zero16;
+    glds16(src, smem, tile_off + (unsigned)(wave * 4 + i) * 1024u);
+  }
+}
+
+// ---- fragment reads: 8 k-values (16 B) of one row/col of the tile for one lane ----------------
+// row-major tile: element (row, k) ; lane needs k = ks*16 + hi*8 .. +7
+__device__ __forceinline__ u32x4 frag_rowmajor(const char* smem, unsigned tile_off, int row, int ks, int hi) {
+  const int slot = (ks * 2 + hi) ^ ((row >> 1) & 7);
+  return lds_read16(smem, tile_off + (unsigned)row * 128u + (unsigned)slot * 16u);
+}
+// k-major tile: two transposing 8-byte reads; `col32` = first column of the 32-wide MFMA tile
+__device__ __forceinline__ u32x4 frag_kmajor(const char* smem, unsigned tile_off, int col32, int ks, int lane) {
+  const int hi = lane >> 5;
+  const int kq = (lane & 15) >> 2;  // row within the 4-row block
+  const int col = col32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int slot = (col >> 3) ^ (kq << 2);  // (k & 3) == kq : the other k terms are multiples of 4
+  const unsigned inner = (unsigned)(col & 7) * 2u;
+  const int kbase = ks * 16 + hi * 8 + kq;
+  const u32x2 lo = lds_read8_tr16(smem, tile_off + (unsigned)kbase * 512u + (unsigned)slot * 16u + inner);
+  const u32x2 hi2 = lds_read8_tr16(smem, tile_off + (unsigned)(kbase + 4) * 512u + (unsigned)slot * 16u + inner);
+  return u32x4{lo[0], lo[1], hi2[0], hi2[1]};
+}
+
+template <int ACT>
+__device__ __forceinline__ float gemm_act(float x) {
+  if (ACT == TAMD_ACT_GELU_ERF) return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  if (ACT == TAMD_ACT_GELU_TANH) return 0.5f * x * (1.f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x)));
+  if (ACT == TAMD_ACT_QUICK_GELU) return x / (1.f + __expf(-1.702f * x));
+  if (ACT == TAMD_ACT_SILU) return x / (1.f + __expf(-x));
+  return x;
+}
+
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT>
+__global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmArgs g) {
+  TAMD_DYN_SMEM(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  // ---- XCD-aware, grouped tile order
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, in_xcd = bid >> 3;
+  const int q = nwg >> 3, rr = nwg & 7;
+  const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + in_xcd;
+  constexpr int GROUP_M = 8;
+  const int group_size = GROUP_M * g.tiles_n;
+  const int grp = logical / group_size;
+  const int first_m = grp * GROUP_M;
+  const int gm = (g.tiles_m - first_m < GROUP_M) ? (g.tiles_m - first_m) : GROUP_M;
+  const int tile_m = first_m + (logical % group_size) % gm;
+  const int tile_n = (logical % group_size) / gm;
+  const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
+
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  const int nk = (int)((g.K + kBK - 1) / kBK);
+  auto issue = [&](int t, int buf) {
+    const int64_t k0 = (int64_t)t * kBK;
+    const unsigned a_off = (unsigned)buf * kBufBytes, b_off = a_off + kTileBytes;
+    if (A_KM)
+      issue_tile_kmajor<T>(A, g.lda, m0, g.M, k0, g.K, smem, a_off, wave, lane);
+    else
+      issue_tile_rowmajor<T>(A, g.lda, m0, g.M, k0, g.K, smem, a_off, wave, lane);
+    if (B_KN)
+      issue_tile_kmajor<T>(B, g.ldb, n0, g.N, k0, g.K, smem, b_off, wave, lane);
+    else
+      issue_tile_rowmajor<T>(B, g.ldb, n0, g.N, k0, g.K, smem, b_off, wave, lane);
+  };
+
+  issue(0, 0);
+  wait_vmcnt0();
+  block_sync();
+  for (int t = 0; t < nk; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nk) issue(t + 1, cur ^ 1);
+    const unsigned a_off = (unsigned)cur * kBufBytes, b_off = a_off + kTileBytes;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 xa[4], wb[2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        if (B_KN)
+          wb[ni] = frag_kmajor(smem, b_off, wn * 64 + ni * 32, ks, lane);
+        else
+          wb[ni] = frag_rowmajor(smem, b_off, wn * 64 + ni * 32 + l31, ks, hi);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        if (A_KM)
+          xa[mi] = frag_kmajor(smem, a_off, wm * 128 + mi * 32, ks, lane);
+        else
+          xa[mi] = frag_rowmajor(smem, a_off, wm * 128 + mi * 32 + l31, ks, hi);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma32<T>(wb[ni], xa[mi], acc[ni][mi]);
+    }
+    wait_vmcnt0();
+    block_sync();
+  }
+
+  // ---- epilogue: round -> stage the wave's 128(m) x 64(n) tile in LDS -> full-row global stores
+  // acc[ni][mi][r] = D[n = ni*32 + (r&3) + 8*(r>>2) + 4*hi][m = mi*32 + l31]
+  const unsigned st_off = (unsigned)wave * kStageWaveBytes;
+  const T* bias = reinterpret_cast<const T*>(g.bias);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int nl = ni * 32 + 8 * qd + 4 * hi;  // first of 4 consecutive local columns
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (EPI == TAMD_EPI_BIAS || EPI == TAMD_EPI_BIAS_ACT || (EPI == TAMD_EPI_RESIDUAL && bias != nullptr)) {
+        const int64_t gn = n0 + wn * 64 + nl;
+        if (gn < g.N) {  // N % 8 == 0 and nl % 4 == 0: the 4 columns are valid together
+          const u32x2 bq = ld8(bias + gn);
+          bv[0] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] & 0xffffu));
+          bv[1] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] >> 16));
+          bv[2] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] & 0xffffu));
+          bv[3] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] >> 16));
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[ni][mi][qd * 4 + e] + bv[e];
+          if (EPI == TAMD_EPI_BIAS_ACT) x = gemm_act<ACT>(round_through<T>(x));
+          v[e] = x;
+        }
+        const u32x2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+        lds_write8(smem, st_off + (unsigned)(mi * 32 + l31) * kStageRowBytes + (unsigned)nl * 2u, pk);
+      }
+    }
+  }
+  // wave-private staging region: the wave's own LDS writes are ordered before its reads below
+  wave_lockstep_point();
+  T* C = reinterpret_cast<T*>(g.C);
+  const T* R = reinterpret_cast<const T*>(g.R);
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 8 + (lane >> 3), slot = lane & 7;
+    const int64_t gm_ = m0 + wm * 128 + row, gn = n0 + wn * 64 + slot * 8;
+    u32x4 v = lds_read16(smem, st_off + (unsigned)row * kStageRowBytes + (unsigned)slot * 16u);
+    if (gm_ < g.M && gn < g.N) {
+      if (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) {
+        const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
+        float a[8], b[8];
+        unpack16<T>(v, a);
+        unpack16<T>(ld16(rp), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        v = pack16<T>(a);
+      }
+      st16(C + gm_ * g.ldc + gn, v);
+    }
+  }
+}
+
+template <typename T, bool A_KM, bool B_KN>
+static int gemm_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kGemmThreads);
+#define TAMD_G(E_, A_)                                                                                          \
+  hipLaunchKernelGGL((gemm_kernel<T, A_KM, B_KN, E_, A_>), grid, block, (size_t)kGemmSmem, s, g); \
+  return launch_status();
+  switch (epilogue) {
+    case TAMD_EPI_NONE: TAMD_G(TAMD_EPI_NONE, TAMD_ACT_NONE)
+    case TAMD_EPI_BIAS: TAMD_G(TAMD_EPI_BIAS, TAMD_ACT_NONE)
+    case TAMD_EPI_RESIDUAL: TAMD_G(TAMD_EPI_RESIDUAL, TAMD_ACT_NONE)
+    case TAMD_EPI_ACCUM: TAMD_G(TAMD_EPI_ACCUM, TAMD_ACT_NONE)
+    case TAMD_EPI_BIAS_ACT:
+      switch (act) {
+        case TAMD_ACT_GELU_ERF: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_GELU_ERF)
+        case TAMD_ACT_GELU_TANH: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_GELU_TANH)
+        case TAMD_ACT_QUICK_GELU: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_QUICK_GELU)
+        case TAMD_ACT_SILU: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_SILU)
+        default: return TAMD_E_ARG;
+      }
+    default: return TAMD_E_ARG;
+  }
+#undef TAMD_G
+}
+
+template <typename T>
+static int gemm_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
+  const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
+  if (!akm && !bkn) return gemm_launch_epi<T, false, false>(g, epilogue, act, s);
+  if (!akm && bkn) return gemm_launch_epi<T, false, true>(g, epilogue, act, s);
+  if (akm && bkn) return gemm_launch_epi<T, true, true>(g, epilogue, act, s);
+  return gemm_launch_epi<T, true, false>(g, epilogue, act, s);
+}
+
+}  // namespace tamd
+
+using namespace tamd;
+
+extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N,
+                         int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue,
+                         int act, int dtype, tamd_stream_t stream) {
+  if (!A || !B || !C) return TAMD_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0) return TAMD_E_SHAPE;
+  if ((K % 8) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return TAMD_E_SHAPE;
+  if ((flags & TAMD_GEMM_A_KM) && (M % 8)) return TAMD_E_SHAPE;
+  if (!aligned16(A) || !aligned16(B) || !aligned16(C)) return TAMD_E_ALIGN;
+  if ((epilogue == TAMD_EPI_BIAS || epilogue == TAMD_EPI_BIAS_ACT) && !bias) return TAMD_E_NULL;
+  if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) return TAMD_E_ALIGN;
+  if (epilogue == TAMD_EPI_RESIDUAL && (!R || (ldr % 8) || !aligned16(R))) return R ? TAMD_E_ALIGN : TAMD_E_NULL;
+  GemmArgs g;
+  g.A = A;
+  g.B = B;
+  g.C = C;
+  g.bias = bias;
+  g.R = R;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = ldc;
+  g.ldr = ldr;
+  g.tiles_m = (int)ceil_div(M, kBM);
+  g.tiles_n = (int)ceil_div(N, kBN);
+  TAMD_DISPATCH_HALF(dtype, return (gemm_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
+  return TAMD_E_DTYPE;
+}

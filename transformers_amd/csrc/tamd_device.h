@@ -1,0 +1,139 @@
+// tamd_device.h -- device-side hardware wrappers for the gfx950 (CDNA4 / MI355X) kernels.
+//
+// Everything the kernels need from the hardware goes through the thin inline
+// wrappers in this file (MFMA, LDS transpose reads, direct-to-LDS loads, lane
+// exchanges).  The kernels themselves are plain C++ over these wrappers and are
+// included as <tamd_device.h>; tests/hipemu/ puts a lane-accurate CPU model of
+// the same wrappers first on the include path and runs the *same kernel
+// sources* under an emulator in the CPU test-suite (tests/hipemu/README.md).
+//
+// Hardware model assumed here (MI355X_MICROARCH.md / cdna_hip_programming.md):
+//   * wave = 64 lanes, 4 SIMDs per CU, 256 CUs in 8 XCDs
+//   * v_mfma_f32_32x32x16_{bf16,f16}: A lane l holds A[l&31][8*(l>>5)..+7],
+//     B lane l holds B[8*(l>>5)..+7][l&31], C/D lane l reg r holds
+//     C[(r&3)+8*(r>>2)+4*(l>>5)][l&31]
+//   * v_mfma_f32_16x16x32_{bf16,f16}: A lane l holds A[l&15][8*(l>>4)..+7],
+//     B likewise, C/D lane l reg r holds C[4*(l>>4)+r][l&15]
+//   * ds_read_b64_tr_b16: inside each 16-lane group, lane i receives element
+//     (i&3) of the 8 bytes addressed by lane 4*j+(i>>2), for j = 0..3
+//   * v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src
+// tests/probe_hw.py checks every one of these statements on the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <tamd_types.h>
+
+namespace tamd {
+
+// ---------------------------------------------------------------- lane exchange
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f32(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor_f32(v, m));
+  return v;
+}
+// value of lane (l ^ 32): one v_permlane32_swap instead of a ds_bpermute
+__device__ __forceinline__ float swap32_f32(float v) {
+  unsigned int u = __builtin_bit_cast(unsigned int, v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  // r[0] (vdst): lanes 32-63 now hold the lower half's value; r[1] (src): lanes 0-31 the upper half's
+  unsigned int o = (lane_id() < 32) ? r[1] : r[0];
+  return __builtin_bit_cast(float, o);
+}
+// Half exchange of two registers: after the call, for lanes 0-31  a = own a, b = upper lanes' a;
+// for lanes 32-63 a = lower lanes' b, b = own b.   (v_permlane32_swap vdst=a', src=b')
+__device__ __forceinline__ void permlane32_swap(unsigned int& a, unsigned int& b) {
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+
+// 64-bit mask of the lanes whose predicate is true
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __ballot(pred); }
+
+// ---------------------------------------------------------------- MFMA
+template <typename T>
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 mfma32<bf16_t>(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+template <>
+__device__ __forceinline__ f32x16 mfma32<f16_t>(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                0);
+}
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<bf16_t>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0,
+                                                 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<f16_t>(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0,
+                                                0);
+}
+
+// ---------------------------------------------------------------- LDS
+// All LDS addressing in the MFMA kernels is by BYTE OFFSET into one dynamic
+// array (cdna_hip_programming.md G17: a single 16-byte aligned extern array).
+#define TAMD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+
+__device__ __forceinline__ u32x4 lds_read16(const char* smem, unsigned off) {
+  return *reinterpret_cast<const u32x4*>(smem + off);
+}
+__device__ __forceinline__ u32x2 lds_read8(const char* smem, unsigned off) {
+  return *reinterpret_cast<const u32x2*>(smem + off);
+}
+__device__ __forceinline__ void lds_write16(char* smem, unsigned off, u32x4 v) {
+  *reinterpret_cast<u32x4*>(smem + off) = v;
+}
+__device__ __forceinline__ void lds_write8(char* smem, unsigned off, u32x2 v) {
+  *reinterpret_cast<u32x2*>(smem + off) = v;
+}
+__device__ __forceinline__ float lds_read_f32(const char* smem, unsigned off) {
+  return *reinterpret_cast<const float*>(smem + off);
+}
+__device__ __forceinline__ void lds_write_f32(char* smem, unsigned off, float v) {
+  *reinterpret_cast<float*>(smem + off) = v;
+}
+// ds_read_b64_tr_b16: transposing 8-byte read (semantics in the file header).
+__device__ __forceinline__ u32x2 lds_read8_tr16(const char* smem, unsigned off) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + off));
+  return __builtin_bit_cast(u32x2, v);
+}
+// Direct-to-LDS 16-byte load: the wave writes 64 x 16 B = 1 KiB contiguous at
+// `smem + wave_base_off` (must be wave-uniform); each lane supplies its own
+// global source address.  Completion is tracked by vmcnt.
+__device__ __forceinline__ void glds16(const void* gsrc, char* smem, unsigned wave_base_off) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)(smem + wave_base_off), 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
+// A wave executes in lockstep on hardware, so LDS writes of one lane are visible to the other lanes of
+// the SAME wave at the next DS instruction (DS ops of a wave retire in order).  This marks such a point
+// (compiler scheduling fence only); the CPU model turns it into a real wave rendez-vous.
+__device__ __forceinline__ void wave_lockstep_point() { __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ void setprio_hi() { __builtin_amdgcn_s_setprio(1); }
+__device__ __forceinline__ void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
+
+// fast transcendental pieces
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __log2f(x); }
+
+}  // namespace tamd
