@@ -244,6 +244,13 @@ struct tamd_attn_bwd_params {
 };
 int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream);
 
+/* ------------------------------------------------------------------ diagnostics */
+
+/* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
+ * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
+ * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */
+int tamd_probe(const void* in, const void* in2, void* out, int which, int dtype, tamd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,75 @@
+"""Test configuration.
+
+`-m "not gpu"` : CPU suite -- oracle vs golden vectors, host logic, C-ABI surface, and the kernel sources
+                 executed under the lane-accurate CPU model in tests/hipemu (same .hip files, host clang).
+`-m gpu`       : parity tests proper -- the same test bodies through libtamd.so on an MI355X.
+"""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (runs the HIP kernels through the C-ABI)")
+
+
+class Env:
+    """What a kernel test needs: the device to allocate on and the backend context."""
+
+    def __init__(self, name):
+        self.name = name
+        self.device = torch.device("cuda:0") if name == "hip" else torch.device("cpu")
+        # the CPU model is ~1e5x slower than the GPU: tests scale their shapes with this flag
+        self.big = name == "hip"
+
+
+def _backend_params():
+    return [pytest.param("emu", id="emu"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=_backend_params())
+def env(request):
+    from transformers_amd import ops
+
+    name = request.param
+    if name == "hip":
+        if not torch.cuda.is_available():
+            pytest.fail("GPU test selected but no GPU is visible")
+        old = ops._set_backend(None)  # force the real HipBackend (raises if libtamd.so is missing)
+        try:
+            ops.backend()
+            yield Env("hip")
+        finally:
+            ops._set_backend(old)
+    else:
+        from emu_backend import emu_backend
+
+        with emu_backend():
+            yield Env("emu")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _build_library_once():
+    """Make sure libtamd.so exists (hipcc cross-compiles without a GPU); the emulator builds lazily."""
+    from transformers_amd import build
+
+    if not build.LIB.exists():
+        build.build()
+    yield
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def max_err(a, b):
+    return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()

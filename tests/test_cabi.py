@@ -1,0 +1,68 @@
+"""The C-ABI surface: every symbol declared in include/tamd.h is exported by libtamd.so and bound with
+the declared arity; argument errors are reported without launching anything (no GPU needed)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+from transformers_amd import _cabi, build
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = (ROOT / "include" / "tamd.h").read_text()
+
+
+def declared_functions():
+    text = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(tamd_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        out[m.group(1)] = n
+    return out
+
+
+def test_header_matches_binding_table():
+    decl = declared_functions()
+    assert set(decl) == set(_cabi.SIGNATURES), set(decl) ^ set(_cabi.SIGNATURES)
+    for name, n in decl.items():
+        assert len(_cabi.SIGNATURES[name][1]) == n, name
+
+
+def test_library_exports_every_symbol():
+    lib_path = build.build()
+    dll = ctypes.CDLL(str(lib_path))
+    for name in declared_functions():
+        assert hasattr(dll, name), f"{name} not exported by {lib_path}"
+    lib = _cabi.TamdLib(lib_path)
+    assert lib.tamd_abi_version() == _cabi.ABI_VERSION
+    assert lib.tamd_error_string(0) == b"ok"
+
+
+def test_argument_errors_do_not_launch():
+    lib = _cabi.TamdLib(build.build())
+    # NULL pointers / bad shapes are rejected before any launch (safe without a GPU)
+    assert lib.tamd_rmsnorm_fwd(None, None, None, None, None, None, 4, 64, 1e-5, 0, None) == -4
+    assert lib.tamd_gemm(None, None, None, None, None, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 0, None) == -4
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    aligned = ctypes.c_void_p((p.value + 15) & ~15)
+    assert lib.tamd_gemm(aligned, aligned, aligned, None, None, 8, 8, 7, 8, 8, 8, 0, 0, 0, 0, 0, None) == -2  # K % 8
+    assert lib.tamd_gemm(aligned, aligned, aligned, None, None, 8, 8, 8, 8, 8, 8, 0, 0, 0, 0, 2, None) == -1  # fp32
+    ap = _cabi.AttnParams()
+    ap.q = ap.k = ap.v = ap.o = aligned.value
+    ap.batch, ap.heads_q, ap.heads_kv, ap.seq_q, ap.seq_k, ap.head_dim = 1, 2, 1, 8, 8, 80
+    assert lib.tamd_attn_fwd(ctypes.byref(ap), None) == -2  # head_dim 80 unsupported
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+
+    from transformers_amd import ops
+
+    old = ops._set_backend(None)
+    try:
+        with pytest.raises(_cabi.TamdError):
+            ops.raw_rmsnorm_fwd(torch.randn(4, 64).bfloat16(), torch.ones(64).bfloat16(), 1e-5)
+    finally:
+        ops._set_backend(old)

@@ -1,0 +1,356 @@
+"""Op-level parity: every C-ABI kernel against an fp32 restatement of the reference formula on the
+SAME (storage-dtype-rounded) inputs.  The tolerance for floating-point ops is 1e-3 norm-relative
+unless the op's output rounding dominates (then 2^-8 relative = one bf16 ulp); integer / index paths
+(embedding gather, label handling) are bit-exact.  Each test runs twice: under the CPU execution model
+(`emu`, not gpu) and on the MI355X (`hip`, gpu)."""
+import math
+
+import pytest
+import torch
+
+from conftest import max_err, rel_err
+from transformers_amd import ops
+
+BF16_EPS = 2.0 ** -8
+
+
+def ref_rmsnorm(x, w, eps):  # models/llama/modeling_llama.py:62-67
+    xf = x.float()
+    var = xf.pow(2).mean(-1, keepdim=True)
+    return w * (xf * torch.rsqrt(var + eps)).to(x.dtype)
+
+
+@pytest.mark.parametrize("cols", [64, 768, 4096])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_rmsnorm_fwd_bwd(env, cols, dtype):
+    torch.manual_seed(0)
+    rows = 4096 if env.big else 9
+    x = torch.randn(rows, cols).to(dtype).to(env.device).requires_grad_(True)
+    w = (torch.rand(cols) + 0.5).to(dtype).to(env.device).requires_grad_(True)
+    y = ops.rmsnorm(x, w, 1e-5)
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    yr = ref_rmsnorm(xr, wr, 1e-5)
+    # identical rounding points -> essentially bit-exact (fp32 summation order may flip a last bit)
+    if dtype != torch.float32:
+        assert (y != yr).float().mean().item() < 2e-3
+    assert rel_err(y, yr) < 1e-3
+    g = torch.randn_like(y)
+    y.backward(g)
+    yr.float().backward(g.float())
+    tol = 1e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(x.grad, xr.grad) < tol
+    assert rel_err(w.grad, wr.grad) < (1e-4 if dtype == torch.float32 else 1.5e-2)
+
+
+def test_rmsnorm_fused_residual(env):
+    torch.manual_seed(1)
+    rows, cols = (2048, 4096) if env.big else (7, 512)
+    x = torch.randn(rows, cols).bfloat16().to(env.device)
+    r = torch.randn(rows, cols).bfloat16().to(env.device)
+    w = (torch.rand(cols) + 0.5).bfloat16().to(env.device)
+    y, h, rstd = ops.raw_rmsnorm_fwd(x, w, 1e-6, residual=r)
+    h_ref = x + r
+    assert torch.equal(h, h_ref)  # bit-exact residual add
+    assert rel_err(y, ref_rmsnorm(h_ref, w, 1e-6)) < 1e-3
+    dy, dres = torch.randn_like(y), torch.randn_like(y)
+    dx, dw = ops.raw_rmsnorm_bwd(dy, h, w, rstd, dres=dres)
+    hr = h_ref.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    yr = wr * (hr * torch.rsqrt(hr.pow(2).mean(-1, keepdim=True) + 1e-6))
+    yr.backward(dy.float())
+    assert rel_err(dx, hr.grad + dres.float()) < 6e-3
+    assert rel_err(dw, wr.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("cols", [768, 1024])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_layernorm_fwd_bwd(env, cols, with_res):
+    torch.manual_seed(2)
+    rows = 4096 if env.big else 6
+    dev = env.device
+    x = torch.randn(rows, cols).bfloat16().to(dev).requires_grad_(True)
+    r = torch.randn(rows, cols).bfloat16().to(dev).requires_grad_(True) if with_res else None
+    w = (torch.rand(cols) + 0.5).bfloat16().to(dev).requires_grad_(True)
+    b = torch.randn(cols).bfloat16().to(dev).requires_grad_(True)
+    out = ops.layernorm(x, w, b, 1e-12, residual=r)
+    y = out[0] if with_res else out
+    xr, wr, br = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    rr = r.detach().clone().requires_grad_(True) if with_res else None
+    hin = xr + rr if with_res else xr
+    yr = torch.nn.functional.layer_norm(hin.float(), (cols,), wr.float(), br.float(), 1e-12)
+    assert rel_err(y, yr) < 3e-3  # one bf16 output rounding
+    g = torch.randn_like(y)
+    y.backward(g)
+    yr.backward(g.float())
+    assert rel_err(x.grad, xr.grad) < 6e-3
+    if with_res:
+        assert rel_err(r.grad, rr.grad) < 6e-3
+    assert rel_err(w.grad, wr.grad) < 1.5e-2
+    assert rel_err(b.grad, br.grad) < 1.5e-2
+
+
+def ref_rope(q, cos, sin):  # modeling_llama.py:130-160, q [B,S,H,D], cos [B|1,S,D]
+    def rot(x):
+        x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+        return torch.cat((-x2, x1), dim=-1)
+
+    c, s = cos.unsqueeze(2), sin.unsqueeze(2)
+    return (q * c) + (rot(q) * s)
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_rope_bit_exact_and_adjoint(env, d):
+    torch.manual_seed(3)
+    b, s, hq, hkv = (4, 512, 8, 2) if env.big else (2, 10, 3, 1)
+    dev = env.device
+    row = (hq + 2 * hkv) * d
+    qkv = torch.randn(b, s, row).bfloat16().to(dev)
+    inv = 1.0 / (500000.0 ** (torch.arange(0, d, 2).float() / d))
+    fr = torch.arange(s).float()[:, None] * inv[None]
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos()[None].bfloat16().to(dev), emb.sin()[None].bfloat16().to(dev)
+    out = qkv.clone()
+    ops.raw_rope_(out.view(b * s, row), cos, sin, s, hq + hkv, d)
+    ref = qkv.clone()
+    n = (hq + hkv) * d
+    ref[..., :n] = ref_rope(qkv[..., :n].view(b, s, hq + hkv, d), cos, sin).reshape(b, s, n)
+    assert torch.equal(out, ref)  # same bf16 rounding points as the reference -> bit-exact; v untouched
+    # adjoint: <R x, y> == <x, R^T y> (fp32 accumulate; roundings bound the slack)
+    y = torch.randn(b, s, row).bfloat16().to(dev)
+    rty = y.clone()
+    ops.raw_rope_(rty.view(b * s, row), cos, sin, s, hq + hkv, d, conj=True)
+    lhs = (out[..., :n].float() * y[..., :n].float()).sum()
+    rhs = (qkv[..., :n].float() * rty[..., :n].float()).sum()
+    assert abs(lhs - rhs).item() < 2e-2 * max(1.0, lhs.abs().item())
+
+
+def test_embedding_bit_exact_and_scatter(env):
+    torch.manual_seed(4)
+    vocab, dim, n = (32000, 4096, 8192) if env.big else (50, 64, 40)
+    dev = env.device
+    table = torch.randn(vocab, dim).bfloat16().to(dev)
+    ids = torch.randint(0, vocab, (2, n // 2)).to(dev)
+    ids[0, :3] = 7  # repeated ids
+    out = ops.raw_embedding_fwd(ids, table)
+    assert torch.equal(out, table[ids])
+    dout = torch.randn(2, n // 2, dim).bfloat16().to(dev)
+    dt = ops.raw_embedding_bwd(ids, dout, vocab, padding_idx=None)
+    ref = torch.zeros(vocab, dim, dtype=torch.float32, device=dev).index_add_(0, ids.view(-1), dout.view(-1, dim).float())
+    assert rel_err(dt, ref) < 3e-3
+    untouched = torch.ones(vocab, dtype=torch.bool, device=dev)
+    untouched[ids.view(-1)] = False
+    assert (dt[untouched] == 0).all()
+    dt2 = ops.raw_embedding_bwd(ids, dout, vocab, padding_idx=7)
+    assert (dt2[7] == 0).all()
+
+
+def test_swiglu(env):
+    torch.manual_seed(5)
+    t, inter = (4096, 14336) if env.big else (5, 256)
+    dev = env.device
+    gu = torch.randn(t, 2 * inter).bfloat16().to(dev)
+    act = ops.raw_swiglu_fwd(gu)
+    g, u = gu[:, :inter], gu[:, inter:]
+    ref = torch.nn.functional.silu(g) * u  # the reference's own bf16 op sequence (modeling_llama.py:175)
+    assert (act != ref).float().mean().item() < 1e-3
+    assert rel_err(act, torch.nn.functional.silu(g.float()) * u.float()) < 4e-3
+    dact = torch.randn(t, inter).bfloat16().to(dev)
+    dgu, act2 = ops.raw_swiglu_bwd(gu, dact, want_act=True)
+    assert torch.equal(act2, act)
+    gf, uf = g.float().requires_grad_(True), u.float().requires_grad_(True)
+    (torch.nn.functional.silu(gf) * uf).backward(dact.float())
+    assert rel_err(dgu[:, :inter], gf.grad) < 6e-3
+    assert rel_err(dgu[:, inter:], uf.grad) < 6e-3
+
+
+@pytest.mark.parametrize("act", ["gelu", "gelu_new", "quick_gelu", "silu"])
+def test_bias_act(env, act):
+    from transformers.activations import ACT2FN
+
+    torch.manual_seed(6)
+    rows, cols = (2048, 3072) if env.big else (5, 64)
+    dev = env.device
+    x = torch.randn(rows, cols).bfloat16().to(dev)
+    b = torch.randn(cols).bfloat16().to(dev)
+    code = ops.ACT_CODES[act]
+    y = ops.raw_bias_act_fwd(x, b, code)
+    zf = (x + b).float().requires_grad_(True)
+    yr = ACT2FN[act](zf)
+    assert rel_err(y, yr) < 4e-3
+    dy = torch.randn_like(y)
+    dx = ops.raw_bias_act_bwd(x, b, dy, code)
+    yr.backward(dy.float())
+    assert rel_err(dx, zf.grad) < 6e-3
+
+
+def test_add_colsum_transpose(env):
+    torch.manual_seed(7)
+    rows, cols = (4096, 1024) if env.big else (72, 136)
+    dev = env.device
+    a = torch.randn(rows, cols).bfloat16().to(dev)
+    b = torch.randn(rows, cols).bfloat16().to(dev)
+    assert torch.equal(ops.raw_add(a, b), a + b)
+    assert rel_err(ops.raw_colsum(a), a.float().sum(0)) < 4e-3
+    assert torch.equal(ops.raw_transpose(a), a.t().contiguous())
+
+
+def test_cross_entropy(env):
+    torch.manual_seed(8)
+    t, v = (4096, 128256) if env.big else (6, 1000)
+    dev = env.device
+    logits = (torch.randn(t, v) * 2).bfloat16().to(dev).requires_grad_(True)
+    labels = torch.randint(0, v, (t,)).to(dev)
+    labels[1] = -100
+    lsum = ops.CrossEntropyFn.apply(logits, labels, -100)
+    lf = logits.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, labels, ignore_index=-100, reduction="sum")
+    assert abs(lsum.item() - ref.item()) < 1e-4 * abs(ref.item())
+    (lsum / 5).backward()
+    (ref / 5).backward()
+    assert rel_err(logits.grad, lf.grad) < 4e-3
+    assert (logits.grad[1] == 0).all()
+
+
+GEMM_SHAPES_SMALL = [(256, 256, 64), (264, 248, 136), (130, 520, 72)]
+GEMM_SHAPES_BIG = [(4096, 4096, 4096), (8192, 6144, 4096), (1000, 1032, 520), (4096, 14336, 4096)]
+
+
+@pytest.mark.parametrize("layout", ["nt", "b_kn", "a_km|b_kn", "a_km"])
+def test_gemm_layouts(env, layout):
+    torch.manual_seed(9)
+    dev = env.device
+    for (m, n, k) in (GEMM_SHAPES_BIG if env.big else GEMM_SHAPES_SMALL):
+        if "a_km" in layout and m % 8:
+            continue
+        x = torch.randn(m, k).bfloat16().to(dev)
+        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+        ref = x.float() @ w.float().t()
+        a = x.t().contiguous() if "a_km" in layout else x
+        b = w.t().contiguous() if "b_kn" in layout else w
+        c = ops.raw_gemm(a, b, a_km="a_km" in layout, b_kn="b_kn" in layout)
+        assert rel_err(c, ref) < 4e-3, (layout, m, n, k)  # bf16 output rounding only (fp32 accumulation)
+
+
+def test_gemm_epilogues(env):
+    torch.manual_seed(10)
+    dev = env.device
+    m, n, k = (2048, 3072, 768) if env.big else (136, 264, 72)
+    x = torch.randn(m, k).bfloat16().to(dev)
+    w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+    bias = torch.randn(n).bfloat16().to(dev)
+    res = torch.randn(m, n).bfloat16().to(dev)
+    acc = x.float() @ w.float().t()
+    c = ops.raw_gemm(x, w, bias=bias, epilogue=ops.EPI_BIAS)
+    assert rel_err(c, acc + bias.float()) < 4e-3
+    c = ops.raw_gemm(x, w, residual=res, epilogue=ops.EPI_RESIDUAL)
+    assert rel_err(c, acc.bfloat16().float() + res.float()) < 4e-3
+    c = ops.raw_gemm(x, w, bias=bias, epilogue=ops.EPI_BIAS_ACT, act=ops.ACT_GELU_ERF)
+    assert rel_err(c, torch.nn.functional.gelu((acc + bias.float()).bfloat16().float())) < 5e-3
+    out = res.clone()
+    ops.raw_gemm(x, w, epilogue=ops.EPI_ACCUM, out=out)
+    assert rel_err(out, acc.bfloat16().float() + res.float()) < 4e-3
+
+
+def test_linear_autograd(env):
+    torch.manual_seed(11)
+    dev = env.device
+    b, s, k, n = (4, 512, 1024, 2048) if env.big else (2, 20, 72, 136)
+    x = torch.randn(b, s, k).bfloat16().to(dev).requires_grad_(True)
+    w = (torch.randn(n, k) * 0.05).bfloat16().to(dev).requires_grad_(True)
+    bias = torch.randn(n).bfloat16().to(dev).requires_grad_(True)
+    y = ops.linear(x, w, bias, act=ops.ACT_GELU_ERF)
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, bias))
+    yr = torch.nn.functional.gelu(torch.nn.functional.linear(xr, wr, br))
+    assert rel_err(y, yr) < 6e-3
+    g = torch.randn_like(y)
+    y.backward(g)
+    yr.backward(g.float())
+    assert rel_err(x.grad, xr.grad) < 8e-3
+    assert rel_err(w.grad, wr.grad) < 8e-3
+    assert rel_err(bias.grad, br.grad) < 1.5e-2
+
+
+def ref_attention(q, k, v, scale, causal, key_valid):
+    """eager_attention_forward (modeling_llama.py:191-213) in fp32 on [B,S,H,D] tensors."""
+    b, s, h, d = q.shape
+    sk, hkv = k.shape[1], k.shape[2]
+    g = h // hkv
+    qf = q.float().permute(0, 2, 1, 3)
+    kf = k.float().permute(0, 2, 1, 3).repeat_interleave(g, 1)
+    vf = v.float().permute(0, 2, 1, 3).repeat_interleave(g, 1)
+    sc = qf @ kf.transpose(-1, -2) * scale
+    mask = torch.ones(s, sk, dtype=torch.bool, device=q.device)
+    if causal:
+        mask = torch.tril(mask, diagonal=sk - s)
+    mask = mask[None, None].expand(b, 1, s, sk).clone()
+    if key_valid is not None:
+        mask = mask & key_valid[:, None, None, :].bool()
+    sc = sc.masked_fill(~mask, float("-inf"))
+    return (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3)
+
+
+ATTN_CASES_SMALL = [
+    # b, sq, sk, hq, hkv, d, causal, mask
+    (1, 128, 128, 2, 1, 128, True, False),
+    (2, 200, 200, 4, 2, 64, False, True),
+    (1, 130, 130, 2, 2, 128, False, False),
+    (1, 577, 577, 1, 1, 64, False, False),   # CLIP-L/336: 577 tokens, no tile multiple
+    (2, 192, 192, 4, 1, 128, True, True),
+    (1, 96, 224, 2, 1, 64, True, False),     # seq_q != seq_k (causal offset)
+]
+ATTN_CASES_BIG = [
+    (2, 4096, 4096, 32, 8, 128, True, False),   # Llama-3-8B shape (batch reduced)
+    (4, 512, 512, 12, 12, 64, False, True),     # bert-base with padding
+    (1, 577, 577, 16, 16, 64, False, False),
+    (2, 1000, 1000, 8, 2, 128, True, True),
+    (1, 257, 1024, 4, 4, 64, True, False),
+]
+
+
+def test_attention_fwd_bwd(env):
+    dev = env.device
+    for case in (ATTN_CASES_BIG if env.big else ATTN_CASES_SMALL):
+        b, sq, sk, hq, hkv, d, causal, use_mask = case
+        torch.manual_seed(12)
+        q = torch.randn(b, sq, hq, d).bfloat16().to(dev).requires_grad_(True)
+        k = torch.randn(b, sk, hkv, d).bfloat16().to(dev).requires_grad_(True)
+        v = torch.randn(b, sk, hkv, d).bfloat16().to(dev).requires_grad_(True)
+        kv = None
+        if use_mask:
+            kv = torch.ones(b, sk, dtype=torch.bool, device=dev)
+            for i in range(b):
+                kv[i, sk - 5 - 7 * i:] = False
+        scale = 1 / math.sqrt(d)
+        o = ops.attention(q, k, v, scale, causal, kv)
+        qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        ref = ref_attention(qr, kr, vr, scale, causal, kv)
+        assert rel_err(o, ref) < 5e-3, case
+        do = torch.randn_like(o)
+        o.backward(do)
+        ref.backward(do.float())
+        for name, a, r in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+            assert rel_err(a, r) < 1e-2, (case, name)
+
+
+def test_attention_spike_forces_rescale(env):
+    """Online-softmax rescale path: one key dominates late in the sequence (cdna guide rule 26)."""
+    dev = env.device
+    b, s, h, d = 1, (1024 if env.big else 256), 1, 64
+    torch.manual_seed(13)
+    q = torch.randn(b, s, h, d).bfloat16().to(dev)
+    k = torch.randn(b, s, h, d).bfloat16().to(dev)
+    v = torch.randn(b, s, h, d).bfloat16().to(dev)
+    k[0, s - 20, 0] = q[0, 5, 0] * 8  # huge score for query 5 at a late key tile
+    o, _ = ops.raw_attn_fwd(q, k, v, 0.125, False)
+    assert rel_err(o, ref_attention(q, k, v, 0.125, False, None)) < 5e-3
+    assert torch.isfinite(o.float()).all()
+
+
+def test_attention_fully_masked_rows_are_zero(env):
+    dev = env.device
+    q = torch.randn(1, 64, 1, 64).bfloat16().to(dev)
+    k = torch.randn(1, 64, 1, 64).bfloat16().to(dev)
+    v = torch.randn(1, 64, 1, 64).bfloat16().to(dev)
+    kv = torch.zeros(1, 64, dtype=torch.bool, device=dev)
+    o, lse = ops.raw_attn_fwd(q, k, v, 0.125, False, kv)
+    assert (o == 0).all() and torch.isinf(lse).all()

@@ -63,6 +63,7 @@ SIGNATURES = {
     "tamd_gemm": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P]),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),
     "tamd_attn_bwd": (c_int, [POINTER(AttnBwdParams), P]),
+    "tamd_probe": (c_int, [P, P, P, c_int, c_int, P]),
 }
 
 

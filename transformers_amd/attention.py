@@ -1,0 +1,99 @@
+"""`attn_implementation="tamd"`: the MI355X flash-attention kernel behind the reference's AttentionInterface.
+
+Boundary (SURVEY.md §8b "B1"): `AttentionInterface.register(key, fn)` (src/transformers/modeling_utils.py:5092-5130)
+and `AttentionMaskInterface.register(key, mask_fn)` (src/transformers/masking_utils.py:711-724).  The callee
+signature is the documented one (docs/source/en/attention_interface.md:156-182; call sites
+models/llama/modeling_llama.py:268-277, models/bert/modeling_bert.py:192-201, models/gpt2/modeling_gpt2.py:211-220,
+models/clip/modeling_clip.py:321-330):
+
+    fn(module, query[B,Hq,S,D], key[B,Hkv,Sk,D], value[B,Hkv,Sk,D], attention_mask, *, dropout, scaling, **kwargs)
+        -> (attn_output[B,S,Hq,D] contiguous, None)
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from ._cabi import TamdError
+
+ATTN_KEY = "tamd"
+
+
+def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_function=None, attention_mask=None,
+              **kwargs):
+    """Mask factory for AttentionMaskInterface: the kernel takes a [B, kv_len] key-validity mask (or None).
+
+    Same contract as `flash_attention_mask` (masking_utils.py:607-647) minus its host-side `.all()` sync:
+    causality is a kernel flag, padding is the 2-D mask itself.
+    """
+    if attention_mask is None:
+        return None
+    return attention_mask[:, -kv_length:]
+
+
+def _key_valid_from_mask(attention_mask: torch.Tensor, batch: int, kv_len: int) -> Optional[torch.Tensor]:
+    if attention_mask.dim() == 2:
+        kv = attention_mask
+    elif attention_mask.dim() == 4 and attention_mask.shape[1] == 1 and attention_mask.shape[2] == 1:
+        kv = attention_mask[:, 0, 0, :]  # [B,1,1,Sk] broadcast padding mask
+    else:
+        raise TamdError(
+            "attn_implementation='tamd' takes a 2-D padding mask [batch, kv_len] (register-time mask function "
+            f"`tamd_mask`); got a mask of shape {tuple(attention_mask.shape)}. Arbitrary 4-D masks are not supported.")
+    if kv.dtype.is_floating_point:
+        kv = kv > (torch.finfo(kv.dtype).min / 2)  # additive float mask: 0 keeps, finfo.min / -inf drops
+    elif kv.dtype != torch.bool:
+        kv = kv != 0
+    if kv.shape[0] != batch:
+        kv = kv.expand(batch, -1)
+    return kv[:, -kv_len:].contiguous()
+
+
+def tamd_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0,
+                           scaling: Optional[float] = None, is_causal: Optional[bool] = None, **kwargs):
+    if dropout and dropout > 0.0:
+        raise TamdError("attn_implementation='tamd' has no attention-dropout path yet: run with "
+                        "attention dropout 0 (model.eval() or config.attention*_dropout = 0)")
+    if not query.is_cuda and ops.backend().name == "hip":
+        raise TamdError("attn_implementation='tamd' needs GPU tensors (no CPU fallback); use 'eager' or 'sdpa' on CPU")
+    b, hq, sq, d = query.shape
+    sk = key.shape[2]
+    if d not in (64, 128):
+        raise TamdError(f"attn_implementation='tamd' supports head_dim 64 and 128, got {d}")
+    if query.dtype not in (torch.bfloat16, torch.float16):
+        raise TamdError(f"attn_implementation='tamd' supports bf16/fp16, got {query.dtype}")
+    if scaling is None:
+        scaling = d ** -0.5
+    causal = is_causal if is_causal is not None else getattr(module, "is_causal", True)
+    causal = bool(causal) and sq > 1
+    key_valid = None
+    if attention_mask is not None:
+        key_valid = _key_valid_from_mask(attention_mask, b, sk)
+    # [B,H,S,D] -> [B,S,H,D] views (the projections produced [B,S,H,D]; this undoes the caller's transpose)
+    q, k, v = query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2)
+    if q.stride(3) != 1:
+        q = q.contiguous()
+    if k.stride(3) != 1:
+        k = k.contiguous()
+    if v.stride(3) != 1:
+        v = v.contiguous()
+    out = ops.attention(q, k, v, float(scaling), causal, key_valid)
+    return out, None
+
+
+_registered = False
+
+
+def register() -> None:
+    """Register the backend with the reference's two global registries (idempotent)."""
+    global _registered
+    if _registered:
+        return
+    from transformers.masking_utils import AttentionMaskInterface
+    from transformers.modeling_utils import AttentionInterface
+
+    AttentionInterface.register(ATTN_KEY, tamd_attention_forward)
+    AttentionMaskInterface.register(ATTN_KEY, tamd_mask)
+    _registered = True

@@ -1,0 +1,69 @@
+// probe.hip -- hardware-semantics probe (diagnostic entry point, not on the product path).
+//
+// Every gfx950 behaviour the kernels rely on is funnelled through tamd_device.h; tests/hipemu
+// implements the same wrappers from the documented semantics.  tamd_probe() runs one wrapper on one
+// wave with caller-supplied operands so tests/test_gpu_probe.py can compare the hardware against the
+// CPU model bit for bit (MFMA fragment layouts, ds_read_b64_tr_b16, v_permlane32_swap, direct-to-LDS
+// loads, ballot).  A mismatch means the model -- and therefore every emulator-validated layout -- is wrong.
+#include "common.h"
+
+namespace tamd {
+
+template <typename T>
+__global__ void probe_kernel(const unsigned int* __restrict__ in, const unsigned int* __restrict__ in2,
+                             unsigned int* __restrict__ out, int which) {
+  TAMD_DYN_SMEM(smem);
+  const int lane = threadIdx.x;
+  if (which == 0) {  // mfma 32x32x16
+    const u32x4 a = ld16(in + lane * 4), b = ld16(in + 256 + lane * 4);
+    f32x16 c;
+    for (int r = 0; r < 16; ++r) c[r] = (float)((lane + r) & 7);
+    c = mfma32<T>(a, b, c);
+    for (int r = 0; r < 16; ++r) out[lane * 16 + r] = f32_as_u32(c[r]);
+  } else if (which == 1) {  // mfma 16x16x32
+    const u32x4 a = ld16(in + lane * 4), b = ld16(in + 256 + lane * 4);
+    f32x4 c = {1.f, 2.f, 3.f, 4.f};
+    c = mfma16<T>(a, b, c);
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = f32_as_u32(c[r]);
+  } else if (which == 2) {  // transposing LDS read at caller-chosen per-lane byte offsets
+    for (int i = lane; i < 1024; i += 64) lds_write16(smem, (unsigned)i * 16u, ld16(in + i * 4));
+    block_sync();
+    const u32x2 v = lds_read8_tr16(smem, in2[lane]);
+    out[lane * 2] = v[0];
+    out[lane * 2 + 1] = v[1];
+  } else if (which == 3) {  // permlane32_swap + swap32 + ballot
+    unsigned int a = in[lane], b = in[64 + lane];
+    permlane32_swap(a, b);
+    out[lane] = a;
+    out[64 + lane] = b;
+    out[128 + lane] = f32_as_u32(swap32_f32(u32_as_f32(in[lane])));
+    const unsigned long long m = ballot64((in[lane] & 1u) != 0);
+    out[192 + lane] = (unsigned int)(m >> (lane < 32 ? 0 : 32));
+    out[256 + lane] = f32_as_u32(wave_sum((float)(in[lane] & 0xffu)));
+    out[320 + lane] = f32_as_u32(wave_max((float)(in[lane] & 0xffu)));
+  } else if (which == 4) {  // direct-to-LDS load: wave-uniform base + lane*16, per-lane global source
+    for (int i = lane; i < 256; i += 64) lds_write16(smem, (unsigned)i * 16u, u32x4{0xdeadbeefu, 0, 0, 0});
+    block_sync();
+    glds16(reinterpret_cast<const char*>(in) + in2[lane], smem, 1024u);
+    wait_vmcnt0();
+    block_sync();
+    for (int i = lane; i < 256; i += 64) {
+      const u32x4 v = lds_read16(smem, (unsigned)i * 16u);
+      st16(out + i * 4, v);
+    }
+  }
+}
+
+}  // namespace tamd
+
+using namespace tamd;
+
+// in: 4096 u32 (16 KiB), in2: 64 u32, out: 4096 u32.  One wave.
+extern "C" int tamd_probe(const void* in, const void* in2, void* out, int which, int dtype, tamd_stream_t stream) {
+  if (!in || !in2 || !out) return TAMD_E_NULL;
+  TAMD_DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((probe_kernel<T>), dim3(1), dim3(64), (size_t)16384, TAMD_STREAM(stream),
+                       (const unsigned int*)in, (const unsigned int*)in2, (unsigned int*)out, which);
+  });
+  return launch_status();
+}

@@ -1,0 +1,110 @@
+"""Fused projection weights without touching parameter names.
+
+A fused QKV (or gate|up) GEMM wants ONE [sum(out_i), in] weight, but `state_dict` keys (`q_proj.weight`, ...),
+DDP bucket order, tied weights and `save_pretrained` must keep seeing the reference's separate parameters
+(SURVEY.md §7 "Parameter-layout vs drop-in", §8b invariant 3).  So each parameter keeps its identity and
+shape and its `.data` becomes a row-slice VIEW of one fused buffer: optimizers, `load_state_dict`, DDP
+broadcast all write through to the fused storage; the GEMM reads the fused buffer; the backward computes
+one fused dW and hands each parameter its row-slice.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class FusedLinearFn(torch.autograd.Function):
+    """y = x . Wf^T (+ bf), Wf = concat of the member weights.  Gradients go to the member parameters."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bf, n_members, *members):
+        k = x.shape[-1]
+        x2 = ops._c(x).view(-1, k)
+        y = ops.raw_gemm(x2, wf, bias=bf, epilogue=ops.EPI_BIAS if bf is not None else ops.EPI_NONE)
+        ctx.save_for_backward(x2, wf)
+        ctx.splits = [m.shape[0] for m in members[:n_members]]
+        ctx.n_members = n_members
+        ctx.has_bias = bf is not None
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], wf.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wf = ctx.saved_tensors
+        dy2 = ops._c(dy).view(-1, wf.shape[0])
+        dx = ops.raw_gemm(dy2, wf, b_kn=True).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dwf = ops.raw_gemm(dy2, x2, a_km=True, b_kn=True)
+        dws = list(torch.split(dwf, ctx.splits, dim=0))
+        dbs = []
+        if ctx.has_bias:
+            dbs = list(torch.split(ops.raw_colsum(dy2), ctx.splits, dim=0))
+        return (dx, None, None, None, *dws, *dbs)
+
+
+class FusedWeights:
+    """Row-concatenation of several nn.Linear weights (and biases) kept coherent with the parameters."""
+
+    def __init__(self, linears: List[nn.Linear]):
+        self.linears = list(linears)
+        self._w: Optional[torch.Tensor] = None
+        self._b: Optional[torch.Tensor] = None
+        self.has_bias = self.linears[0].bias is not None
+
+    def _coherent(self) -> bool:
+        if self._w is None:
+            return False
+        off = 0
+        w0 = self.linears[0].weight
+        if self._w.device != w0.device or self._w.dtype != w0.dtype:
+            return False
+        esz = self._w.element_size()
+        row = self._w.shape[1] * esz
+        for lin in self.linears:
+            if lin.weight.data_ptr() != self._w.data_ptr() + off * row or not lin.weight.is_contiguous():
+                return False
+            off += lin.weight.shape[0]
+        if self.has_bias:
+            off = 0
+            for lin in self.linears:
+                if lin.bias.data_ptr() != self._b.data_ptr() + off * esz:
+                    return False
+                off += lin.bias.shape[0]
+        return True
+
+    @torch.no_grad()
+    def refuse(self) -> None:
+        self._w = torch.cat([lin.weight.data for lin in self.linears], dim=0).contiguous()
+        off = 0
+        for lin in self.linears:
+            n = lin.weight.shape[0]
+            lin.weight.data = self._w[off:off + n]
+            off += n
+        if self.has_bias:
+            self._b = torch.cat([lin.bias.data for lin in self.linears], dim=0).contiguous()
+            off = 0
+            for lin in self.linears:
+                n = lin.bias.shape[0]
+                lin.bias.data = self._b[off:off + n]
+                off += n
+
+    def weight(self) -> torch.Tensor:
+        if not self._coherent():
+            self.refuse()
+        return self._w
+
+    def bias(self) -> Optional[torch.Tensor]:
+        if not self.has_bias:
+            return None
+        self.weight()
+        return self._b
+
+    def linear(self, x: torch.Tensor) -> torch.Tensor:
+        wf = self.weight()
+        members = [lin.weight for lin in self.linears]
+        if self.has_bias:
+            members += [lin.bias for lin in self.linears]
+        return FusedLinearFn.apply(x, wf, self.bias(), len(self.linears), *members)

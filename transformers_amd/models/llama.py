@@ -1,0 +1,215 @@
+"""MI355X execution path for the Llama blocks (src/transformers/models/llama/modeling_llama.py).
+
+Replacement classes subclass the reference classes (SURVEY.md §8b "B2" invariants: isinstance-based
+output recorders and gradient checkpointing keep working, `RMSNorm` stays in the class name, parameter
+names / shapes / state_dict keys are untouched) and are swapped in post-construction by
+`transformers_amd.accelerate` (`module.__class__ = ...`).
+
+Fusion levels, outermost first -- each falls back to the next when its preconditions fail:
+  TamdLlamaDecoderLayer   whole layer as ONE autograd node (LlamaLayerFn): 4 GEMMs, attention, 2 norms,
+                          rope and SwiGLU launches forward; residual adds live in GEMM epilogues.
+  TamdLlamaAttention / TamdLlamaMLP / TamdLlamaRMSNorm   module-level replacements (fused QKV, fused gate|up).
+CPU tensors always take the reference's own forward (config 1, GPT-2 on CPU, must run unchanged).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from transformers.models.llama import modeling_llama as ref
+
+from .. import ops
+from ..fused_params import FusedWeights
+from ..ops import EPI_RESIDUAL
+
+
+def _on_gpu(t: torch.Tensor) -> bool:
+    return t.is_cuda or ops.backend_is_emulated()
+
+
+def _has_hooks(*mods: nn.Module) -> bool:
+    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in mods)
+
+
+class TamdLlamaRMSNorm(ref.LlamaRMSNorm):
+    """LlamaRMSNorm.forward, modeling_llama.py:62-67, on the row-reduction kernel."""
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        if not _on_gpu(hidden_states):
+            return super().forward(hidden_states)
+        return ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
+
+
+class TamdLlamaMLP(ref.LlamaMLP):
+    """LlamaMLP.forward, modeling_llama.py:174-176: one fused gate|up GEMM, SwiGLU kernel, down GEMM."""
+
+    def _fused(self) -> FusedWeights:
+        fw = self.__dict__.get("_tamd_gate_up")
+        if fw is None:
+            fw = FusedWeights([self.gate_proj, self.up_proj])
+            self.__dict__["_tamd_gate_up"] = fw
+        return fw
+
+    def forward(self, x):
+        if not _on_gpu(x) or self.config.hidden_act not in ("silu", "swish") or self.gate_proj.bias is not None:
+            return super().forward(x)
+        gu = self._fused().linear(x)
+        act = ops.SwiGLUFn.apply(gu)
+        return ops.linear(act, self.down_proj.weight)
+
+
+class TamdLlamaAttention(ref.LlamaAttention):
+    """LlamaAttention.forward, modeling_llama.py:243-281: fused QKV GEMM + rotary + flash attention + o_proj."""
+
+    def _fused(self) -> FusedWeights:
+        fw = self.__dict__.get("_tamd_qkv")
+        if fw is None:
+            fw = FusedWeights([self.q_proj, self.k_proj, self.v_proj])
+            self.__dict__["_tamd_qkv"] = fw
+        return fw
+
+    def _fast_ok(self, hidden_states, past_key_values) -> bool:
+        return (_on_gpu(hidden_states) and past_key_values is None and self.q_proj.bias is None
+                and self.head_dim in (64, 128) and hidden_states.dtype in (torch.bfloat16, torch.float16)
+                and self.config._attn_implementation == "tamd"
+                and not (self.training and self.attention_dropout > 0))
+
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        if not self._fast_ok(hidden_states, past_key_values):
+            return super().forward(hidden_states, position_embeddings=position_embeddings,
+                                   attention_mask=attention_mask, past_key_values=past_key_values, **kwargs)
+        b, s, _ = hidden_states.shape
+        hq = self.config.num_attention_heads
+        hkv = self.config.num_key_value_heads
+        d = self.head_dim
+        cos, sin = position_embeddings
+        qkv = self._fused().linear(hidden_states)                       # [B, S, (Hq+2Hkv)*D]
+        qkv = ops.RopeFn.apply(qkv, cos, sin, hq + hkv, d)
+        q = qkv[..., : hq * d].view(b, s, hq, d)
+        k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d)
+        v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d)
+        key_valid = None
+        if attention_mask is not None:
+            from ..attention import _key_valid_from_mask
+            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid)
+        out = ops.linear(o.view(b, s, hq * d), self.o_proj.weight)
+        return out, None
+
+
+class LlamaLayerFn(torch.autograd.Function):
+    """LlamaDecoderLayer.forward (modeling_llama.py:295-324) as one autograd node.
+
+    forward : rmsnorm -> QKV GEMM -> rope(in place) -> attention -> o_proj GEMM(+residual)
+              -> rmsnorm -> gate|up GEMM -> SwiGLU -> down GEMM(+residual)
+    backward: the derivatives of SURVEY.md §8a in reverse; every weight gradient is a k-major GEMM on the
+              saved activations, the SiLU*up product is re-materialised instead of stored, d(gate|up)
+              overwrites the saved gate|up buffer, and the residual-stream gradient is folded into the
+              RMSNorm backward kernels (`dres`).
+    """
+
+    @staticmethod
+    def forward(ctx, h_in, cos, sin, key_valid, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, meta):
+        eps, hq, hkv, d, scale, causal = meta
+        b, s, hd = h_in.shape
+        t = b * s
+        x = h_in.contiguous().view(t, hd)
+        xn, _, rstd1 = ops.raw_rmsnorm_fwd(x, w_ln1, eps)
+        qkv = ops.raw_gemm(xn, wqkv)
+        ops.raw_rope_(qkv, cos, sin, s, hq + hkv, d)
+        q = qkv[:, : hq * d].view(b, s, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
+        need_grad = any(ctx.needs_input_grad)
+        o, lse = ops.raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need_grad)
+        h_mid = ops.raw_gemm(o.view(t, hq * d), wo, residual=x, epilogue=EPI_RESIDUAL)
+        xn2, _, rstd2 = ops.raw_rmsnorm_fwd(h_mid, w_ln2, eps)
+        gu = ops.raw_gemm(xn2, wgu)
+        act = ops.raw_swiglu_fwd(gu)
+        h_out = ops.raw_gemm(act, wd, residual=h_mid, epilogue=EPI_RESIDUAL)
+        if need_grad:
+            ctx.save_for_backward(x, cos, sin, key_valid, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse,
+                                  h_mid, rstd2, xn2, gu)
+            ctx.meta = meta
+            ctx.shape = (b, s, hd)
+        return h_out.view(b, s, hd)
+
+    @staticmethod
+    def backward(ctx, d_hout):
+        (x, cos, sin, key_valid, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse, h_mid, rstd2, xn2,
+         gu) = ctx.saved_tensors
+        eps, hq, hkv, d, scale, causal = ctx.meta
+        b, s, hd = ctx.shape
+        t = b * s
+        dh = d_hout.contiguous().view(t, hd)
+        # ---- MLP
+        d_act = ops.raw_gemm(dh, wd, b_kn=True)                                  # [T, I]
+        d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True, inplace=True)   # d_gu aliases gu
+        del d_act
+        dwd = ops.raw_gemm(dh, act, a_km=True, b_kn=True)                        # [hd, I]
+        del act
+        d_xn2 = ops.raw_gemm(d_gu, wgu, b_kn=True)                               # [T, hd]
+        dwgu = ops.raw_gemm(d_gu, xn2, a_km=True, b_kn=True)                     # [2I, hd]
+        d_hmid, dw_ln2 = ops.raw_rmsnorm_bwd(d_xn2, h_mid, w_ln2, rstd2, dres=dh)
+        del d_xn2
+        # ---- attention
+        o2 = o.view(t, hq * d)
+        d_o = ops.raw_gemm(d_hmid, wo, b_kn=True)                                # [T, Hq*D]
+        dwo = ops.raw_gemm(d_hmid, o2, a_km=True, b_kn=True)
+        d_qkv = torch.empty_like(qkv)
+        q = qkv[:, : hq * d].view(b, s, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
+        dq = d_qkv[:, : hq * d].view(b, s, hq, d)
+        dk = d_qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
+        dv = d_qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
+        ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, hq, d), scale, causal, key_valid, dq=dq, dk=dk, dv=dv)
+        del d_o
+        ops.raw_rope_(d_qkv, cos, sin, s, hq + hkv, d, conj=True)
+        d_xn = ops.raw_gemm(d_qkv, wqkv, b_kn=True)
+        dwqkv = ops.raw_gemm(d_qkv, xn, a_km=True, b_kn=True)                    # [(Hq+2Hkv)D, hd]
+        d_hin, dw_ln1 = ops.raw_rmsnorm_bwd(d_xn, x, w_ln1, rstd1, dres=d_hmid)
+        nq, nk = hq * d, hkv * d
+        inter = wgu.shape[0] // 2
+        return (d_hin.view(b, s, hd), None, None, None, dw_ln1, None, dwqkv[:nq], dwqkv[nq:nq + nk],
+                dwqkv[nq + nk:], dwo, dw_ln2, None, dwgu[:inter], dwgu[inter:], dwd, None)
+
+
+class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
+    """LlamaDecoderLayer.forward, modeling_llama.py:295-324."""
+
+    def _fused_ok(self, hidden_states, past_key_values) -> bool:
+        attn, mlp = self.self_attn, self.mlp
+        return (isinstance(attn, TamdLlamaAttention) and isinstance(mlp, TamdLlamaMLP)
+                and attn._fast_ok(hidden_states, past_key_values)
+                and mlp.config.hidden_act in ("silu", "swish") and mlp.gate_proj.bias is None
+                and attn.o_proj.bias is None
+                and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm))
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                position_embeddings=None, **kwargs):
+        if not self._fused_ok(hidden_states, past_key_values):
+            return super().forward(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                                   past_key_values=past_key_values, use_cache=use_cache,
+                                   position_embeddings=position_embeddings, **kwargs)
+        attn, mlp = self.self_attn, self.mlp
+        b, s, _ = hidden_states.shape
+        cos, sin = position_embeddings
+        key_valid = None
+        if attention_mask is not None:
+            from ..attention import _key_valid_from_mask
+            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        qkv, gu = attn._fused(), mlp._fused()
+        meta = (float(self.input_layernorm.variance_epsilon), attn.config.num_attention_heads,
+                attn.config.num_key_value_heads, attn.head_dim, float(attn.scaling), bool(attn.is_causal) and s > 1)
+        return LlamaLayerFn.apply(hidden_states, cos, sin, key_valid, self.input_layernorm.weight, qkv.weight(),
+                                  attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight, attn.o_proj.weight,
+                                  self.post_attention_layernorm.weight, gu.weight(), mlp.gate_proj.weight,
+                                  mlp.up_proj.weight, mlp.down_proj.weight, meta)
+
+
+REPLACEMENTS = {
+    ref.LlamaRMSNorm: TamdLlamaRMSNorm,
+    ref.LlamaMLP: TamdLlamaMLP,
+    ref.LlamaAttention: TamdLlamaAttention,
+    ref.LlamaDecoderLayer: TamdLlamaDecoderLayer,
+}

@@ -1,0 +1,710 @@
+"""torch-level entry points of the MI355X kernels.
+
+Three layers, all thin:
+
+1. ``raw_*``   -- one Python function per C-ABI entry point (include/tamd.h): argument checks,
+                 output allocation with torch's caching allocator, launch on the *current* HIP
+                 stream of the calling thread.  No autograd.
+2. ``torch.ops.tamd.*`` -- the same functions registered with ``torch.library`` (the reference's own
+                 precedent: src/transformers/integrations/moe.py:245-257), with Meta ("fake")
+                 implementations so they compose with torch's tooling.
+3. ``*Fn``     -- ``torch.autograd.Function``s implementing the backward contract of SURVEY.md §8a.
+
+The HIP library is mandatory: there is no CPU or eager fallback in this module.  If libtamd.so is
+missing, or a tensor is not on a GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Optional
+
+import torch
+
+from . import _cabi
+from ._cabi import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_NONE, ACT_QUICK_GELU, ACT_SILU, EPI_ACCUM, EPI_BIAS,
+                    EPI_BIAS_ACT, EPI_NONE, EPI_RESIDUAL, GEMM_A_KM, GEMM_B_KN, TamdError)
+
+_DTYPE_CODE = {torch.bfloat16: _cabi.TAMD_BF16, torch.float16: _cabi.TAMD_F16, torch.float32: _cabi.TAMD_F32}
+ACT_CODES = {"none": ACT_NONE, "gelu": ACT_GELU_ERF, "gelu_new": ACT_GELU_TANH, "gelu_pytorch_tanh": ACT_GELU_TANH,
+             "quick_gelu": ACT_QUICK_GELU, "silu": ACT_SILU, "swish": ACT_SILU}
+
+
+# --------------------------------------------------------------------------- backend
+class HipBackend:
+    """libtamd.so + the calling thread's current HIP stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        path = _cabi.default_library_path()
+        if not path.exists():
+            raise TamdError(
+                f"{path} not found: build it with `python -m transformers_amd.build` "
+                "(the MI355X path has no CPU/eager fallback)")
+        self.lib = _cabi.TamdLib(path)
+
+    def check_tensor(self, t: torch.Tensor) -> None:
+        if not t.is_cuda:
+            raise TamdError(f"tamd op received a {t.device} tensor; the HIP kernels need GPU memory")
+
+    def stream(self, t: torch.Tensor):
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+_backend = None
+_backend_lock = threading.Lock()
+
+
+def backend():
+    global _backend
+    if _backend is None:
+        with _backend_lock:
+            if _backend is None:
+                _backend = HipBackend()
+    return _backend
+
+
+def _set_backend(b):
+    """Test hook (tests/hipemu installs the CPU execution model of the same kernels here)."""
+    global _backend
+    old, _backend = _backend, b
+    return old
+
+
+def backend_is_emulated() -> bool:
+    """True only while tests/hipemu has installed the CPU execution model of the kernels."""
+    return _backend is not None and _backend.name != "hip"
+
+
+def _code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise TamdError(f"unsupported dtype {t.dtype}") from None
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _prep(*tensors):
+    be = backend()
+    for t in tensors:
+        if t is not None:
+            be.check_tensor(t)
+    return be
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- raw ops
+def raw_rmsnorm_fwd(x, w, eps, residual=None):
+    """-> (y, h, rstd); h is x+residual (or x itself when residual is None)."""
+    cols = x.shape[-1]
+    x2 = _c(x).view(-1, cols)
+    r2 = None if residual is None else _c(residual).view(-1, cols)
+    be = _prep(x2, w, r2)
+    y = torch.empty_like(x2)
+    h = torch.empty_like(x2) if r2 is not None else x2
+    rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    be.lib.check(be.lib.tamd_rmsnorm_fwd(_p(x2), _p(r2), _p(_c(w)), _p(y), _p(h) if r2 is not None else None,
+                                         _p(rstd), x2.shape[0], cols, float(eps), _code(x2), be.stream(x2)),
+                 "tamd_rmsnorm_fwd")
+    return y.view(x.shape), h.view(x.shape), rstd
+
+
+def raw_rmsnorm_bwd(dy, h, w, rstd, dres=None):
+    cols = h.shape[-1]
+    dy2, h2 = _c(dy).view(-1, cols), _c(h).view(-1, cols)
+    dr2 = None if dres is None else _c(dres).view(-1, cols)
+    be = _prep(dy2, h2, w, dr2)
+    rows = h2.shape[0]
+    dx = torch.empty_like(h2)
+    dw = torch.empty_like(w)
+    nbytes = be.lib.tamd_norm_bwd_workspace_bytes(rows, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+    be.lib.check(be.lib.tamd_rmsnorm_bwd(_p(dy2), _p(h2), _p(_c(w)), _p(rstd), _p(dr2), _p(dx), _p(dw), _p(ws), nbytes,
+                                         rows, cols, _code(h2), be.stream(h2)), "tamd_rmsnorm_bwd")
+    return dx.view(h.shape), dw
+
+
+def raw_layernorm_fwd(x, w, b, eps, residual=None):
+    cols = x.shape[-1]
+    x2 = _c(x).view(-1, cols)
+    r2 = None if residual is None else _c(residual).view(-1, cols)
+    be = _prep(x2, w, b, r2)
+    y = torch.empty_like(x2)
+    h = torch.empty_like(x2) if r2 is not None else x2
+    mean = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    be.lib.check(be.lib.tamd_layernorm_fwd(_p(x2), _p(r2), _p(_c(w)), _p(None if b is None else _c(b)), _p(y),
+                                           _p(h) if r2 is not None else None, _p(mean), _p(rstd), x2.shape[0], cols,
+                                           float(eps), _code(x2), be.stream(x2)), "tamd_layernorm_fwd")
+    return y.view(x.shape), h.view(x.shape), mean, rstd
+
+
+def raw_layernorm_bwd(dy, h, w, mean, rstd, dres=None, need_db=True):
+    cols = h.shape[-1]
+    dy2, h2 = _c(dy).view(-1, cols), _c(h).view(-1, cols)
+    dr2 = None if dres is None else _c(dres).view(-1, cols)
+    be = _prep(dy2, h2, w, dr2)
+    rows = h2.shape[0]
+    dx = torch.empty_like(h2)
+    dw = torch.empty_like(w)
+    db = torch.empty_like(w) if need_db else None
+    nbytes = be.lib.tamd_norm_bwd_workspace_bytes(rows, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+    be.lib.check(be.lib.tamd_layernorm_bwd(_p(dy2), _p(h2), _p(_c(w)), _p(mean), _p(rstd), _p(dr2), _p(dx), _p(dw),
+                                           _p(db), _p(ws), nbytes, rows, cols, _code(h2), be.stream(h2)),
+                 "tamd_layernorm_bwd")
+    return dx.view(h.shape), dw, db
+
+
+def raw_rope_(x2d, cos, sin, seq, nheads, head_dim, conj=False):
+    """In-place rotary on the first `nheads` heads of every row of x2d [tokens, row_stride]."""
+    be = _prep(x2d, cos, sin)
+    assert x2d.dim() == 2 and x2d.stride(1) == 1
+    cos, sin = _c(cos), _c(sin)
+    if cos.dtype != x2d.dtype:
+        cos, sin = cos.to(x2d.dtype), sin.to(x2d.dtype)
+    cos_batch = cos.shape[0] if cos.dim() == 3 else 1
+    be.lib.check(be.lib.tamd_rope_inplace(_p(x2d), _p(cos), _p(sin), x2d.shape[0], seq, x2d.stride(0), nheads,
+                                          head_dim, cos_batch, int(conj), _code(x2d), be.stream(x2d)),
+                 "tamd_rope_inplace")
+    return x2d
+
+
+def raw_embedding_fwd(ids, table):
+    be = _prep(ids, table)
+    ids_c = _c(ids)
+    if ids_c.dtype != torch.int64:
+        ids_c = ids_c.long()
+    out = torch.empty(*ids.shape, table.shape[1], dtype=table.dtype, device=table.device)
+    be.lib.check(be.lib.tamd_embedding_fwd(_p(ids_c), _p(_c(table)), _p(out), ids_c.numel(), table.shape[0],
+                                           table.shape[1], None, _code(table), be.stream(table)),
+                 "tamd_embedding_fwd")
+    return out
+
+
+def raw_embedding_bwd(ids, dout, vocab, padding_idx=-1):
+    be = _prep(ids, dout)
+    dim = dout.shape[-1]
+    flat = _c(ids).view(-1).long()
+    sorted_ids, perm = torch.sort(flat, stable=True)  # index plumbing on torch; accumulation is ours
+    dtable = torch.zeros(vocab, dim, dtype=dout.dtype, device=dout.device)
+    d2 = _c(dout).view(-1, dim)
+    be.lib.check(be.lib.tamd_embedding_bwd(_p(sorted_ids), _p(perm), _p(d2), _p(dtable), flat.numel(), vocab, dim,
+                                           -1 if padding_idx is None else int(padding_idx), _code(d2),
+                                           be.stream(d2)), "tamd_embedding_bwd")
+    return dtable
+
+
+def raw_bert_embeddings_fwd(input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, keep_pre_ln):
+    be = _prep(input_ids, word, typ, pos, ln_w, ln_b)
+    n = input_ids.numel()
+    dim = word.shape[1]
+    out = torch.empty(*input_ids.shape, dim, dtype=word.dtype, device=word.device)
+    pre = torch.empty_like(out) if keep_pre_ln else None
+    mean = torch.empty(n, dtype=torch.float32, device=word.device)
+    rstd = torch.empty_like(mean)
+    be.lib.check(be.lib.tamd_bert_embeddings_fwd(
+        _p(_c(input_ids).long()), _p(_c(token_type_ids).long()), _p(_c(position_ids).long()), _p(_c(word)),
+        _p(_c(typ)), _p(_c(pos)), _p(_c(ln_w)), _p(_c(ln_b)), _p(out), _p(pre), _p(mean), _p(rstd), n, dim,
+        word.shape[0], typ.shape[0], pos.shape[0], float(eps), _code(word), be.stream(word)),
+        "tamd_bert_embeddings_fwd")
+    return out, pre, mean, rstd
+
+
+def raw_swiglu_fwd(gu):
+    """gu [T, 2I] = [gate | up]  ->  act [T, I]"""
+    be = _prep(gu)
+    t, two_i = gu.shape
+    inter = two_i // 2
+    act = torch.empty(t, inter, dtype=gu.dtype, device=gu.device)
+    up = gu[:, inter:]
+    be.lib.check(be.lib.tamd_swiglu_fwd(_p(gu), _p(up), _p(act), t, inter, gu.stride(0), act.stride(0), _code(gu),
+                                        be.stream(gu)), "tamd_swiglu_fwd")
+    return act
+
+
+def raw_swiglu_bwd(gu, dact, want_act=False, inplace=False):
+    be = _prep(gu, dact)
+    t, two_i = gu.shape
+    inter = two_i // 2
+    dgu = gu if inplace else torch.empty_like(gu)
+    act = torch.empty_like(dact) if want_act else None
+    dact = _c(dact)
+    be.lib.check(be.lib.tamd_swiglu_bwd(_p(gu), _p(gu[:, inter:]), _p(dact), _p(dgu), _p(dgu[:, inter:]), _p(act), t,
+                                        inter, gu.stride(0), dact.stride(0), _code(gu), be.stream(gu)),
+                 "tamd_swiglu_bwd")
+    return dgu, act
+
+
+def raw_bias_act_fwd(x, bias, act):
+    x2 = _c(x).view(-1, x.shape[-1])
+    be = _prep(x2, bias)
+    y = torch.empty_like(x2)
+    be.lib.check(be.lib.tamd_bias_act_fwd(_p(x2), _p(bias), _p(y), x2.shape[0], x2.shape[1], act, _code(x2),
+                                          be.stream(x2)), "tamd_bias_act_fwd")
+    return y.view(x.shape)
+
+
+def raw_bias_act_bwd(x, bias, dy, act):
+    x2, dy2 = _c(x).view(-1, x.shape[-1]), _c(dy).view(-1, x.shape[-1])
+    be = _prep(x2, bias, dy2)
+    dx = torch.empty_like(x2)
+    be.lib.check(be.lib.tamd_bias_act_bwd(_p(x2), _p(bias), _p(dy2), _p(dx), x2.shape[0], x2.shape[1], act,
+                                          _code(x2), be.stream(x2)), "tamd_bias_act_bwd")
+    return dx.view(x.shape)
+
+
+def raw_add(a, b):
+    a, b = _c(a), _c(b)
+    be = _prep(a, b)
+    out = torch.empty_like(a)
+    be.lib.check(be.lib.tamd_add(_p(a), _p(b), _p(out), a.numel(), _code(a), be.stream(a)), "tamd_add")
+    return out
+
+
+def raw_colsum(x2d):
+    be = _prep(x2d)
+    rows, cols = x2d.shape
+    out = torch.empty(cols, dtype=x2d.dtype, device=x2d.device)
+    nbytes = be.lib.tamd_colsum_workspace_bytes(rows, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x2d.device)
+    be.lib.check(be.lib.tamd_colsum(_p(x2d), _p(out), _p(ws), nbytes, rows, cols, x2d.stride(0), _code(x2d),
+                                    be.stream(x2d)), "tamd_colsum")
+    return out
+
+
+def raw_transpose(x2d):
+    be = _prep(x2d)
+    rows, cols = x2d.shape
+    out = torch.empty(cols, rows, dtype=x2d.dtype, device=x2d.device)
+    be.lib.check(be.lib.tamd_transpose(_p(x2d), _p(out), rows, cols, x2d.stride(0), out.stride(0), _code(x2d),
+                                       be.stream(x2d)), "tamd_transpose")
+    return out
+
+
+def raw_cross_entropy_fwd(logits2d, labels, ignore_index=-100):
+    be = _prep(logits2d, labels)
+    t, v = logits2d.shape
+    lse = torch.empty(t, dtype=torch.float32, device=logits2d.device)
+    row_loss = torch.empty_like(lse)
+    be.lib.check(be.lib.tamd_cross_entropy_fwd(_p(logits2d), _p(labels), _p(lse), _p(row_loss), t, v,
+                                               logits2d.stride(0), ignore_index, _code(logits2d),
+                                               be.stream(logits2d)), "tamd_cross_entropy_fwd")
+    return lse, row_loss
+
+
+def raw_cross_entropy_bwd(logits2d, labels, lse, gscale, ignore_index=-100):
+    be = _prep(logits2d, labels, lse, gscale)
+    t, v = logits2d.shape
+    dlogits = torch.empty_like(logits2d)
+    be.lib.check(be.lib.tamd_cross_entropy_bwd(_p(logits2d), _p(labels), _p(lse), _p(gscale), _p(dlogits), t, v,
+                                               logits2d.stride(0), ignore_index, _code(logits2d),
+                                               be.stream(logits2d)), "tamd_cross_entropy_bwd")
+    return dlogits
+
+
+def gemm_supported(m, n, k, dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and k % 8 == 0 and n % 8 == 0 and m > 0
+
+
+def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None):
+    """C[M,N] = epi(A . B^T).  a: [M,K] (or [K,M] if a_km); b: [N,K] (or [K,N] if b_kn)."""
+    be = _prep(a, b, bias, residual, out)
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    (k_a, m) = a.shape if a_km else (a.shape[1], a.shape[0])
+    (k_b, n) = b.shape if b_kn else (b.shape[1], b.shape[0])
+    if k_a != k_b:
+        raise TamdError(f"gemm K mismatch: {tuple(a.shape)} x {tuple(b.shape)} (a_km={a_km}, b_kn={b_kn})")
+    if out is None:
+        out = torch.empty(m, n, dtype=a.dtype, device=a.device)
+    flags = (GEMM_A_KM if a_km else 0) | (GEMM_B_KN if b_kn else 0)
+    ldr = residual.stride(0) if residual is not None else 0
+    be.lib.check(be.lib.tamd_gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), m, n, k_a, a.stride(0), b.stride(0),
+                                  out.stride(0), ldr, flags, epilogue, act, _code(a), be.stream(a)), "tamd_gemm")
+    return out
+
+
+def _attn_params(q, k, v, o, lse, key_valid, scale, causal):
+    """q/k/v/o are [B, S, H, D] *views* (any batch/seq/head strides, D contiguous)."""
+    p = _cabi.AttnParams()
+    p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    p.lse = lse.data_ptr() if lse is not None else None
+    p.key_valid = key_valid.data_ptr() if key_valid is not None else None
+    p.batch, p.seq_q, p.heads_q, p.head_dim = q.shape
+    p.seq_k, p.heads_kv = k.shape[1], k.shape[2]
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+        if t.stride(3) != 1:
+            raise TamdError("attention operands must have a contiguous head_dim")
+        setattr(p, name + "_stride_b", t.stride(0))
+        setattr(p, name + "_stride_s", t.stride(1))
+        setattr(p, name + "_stride_h", t.stride(2))
+    p.scale = float(scale)
+    p.causal = int(bool(causal))
+    p.dtype = _code(q)
+    return p
+
+
+def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None):
+    """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32."""
+    be = _prep(q, k, v, key_valid, out)
+    b, sq, hq, d = q.shape
+    o = out if out is not None else torch.empty(b, sq, hq, d, dtype=q.dtype, device=q.device)
+    lse = torch.empty(b, hq, sq, dtype=torch.float32, device=q.device) if need_lse else None
+    if key_valid is not None:
+        key_valid = _c(key_valid.to(torch.uint8))
+    p = _attn_params(q, k, v, o, lse, key_valid, scale, causal)
+    be.lib.check(be.lib.tamd_attn_fwd(ctypes.byref(p), be.stream(q)), "tamd_attn_fwd")
+    return o, lse
+
+
+def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, dk=None, dv=None):
+    """Gradients written into dq/dk/dv (views with the strides of q/k/v) or freshly allocated."""
+    be = _prep(q, k, v, o, lse, dout, key_valid)
+    if dout.stride() != o.stride():
+        dout = dout.contiguous() if o.is_contiguous() else dout.clone(memory_format=torch.preserve_format)
+    if dq is None:
+        dq = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device)
+    if dk is None:
+        dk = torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device)
+    if dv is None:
+        dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
+    assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
+    if key_valid is not None:
+        key_valid = _c(key_valid.to(torch.uint8))
+    delta = torch.empty_like(lse)
+    bp = _cabi.AttnBwdParams()
+    bp.fwd = _attn_params(q, k, v, o, lse, key_valid, scale, causal)
+    bp.dout, bp.dq, bp.dk, bp.dv, bp.delta = (dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                              delta.data_ptr())
+    be.lib.check(be.lib.tamd_attn_bwd(ctypes.byref(bp), be.stream(q)), "tamd_attn_bwd")
+    return dq, dk, dv
+
+
+# --------------------------------------------------------------------------- autograd functions
+class RMSNormFn(torch.autograd.Function):
+    """y = LlamaRMSNorm(x).  Reference: models/llama/modeling_llama.py:62-67."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        y, h, rstd = raw_rmsnorm_fwd(x, w, eps, None)
+        ctx.save_for_backward(h, w, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, rstd = ctx.saved_tensors
+        dx, dw = raw_rmsnorm_bwd(dy, h, w, rstd)
+        return dx, dw, None
+
+
+class AddRMSNormFn(torch.autograd.Function):
+    """h = x + residual; y = LlamaRMSNorm(h) -> (y, h): the residual add of LlamaDecoderLayer.forward
+    (modeling_llama.py:317,323) fused into the norm that follows it."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w, eps):
+        y, h, rstd = raw_rmsnorm_fwd(x, w, eps, residual)
+        ctx.save_for_backward(h, w, rstd)
+        ctx.set_materialize_grads(False)
+        return y, h
+
+    @staticmethod
+    def backward(ctx, dy, dh):
+        h, w, rstd = ctx.saved_tensors
+        if dy is None:
+            return dh, dh, None, None
+        dx, dw = raw_rmsnorm_bwd(dy, h, w, rstd, dres=dh)
+        return dx, dx, dw, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = nn.LayerNorm(x).  Call sites: models/bert/modeling_bert.py:62,106; gpt2 :252-254; clip :358-360."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        y, h, mean, rstd = raw_layernorm_fwd(x, w, b, eps, None)
+        ctx.save_for_backward(h, w, mean, rstd)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = raw_layernorm_bwd(dy, h, w, mean, rstd, need_db=ctx.has_b)
+        return dx, dw, db, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + residual) -> (y, h): BertSelfOutput / BertOutput (modeling_bert.py:289-293, :347-351)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, w, b, eps):
+        y, h, mean, rstd = raw_layernorm_fwd(x, w, b, eps, residual)
+        ctx.save_for_backward(h, w, mean, rstd)
+        ctx.has_b = b is not None
+        ctx.set_materialize_grads(False)
+        return y, h
+
+    @staticmethod
+    def backward(ctx, dy, dh):
+        h, w, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dh, dh, None, None, None
+        dx, dw, db = raw_layernorm_bwd(dy, h, w, mean, rstd, dres=dh, need_db=ctx.has_b)
+        return dx, dx, dw, db, None
+
+
+def rmsnorm(x, w, eps, residual=None):
+    """-> y  (or (y, h) with h = x + residual when a residual is given)."""
+    if residual is None:
+        return RMSNormFn.apply(x, w, eps)
+    return AddRMSNormFn.apply(x, residual, w, eps)
+
+
+def layernorm(x, w, b, eps, residual=None):
+    if residual is None:
+        return LayerNormFn.apply(x, w, b, eps)
+    return AddLayerNormFn.apply(x, residual, w, b, eps)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) [+ residual] on the MFMA GEMM; dX and dW use the k-major operand modes
+    (no HBM transposes).  nn.Linear call sites: see csrc/gemm.hip header."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, act):
+        k = x.shape[-1]
+        x2 = _c(x).view(-1, k)
+        epi, r2 = EPI_NONE, None
+        if residual is not None:
+            epi, r2 = EPI_RESIDUAL, _c(residual).view(-1, w.shape[0])
+        elif bias is not None and act != ACT_NONE:
+            epi = EPI_BIAS_ACT
+        elif bias is not None:
+            epi = EPI_BIAS
+        pre = None
+        if act != ACT_NONE and (bias is None or residual is not None):
+            raise TamdError("activation epilogue needs a bias and no residual")
+        if epi == EPI_BIAS_ACT and any(ctx.needs_input_grad[:3]):
+            # keep the pre-activation for the backward: GEMM+bias, then the activation kernel
+            pre = raw_gemm(x2, w, bias=bias, epilogue=EPI_BIAS)
+            y = raw_bias_act_fwd(pre, None, act)
+        else:
+            y = raw_gemm(x2, w, bias=bias, residual=r2, epilogue=epi, act=act)
+        ctx.save_for_backward(x2, w, pre)
+        ctx.has_bias, ctx.has_res, ctx.act = bias is not None, residual is not None, act
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        n = w.shape[0]
+        dy2 = _c(dy).view(-1, n)
+        dres = dy if ctx.has_res else None
+        if pre is not None:
+            dy2 = raw_bias_act_bwd(pre, None, dy2, ctx.act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = raw_gemm(dy2, w, b_kn=True).view(ctx.x_shape)          # dX = dY . W
+        if ctx.needs_input_grad[1]:
+            dw = raw_gemm(dy2, x2, a_km=True, b_kn=True)                # dW = dY^T . X
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = raw_colsum(dy2)
+        return dx, dw, db, dres, None
+
+
+def linear(x, w, bias=None, residual=None, act=ACT_NONE):
+    return LinearFn.apply(x, w, bias, residual, act)
+
+
+class RopeFn(torch.autograd.Function):
+    """Rotary embedding applied to the first `nheads` heads of a [B, S, row] projection output
+    (models/llama/modeling_llama.py:130-160).  Out of place at this level (autograd needs the input intact)."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, nheads, head_dim):
+        b, s, row = x.shape
+        y = x.clone()
+        raw_rope_(y.view(b * s, row), cos, sin, s, nheads, head_dim, conj=False)
+        ctx.save_for_backward(cos, sin)
+        ctx.meta = (nheads, head_dim)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cos, sin = ctx.saved_tensors
+        nheads, head_dim = ctx.meta
+        b, s, row = dy.shape
+        dx = dy.clone()
+        raw_rope_(dx.view(b * s, row), cos, sin, s, nheads, head_dim, conj=True)
+        return dx, None, None, None, None
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(scale QK^T + mask) V on [B,S,H,D] views.  Reference: eager_attention_forward,
+    models/llama/modeling_llama.py:191-213 and siblings."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_valid, scale, causal):
+        need = any(ctx.needs_input_grad[:3])
+        o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need)
+        if need:
+            ctx.save_for_backward(q, k, v, o, lse, key_valid)
+        ctx.meta = (scale, causal)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, key_valid = ctx.saved_tensors
+        scale, causal = ctx.meta
+        dq, dk, dv = raw_attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid)
+        return dq, dk, dv, None, None, None
+
+
+def attention(q, k, v, scale, causal, key_valid=None):
+    return AttentionFn.apply(q, k, v, key_valid, scale, causal)
+
+
+class SwiGLUFn(torch.autograd.Function):
+    """act = silu(gate) * up on a fused [T, 2I] projection output (modeling_llama.py:174-176)."""
+
+    @staticmethod
+    def forward(ctx, gu):
+        shape = gu.shape
+        gu2 = _c(gu).view(-1, shape[-1])
+        ctx.save_for_backward(gu2)
+        ctx.shape = shape
+        return raw_swiglu_fwd(gu2).view(*shape[:-1], shape[-1] // 2)
+
+    @staticmethod
+    def backward(ctx, dact):
+        (gu2,) = ctx.saved_tensors
+        dgu, _ = raw_swiglu_bwd(gu2, _c(dact).view(gu2.shape[0], -1))
+        return dgu.view(ctx.shape)
+
+
+class BiasActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, act):
+        ctx.save_for_backward(x, bias)
+        ctx.act = act
+        return raw_bias_act_fwd(x, bias, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bias = ctx.saved_tensors
+        dx = raw_bias_act_bwd(x, bias, dy, ctx.act)
+        db = raw_colsum(dx.view(-1, dx.shape[-1])) if bias is not None else None
+        return dx, db, None
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding (models/llama/modeling_llama.py:381): bit-exact gather, sorted scatter-add backward."""
+
+    @staticmethod
+    def forward(ctx, ids, table, padding_idx):
+        ctx.save_for_backward(ids)
+        ctx.meta = (table.shape[0], padding_idx)
+        return raw_embedding_fwd(ids, table)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        vocab, padding_idx = ctx.meta
+        return None, raw_embedding_bwd(ids, dout, vocab, padding_idx), None
+
+
+def embedding(ids, table, padding_idx=None):
+    return EmbeddingFn.apply(ids, table, padding_idx)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """fixed_cross_entropy on `logits.float()` (loss/loss_utils.py:32-46) without materialising fp32 logits.
+    Returns the SUM of per-token losses; the caller divides (mean over valid labels or num_items_in_batch)."""
+
+    @staticmethod
+    def forward(ctx, logits2d, labels, ignore_index):
+        lse, row_loss = raw_cross_entropy_fwd(logits2d, labels, ignore_index)
+        ctx.save_for_backward(logits2d, labels, lse)
+        ctx.ignore_index = ignore_index
+        return row_loss.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits2d, labels, lse = ctx.saved_tensors
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        return raw_cross_entropy_bwd(logits2d, labels, lse, gs, ctx.ignore_index), None, None
+
+
+def causal_lm_loss(logits, labels, vocab_size, num_items_in_batch=None, ignore_index=-100, shift_labels=None,
+                   **_unused):
+    """Drop-in for ForCausalLMLoss (loss/loss_utils.py:49-71): same shifting, same reductions."""
+    if shift_labels is None:
+        labels = torch.nn.functional.pad(labels, (0, 1), value=ignore_index)
+        shift_labels = labels[..., 1:].contiguous()
+    logits2d = logits.reshape(-1, vocab_size)
+    shift_labels = shift_labels.reshape(-1).to(logits.device)
+    total = CrossEntropyFn.apply(logits2d, shift_labels, ignore_index)
+    if num_items_in_batch is not None:
+        if torch.is_tensor(num_items_in_batch):
+            num_items_in_batch = num_items_in_batch.to(total.device)
+        return total / num_items_in_batch
+    n_valid = (shift_labels != ignore_index).sum()
+    return total / n_valid
+
+
+# --------------------------------------------------------------------------- torch.ops registration
+_LIB = torch.library.Library("tamd", "DEF")
+_registered = False
+
+
+def _register():
+    """torch.ops.tamd.<name>: the raw kernels as dispatcher ops (CUDA key = HIP on ROCm) + Meta shapes."""
+    global _registered
+    if _registered:
+        return
+    _registered = True
+    defs = [
+        ("rmsnorm_fwd(Tensor x, Tensor w, float eps, Tensor? residual=None) -> (Tensor, Tensor, Tensor)",
+         raw_rmsnorm_fwd,
+         lambda x, w, eps, residual=None: (torch.empty_like(x), torch.empty_like(x),
+                                           x.new_empty(x.numel() // x.shape[-1], dtype=torch.float32))),
+        ("rmsnorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor rstd, Tensor? dres=None) -> (Tensor, Tensor)",
+         raw_rmsnorm_bwd, lambda dy, h, w, rstd, dres=None: (torch.empty_like(h), torch.empty_like(w))),
+        ("layernorm_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor? residual=None) -> "
+         "(Tensor, Tensor, Tensor, Tensor)", raw_layernorm_fwd,
+         lambda x, w, b, eps, residual=None: (torch.empty_like(x), torch.empty_like(x),
+                                              x.new_empty(x.numel() // x.shape[-1], dtype=torch.float32),
+                                              x.new_empty(x.numel() // x.shape[-1], dtype=torch.float32))),
+        ("swiglu_fwd(Tensor gu) -> Tensor", raw_swiglu_fwd,
+         lambda gu: gu.new_empty(gu.shape[0], gu.shape[1] // 2)),
+        ("embedding_fwd(Tensor ids, Tensor table) -> Tensor", raw_embedding_fwd,
+         lambda ids, table: table.new_empty(*ids.shape, table.shape[1])),
+        ("gemm(Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, Tensor? residual=None, "
+         "int epilogue=0, int act=0) -> Tensor",
+         lambda a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0: raw_gemm(
+             a, b, a_km=a_km, b_kn=b_kn, bias=bias, residual=residual, epilogue=epilogue, act=act),
+         lambda a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0: a.new_empty(
+             a.shape[1] if a_km else a.shape[0], b.shape[1] if b_kn else b.shape[0])),
+        ("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None) -> "
+         "(Tensor, Tensor)",
+         lambda q, k, v, scale, causal, key_valid=None: raw_attn_fwd(q, k, v, scale, causal, key_valid),
+         lambda q, k, v, scale, causal, key_valid=None: (
+             q.new_empty(q.shape), q.new_empty(q.shape[0], q.shape[2], q.shape[1], dtype=torch.float32))),
+    ]
+    for schema, impl, meta in defs:
+        _LIB.define(schema)
+        name = schema.split("(")[0]
+        _LIB.impl(name, impl, "CUDA")
+        _LIB.impl(name, meta, "Meta")
+
+
+_register()

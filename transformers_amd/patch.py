@@ -1,0 +1,84 @@
+"""In-place module replacement (SURVEY.md §8b "B2").
+
+The reference's registry route (`register_patch_mapping` + `apply_patches`,
+src/transformers/monkey_patching.py:85-155, 233-297) crashes in environments without torchvision
+(`dir()` on lazy alias modules, monkey_patching.py:275), so the swap is done post-construction:
+`module.__class__ = Replacement` for every module whose class is in the replacement tables.  The
+replacement classes subclass the originals and add no parameters, so this is exact and reversible.
+"""
+from __future__ import annotations
+
+from typing import Dict, Type
+
+import torch
+from torch import nn
+
+from . import attention
+
+
+def _tables() -> Dict[Type[nn.Module], Type[nn.Module]]:
+    from .models import bert, clip, gpt2, llama
+
+    table: Dict[Type[nn.Module], Type[nn.Module]] = {}
+    for mod in (llama, bert, clip, gpt2):
+        table.update(mod.REPLACEMENTS)
+    return table
+
+
+def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bool = True) -> nn.Module:
+    """Switch `model` (any PreTrainedModel containing Llama / BERT / CLIP / GPT-2 blocks) to the MI355X path.
+
+    * registers and selects `attn_implementation="tamd"` (reference API: `set_attn_implementation`,
+      src/transformers/modeling_utils.py:2041-2139);
+    * swaps norm / MLP / attention / layer modules for their tamd subclasses in place;
+    * installs the fused cross-entropy as `model.loss_function` for causal-LM heads
+      (reference hook: modeling_utils.py:4652-4669).
+    Returns the same object.
+    """
+    attention.register()
+    table = _tables()
+    n = 0
+    for m in model.modules():
+        repl = table.get(type(m))
+        if repl is not None:
+            m.__class__ = repl
+            n += 1
+    model._tamd_swapped = n
+    if attn_implementation and hasattr(model, "set_attn_implementation"):
+        model.set_attn_implementation(attention.ATTN_KEY)
+    # eager weight fusion (before DDP wraps the model)
+    for m in model.modules():
+        fuse = getattr(m, "_fused", None)
+        if callable(fuse) and all(p.is_cuda for p in m.parameters(recurse=True)):
+            fuse().weight()
+    if fuse_loss and getattr(model, "loss_type", None) == "ForCausalLM":
+        from .ops import causal_lm_loss
+
+        model.loss_function = _LossDispatch(causal_lm_loss, model.loss_function)
+    return model
+
+
+class _LossDispatch:
+    """GPU logits -> fused cross-entropy kernel; anything else -> the reference loss it replaced."""
+
+    def __init__(self, fast, reference):
+        self.fast, self.reference = fast, reference
+
+    def __call__(self, logits, labels, vocab_size, **kwargs):
+        from . import ops
+
+        if logits.is_cuda or ops.backend_is_emulated():
+            return self.fast(logits=logits, labels=labels, vocab_size=vocab_size, **kwargs)
+        return self.reference(logits=logits, labels=labels, vocab_size=vocab_size, **kwargs)
+
+
+def revert(model: nn.Module) -> nn.Module:
+    """Undo `accelerate` (class swaps only; fused weight storage stays valid for the reference modules)."""
+    inv = {v: k for k, v in _tables().items()}
+    for m in model.modules():
+        orig = inv.get(type(m))
+        if orig is not None:
+            m.__class__ = orig
+    if isinstance(getattr(model, "loss_function", None), _LossDispatch):
+        model.loss_function = model.loss_function.reference
+    return model
