@@ -1,0 +1,137 @@
+"""Model-level parity through the unchanged reference classes (AutoModel / LlamaForCausalLM + accelerate()).
+
+Gate (SURVEY.md §8c "parity noise floor"): in bf16, our logits' error against the reference's fp32 eager path
+must not exceed ~1.1x the error of the reference's own bf16 eager path against the same fp32 run; the
+reference's backend-parity rule (tests/test_modeling_common.py:199-231: bf16 atol/rtol 1e-2) is the regression
+gate for hidden states; losses agree to 2e-3 relative; integer paths are exact."""
+import copy
+
+import pytest
+import torch
+
+import transformers_amd
+from conftest import rel_err
+from transformers import LlamaConfig, LlamaForCausalLM
+
+
+def tiny_llama(big):
+    if big:
+        return LlamaConfig(vocab_size=4096, hidden_size=1024, intermediate_size=2816, num_hidden_layers=3,
+                           num_attention_heads=8, num_key_value_heads=2, head_dim=128, max_position_embeddings=2048,
+                           rms_norm_eps=1e-5, attn_implementation="eager")
+    return LlamaConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                       num_attention_heads=4, num_key_value_heads=2, head_dim=64, max_position_embeddings=512,
+                       rms_norm_eps=1e-5, attn_implementation="eager")
+
+
+@pytest.mark.parametrize("padding", [False, True])
+def test_llama_forward_backward_parity(env, padding):
+    torch.manual_seed(0)
+    cfg = tiny_llama(env.big)
+    ref = LlamaForCausalLM(cfg).bfloat16().train()
+    ref32 = copy.deepcopy(ref).float()
+    fast = copy.deepcopy(ref).to(env.device)
+    b, s = (4, 1024) if env.big else (2, 96)
+    ids = torch.randint(0, cfg.vocab_size, (b, s))
+    labels = ids.clone()
+    labels[0, :10] = -100
+    am = None
+    if padding:
+        am = torch.ones(b, s, dtype=torch.long)
+        am[1, s - 16:] = 0
+        labels[1, s - 16:] = -100
+    o_ref = ref(input_ids=ids, labels=labels, attention_mask=am, use_cache=False)
+    o_ref.loss.backward()
+    o32 = ref32(input_ids=ids, labels=labels, attention_mask=am, use_cache=False)
+    o32.loss.backward()
+    transformers_amd.accelerate(fast)
+    assert fast.config._attn_implementation == "tamd"
+    assert type(fast.model.layers[0]).__name__ == "TamdLlamaDecoderLayer"
+    dev = env.device
+    o = fast(input_ids=ids.to(dev), labels=labels.to(dev), attention_mask=None if am is None else am.to(dev),
+             use_cache=False)
+    o.loss.backward()
+    valid = torch.ones(b, s, dtype=torch.bool) if am is None else am.bool()
+    e_fast = rel_err(o.logits[valid.to(dev)], o32.logits[valid])
+    e_ref = rel_err(o_ref.logits[valid], o32.logits[valid])
+    assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
+    assert abs(o.loss.item() - o32.loss.item()) <= 2e-3 * abs(o32.loss.item()) + 2e-3
+    g32 = dict(ref32.named_parameters())
+    gref = dict(ref.named_parameters())
+    for n, p in fast.named_parameters():
+        ef, er = rel_err(p.grad, g32[n].grad), rel_err(gref[n].grad, g32[n].grad)
+        assert ef <= 1.25 * er + 2e-3, (n, ef, er)
+
+
+def test_llama_module_level_path_matches_fused_layer(env):
+    """The module-by-module replacements (hooks installed -> no whole-layer fusion) and the fused layer agree."""
+    torch.manual_seed(1)
+    cfg = tiny_llama(False)
+    m = LlamaForCausalLM(cfg).bfloat16().eval().to(env.device)
+    transformers_amd.accelerate(m)
+    ids = torch.randint(0, cfg.vocab_size, (2, 64)).to(env.device)
+    with torch.no_grad():
+        a = m(input_ids=ids, use_cache=False).logits
+        hs = m(input_ids=ids, use_cache=False, output_hidden_states=True)
+        handles = [l.mlp.register_forward_hook(lambda *_: None) for l in m.model.layers]
+        b = m(input_ids=ids, use_cache=False).logits
+        for h in handles:
+            h.remove()
+    assert len(hs.hidden_states) == cfg.num_hidden_layers + 1
+    assert rel_err(b, a) < 1e-2
+    assert (a.argmax(-1) == b.argmax(-1)).float().mean() > 0.97
+
+
+def test_generate_with_cache_uses_reference_modules(env):
+    """KV-cache decode goes through the reference attention module + our registered attention function."""
+    torch.manual_seed(2)
+    cfg = tiny_llama(False)
+    ref = LlamaForCausalLM(cfg).bfloat16().eval()
+    fast = copy.deepcopy(ref).to(env.device)
+    transformers_amd.accelerate(fast)
+    ids = torch.randint(0, cfg.vocab_size, (1, 12))
+    with torch.no_grad():
+        want = ref(input_ids=ids, use_cache=True)
+        got = fast(input_ids=ids.to(env.device), use_cache=True)
+    assert rel_err(got.logits, want.logits) < 2e-2
+    assert got.past_key_values is not None
+
+
+def test_state_dict_keys_and_fused_views_roundtrip(env):
+    cfg = tiny_llama(False)
+    ref = LlamaForCausalLM(cfg).bfloat16()
+    fast = copy.deepcopy(ref).to(env.device)
+    keys = list(fast.state_dict().keys())
+    transformers_amd.accelerate(fast)
+    ids = torch.randint(0, cfg.vocab_size, (1, 32)).to(env.device)
+    fast(input_ids=ids, use_cache=False)  # builds the fused QKV / gate|up buffers
+    assert list(fast.state_dict().keys()) == keys
+    sd = {k: v.detach().cpu().clone() for k, v in fast.state_dict().items()}
+    for k, v in ref.state_dict().items():
+        assert torch.equal(sd[k], v), k
+    # writes through the parameters reach the fused buffers (optimizer / load_state_dict semantics)
+    att = fast.model.layers[0].self_attn
+    with torch.no_grad():
+        att.k_proj.weight.mul_(0).add_(1.0)
+    fw = att._fused().weight()
+    hq = cfg.num_attention_heads * cfg.head_dim
+    assert (fw[hq: hq + att.k_proj.weight.shape[0]] == 1).all()
+    transformers_amd.revert(fast)
+    assert type(fast.model.layers[0]).__name__ == "LlamaDecoderLayer"
+
+
+def test_gpt2_cpu_path_untouched():
+    """BASELINE config 1: gpt2 eager forward on CPU through AutoModelForCausalLM must run unchanged with the
+    package imported (and even after accelerate(): CPU tensors take the reference forward)."""
+    from transformers import AutoModelForCausalLM, GPT2Config
+
+    torch.manual_seed(0)
+    cfg = GPT2Config(n_layer=2, n_embd=64, n_head=2, vocab_size=300, n_positions=64)
+    m = AutoModelForCausalLM.from_config(cfg, attn_implementation="eager").eval()
+    ids = torch.randint(0, 300, (1, 16))
+    with torch.no_grad():
+        want = m(ids).logits
+        m2 = copy.deepcopy(m)
+        transformers_amd.accelerate(m2, attn_implementation=False)
+        got = m2(ids).logits
+    assert torch.equal(want, got)

@@ -17,10 +17,10 @@ from . import attention
 
 
 def _tables() -> Dict[Type[nn.Module], Type[nn.Module]]:
-    from .models import bert, clip, gpt2, llama
+    from .models import bert, clip, common, gpt2, llama
 
     table: Dict[Type[nn.Module], Type[nn.Module]] = {}
-    for mod in (llama, bert, clip, gpt2):
+    for mod in (common, llama, bert, clip, gpt2):
         table.update(mod.REPLACEMENTS)
     return table
 
