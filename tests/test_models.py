@@ -135,3 +135,95 @@ def test_gpt2_cpu_path_untouched():
         transformers_amd.accelerate(m2, attn_implementation=False)
         got = m2(ids).logits
     assert torch.equal(want, got)
+
+
+def _grad_parity(fast, ref, ref32, skip=()):
+    g32, gref = dict(ref32.named_parameters()), dict(ref.named_parameters())
+    for n, p in fast.named_parameters():
+        if any(s in n for s in skip) or g32[n].grad is None:
+            continue
+        assert p.grad is not None, n
+        ef, er = rel_err(p.grad, g32[n].grad), rel_err(gref[n].grad, g32[n].grad)
+        assert ef <= 1.6 * er + 3e-3, (n, ef, er)
+
+
+def test_bert_masked_lm_parity(env):
+    """BASELINE config 2 architecture (encoder LayerNorm/GeLU path) at test scale, dropout 0 (parity mode)."""
+    from transformers import BertConfig, BertForMaskedLM
+
+    torch.manual_seed(3)
+    big = env.big
+    cfg = BertConfig(vocab_size=1000 if big else 200, hidden_size=768 if big else 128,
+                     num_hidden_layers=2, num_attention_heads=12 if big else 2,
+                     intermediate_size=3072 if big else 256, max_position_embeddings=512 if big else 64,
+                     attn_implementation="eager", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    ref = BertForMaskedLM(cfg).bfloat16().train()
+    ref32 = copy.deepcopy(ref).float()
+    fast = copy.deepcopy(ref).to(env.device)
+    b, s = (8, 512) if big else (2, 40)
+    ids = torch.randint(1, cfg.vocab_size, (b, s))
+    am = torch.ones(b, s, dtype=torch.long)
+    am[0, s - 7:] = 0
+    labels = ids.clone()
+    labels[:, ::3] = -100
+    o_ref = ref(input_ids=ids, attention_mask=am, labels=labels)
+    o_ref.loss.backward()
+    o32 = ref32(input_ids=ids, attention_mask=am, labels=labels)
+    o32.loss.backward()
+    transformers_amd.accelerate(fast)
+    assert type(fast.bert.embeddings).__name__ == "TamdBertEmbeddings"
+    dev = env.device
+    o = fast(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev))
+    o.loss.backward()
+    v = am.bool()
+    e_fast, e_ref = rel_err(o.logits[v.to(dev)], o32.logits[v]), rel_err(o_ref.logits[v], o32.logits[v])
+    assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
+    # key.bias has an exactly-zero gradient (softmax shift invariance): relative error is meaningless there
+    _grad_parity(fast, ref, ref32, skip=("key.bias",))
+
+
+def test_clip_vision_tower_hidden_states(env):
+    """LLaVA's use of CLIP (models/llava/modeling_llava.py:154-166): output_hidden_states -> hidden_states[-2]."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+
+    torch.manual_seed(4)
+    big = env.big
+    cfg = CLIPVisionConfig(hidden_size=1024 if big else 128, intermediate_size=4096 if big else 256,
+                           num_hidden_layers=3 if big else 2, num_attention_heads=16 if big else 2,
+                           image_size=336 if big else 56, patch_size=14, attn_implementation="eager")
+    ref = CLIPVisionModel(cfg).bfloat16().eval()
+    ref32 = copy.deepcopy(ref).float()
+    fast = copy.deepcopy(ref).to(env.device)
+    px = torch.randn(1, 3, cfg.image_size, cfg.image_size)
+    with torch.no_grad():
+        a = ref(pixel_values=px.bfloat16(), output_hidden_states=True)
+        a32 = ref32(pixel_values=px, output_hidden_states=True)
+        transformers_amd.accelerate(fast)
+        c = fast(pixel_values=px.bfloat16().to(env.device), output_hidden_states=True)
+    assert len(c.hidden_states) == cfg.num_hidden_layers + 1
+    assert c.hidden_states[-2].shape[1] == (cfg.image_size // 14) ** 2 + 1  # 577 tokens at 336 px: ragged tiles
+    e_fast = rel_err(c.hidden_states[-2], a32.hidden_states[-2])
+    e_ref = rel_err(a.hidden_states[-2], a32.hidden_states[-2])
+    assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
+
+
+def test_gpt2_on_kernels(env):
+    """GPT-2 blocks (Conv1D = k-major GEMM operand, gelu_new, pre-LN, tied lm_head) through the kernels."""
+    from transformers import GPT2Config, GPT2LMHeadModel
+
+    torch.manual_seed(5)
+    cfg = GPT2Config(n_layer=2, n_embd=768 if env.big else 128, n_head=12 if env.big else 2, vocab_size=304,
+                     n_positions=256, attn_implementation="eager", resid_pdrop=0, embd_pdrop=0, attn_pdrop=0)
+    ref = GPT2LMHeadModel(cfg).bfloat16().train()
+    ref32 = copy.deepcopy(ref).float()
+    fast = copy.deepcopy(ref).to(env.device)
+    ids = torch.randint(0, 304, (2, 200 if env.big else 48))
+    o_ref = ref(ids, labels=ids)
+    o_ref.loss.backward()
+    o32 = ref32(ids, labels=ids)
+    o32.loss.backward()
+    transformers_amd.accelerate(fast)
+    o = fast(ids.to(env.device), labels=ids.to(env.device))
+    o.loss.backward()
+    assert rel_err(o.logits, o32.logits) <= 1.1 * rel_err(o_ref.logits, o32.logits) + 1e-3
+    _grad_parity(fast, ref, ref32)

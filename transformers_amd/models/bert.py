@@ -1,1 +1,150 @@
-REPLACEMENTS = {}
+"""MI355X execution path for the BERT encoder blocks (src/transformers/models/bert/modeling_bert.py).
+
+Post-LN blocks with biases: `LayerNorm(dropout(dense(x)) + residual)`.  The fused forms below are used when
+dropout is inactive (eval mode or p = 0); otherwise the reference forward runs over the swapped leaf modules
+(TamdLinear / TamdLayerNorm) with torch's dropout in between.
+"""
+from __future__ import annotations
+
+import torch
+from transformers.models.bert import modeling_bert as ref
+
+from .. import ops
+from ..fused_params import FusedWeights
+from .common import _gpu
+
+
+def _no_dropout(mod) -> bool:
+    return (not mod.training) or mod.dropout.p == 0.0
+
+
+class TamdBertSelfAttention(ref.BertSelfAttention):
+    """BertSelfAttention.forward, modeling_bert.py:164-203: one fused QKV GEMM (+bias) and the flash kernel."""
+
+    def _fused(self) -> FusedWeights:
+        fw = self.__dict__.get("_tamd_qkv")
+        if fw is None:
+            fw = FusedWeights([self.query, self.key, self.value])
+            self.__dict__["_tamd_qkv"] = fw
+        return fw
+
+    def forward(self, hidden_states, attention_mask=None, past_key_values=None, **kwargs):
+        d = self.attention_head_size
+        if not (_gpu(hidden_states) and past_key_values is None and _no_dropout(self) and d in (64, 128)
+                and hidden_states.dtype in (torch.bfloat16, torch.float16)
+                and self.config._attn_implementation == "tamd" and not kwargs.get("output_attentions", False)):
+            return super().forward(hidden_states, attention_mask=attention_mask, past_key_values=past_key_values,
+                                   **kwargs)
+        b, s, h = hidden_states.shape
+        nh = self.num_attention_heads
+        qkv = self._fused().linear(hidden_states)  # [B,S,3h]
+        q = qkv[..., :h].view(b, s, nh, d)
+        k = qkv[..., h:2 * h].view(b, s, nh, d)
+        v = qkv[..., 2 * h:].view(b, s, nh, d)
+        key_valid = None
+        if attention_mask is not None:
+            from ..attention import _key_valid_from_mask
+            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid)
+        return o.view(b, s, h), None
+
+
+class _DenseResidualLN:
+    """dense -> (+bias, +residual in the GEMM epilogue) -> LayerNorm: BertSelfOutput / BertOutput."""
+
+    def _fast(self, hidden_states, input_tensor):
+        y = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+        return ops.layernorm(y, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+    def _ok(self, x):
+        return (_gpu(x) and _no_dropout(self) and x.dtype in (torch.bfloat16, torch.float16)
+                and self.dense.bias is not None)
+
+
+class TamdBertSelfOutput(_DenseResidualLN, ref.BertSelfOutput):
+    """modeling_bert.py:289-293"""
+
+    def forward(self, hidden_states, input_tensor):
+        if not self._ok(hidden_states):
+            return ref.BertSelfOutput.forward(self, hidden_states, input_tensor)
+        return self._fast(hidden_states, input_tensor)
+
+
+class TamdBertOutput(_DenseResidualLN, ref.BertOutput):
+    """modeling_bert.py:347-351"""
+
+    def forward(self, hidden_states, input_tensor):
+        if not self._ok(hidden_states):
+            return ref.BertOutput.forward(self, hidden_states, input_tensor)
+        return self._fast(hidden_states, input_tensor)
+
+
+class TamdBertIntermediate(ref.BertIntermediate):
+    """dense + GELU, modeling_bert.py:334-337: bias and activation live in the GEMM epilogue."""
+
+    def forward(self, hidden_states):
+        act = getattr(self, "_tamd_act", None)
+        if act is None:  # BertIntermediate keeps only the callable: recover its name from ACT2FN
+            from transformers.activations import ACT2FN
+            fn = self.intermediate_act_fn
+            act = next((k for k in ("gelu", "gelu_new", "quick_gelu", "silu", "gelu_pytorch_tanh")
+                        if type(ACT2FN[k]) is type(fn)), "")
+            self._tamd_act = act
+        if not (_gpu(hidden_states) and act in ops.ACT_CODES and ops.ACT_CODES[act] != ops.ACT_NONE
+                and hidden_states.dtype in (torch.bfloat16, torch.float16) and self.dense.bias is not None):
+            return super().forward(hidden_states)
+        return ops.linear(hidden_states, self.dense.weight, self.dense.bias, act=ops.ACT_CODES[act])
+
+
+class BertEmbeddingsFn(torch.autograd.Function):
+    """BertEmbeddings.forward (modeling_bert.py:68-108) as one kernel: 3 gathers + 2 adds + LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, padding_idx):
+        need = any(ctx.needs_input_grad)
+        out, pre, mean, rstd = ops.raw_bert_embeddings_fwd(input_ids, token_type_ids, position_ids, word, typ, pos,
+                                                           ln_w, ln_b, eps, keep_pre_ln=need)
+        if need:
+            ctx.save_for_backward(input_ids, token_type_ids, position_ids, pre, ln_w, mean, rstd)
+            ctx.meta = (word.shape[0], typ.shape[0], pos.shape[0], padding_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        input_ids, token_type_ids, position_ids, pre, ln_w, mean, rstd = ctx.saved_tensors
+        vocab, tvocab, npos, padding_idx = ctx.meta
+        d_pre, dw, db = ops.raw_layernorm_bwd(dy, pre, ln_w, mean, rstd)
+        d_word = ops.raw_embedding_bwd(input_ids, d_pre, vocab, padding_idx)
+        d_typ = ops.raw_embedding_bwd(token_type_ids, d_pre, tvocab, None)
+        d_pos = ops.raw_embedding_bwd(position_ids, d_pre, npos, None)
+        return None, None, None, d_word, d_typ, d_pos, dw, db, None, None
+
+
+class TamdBertEmbeddings(ref.BertEmbeddings):
+    def forward(self, input_ids=None, token_type_ids=None, position_ids=None, inputs_embeds=None,
+                past_key_values_length=0):
+        w = self.word_embeddings.weight
+        if not (input_ids is not None and inputs_embeds is None and _gpu(w) and _no_dropout(self)
+                and w.shape[1] % 8 == 0 and w.shape[1] <= 4096
+                and w.dtype in (torch.bfloat16, torch.float16, torch.float32)):
+            return super().forward(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
+                                   inputs_embeds=inputs_embeds, past_key_values_length=past_key_values_length)
+        b, s = input_ids.shape
+        if position_ids is None:
+            position_ids = self.position_ids[:, past_key_values_length: s + past_key_values_length]
+        if token_type_ids is None:
+            token_type_ids = torch.zeros_like(input_ids)
+        position_ids = position_ids.expand(b, s)
+        token_type_ids = token_type_ids.expand(b, s)
+        return BertEmbeddingsFn.apply(input_ids, token_type_ids, position_ids, w, self.token_type_embeddings.weight,
+                                      self.position_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
+                                      float(self.LayerNorm.eps), self.word_embeddings.padding_idx)
+
+
+REPLACEMENTS = {
+    ref.BertSelfAttention: TamdBertSelfAttention,
+    ref.BertSelfOutput: TamdBertSelfOutput,
+    ref.BertOutput: TamdBertOutput,
+    ref.BertIntermediate: TamdBertIntermediate,
+    ref.BertEmbeddings: TamdBertEmbeddings,
+}

@@ -1,1 +1,93 @@
-REPLACEMENTS = {}
+"""MI355X execution path for the CLIP vision/text encoder blocks (src/transformers/models/clip/modeling_clip.py),
+used by LLaVA's vision tower (BASELINE config 5).  Pre-LN blocks with biases and `quick_gelu`.
+
+`CLIPEncoderLayer` stays a hookable module with a tensor output (LLaVA reads hidden_states[-2] through the
+output-capturing hooks, models/llava/modeling_llava.py:154-166), so fusion stops at the layer boundary."""
+from __future__ import annotations
+
+import torch
+from transformers.models.clip import modeling_clip as ref
+
+from .. import ops
+from ..fused_params import FusedWeights
+from .common import _gpu
+
+
+class TamdCLIPAttention(ref.CLIPAttention):
+    """CLIPAttention.forward, modeling_clip.py:298-335: fused QKV GEMM (+bias), flash kernel, out_proj."""
+
+    def _fused(self) -> FusedWeights:
+        fw = self.__dict__.get("_tamd_qkv")
+        if fw is None:
+            fw = FusedWeights([self.q_proj, self.k_proj, self.v_proj])
+            self.__dict__["_tamd_qkv"] = fw
+        return fw
+
+    def forward(self, hidden_states, attention_mask=None, **kwargs):
+        d = self.head_dim
+        if not (_gpu(hidden_states) and d in (64, 128) and hidden_states.dtype in (torch.bfloat16, torch.float16)
+                and self.config._attn_implementation == "tamd" and not (self.training and self.dropout > 0)
+                and not kwargs.get("output_attentions", False)):
+            return super().forward(hidden_states, attention_mask=attention_mask, **kwargs)
+        b, s, h = hidden_states.shape
+        nh = self.num_heads
+        qkv = self._fused().linear(hidden_states)
+        q = qkv[..., :h].view(b, s, nh, d)
+        k = qkv[..., h:2 * h].view(b, s, nh, d)
+        v = qkv[..., 2 * h:].view(b, s, nh, d)
+        key_valid = None
+        if attention_mask is not None:
+            from ..attention import _key_valid_from_mask
+            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        causal = bool(kwargs.get("is_causal", self.is_causal)) and s > 1
+        o = ops.attention(q, k, v, float(self.scale), causal, key_valid)
+        return ops.linear(o.view(b, s, h), self.out_proj.weight, self.out_proj.bias), None
+
+
+class TamdCLIPMLP(ref.CLIPMLP):
+    """CLIPMLP.forward, modeling_clip.py:346-350: fc1 + bias + activation in one GEMM epilogue, then fc2."""
+
+    def forward(self, hidden_states):
+        act = self.config.hidden_act
+        if not (_gpu(hidden_states) and isinstance(act, str) and ops.ACT_CODES.get(act, 0) != ops.ACT_NONE
+                and hidden_states.dtype in (torch.bfloat16, torch.float16) and self.fc1.bias is not None):
+            return super().forward(hidden_states)
+        hmid = ops.linear(hidden_states, self.fc1.weight, self.fc1.bias, act=ops.ACT_CODES[act])
+        return ops.linear(hmid, self.fc2.weight, self.fc2.bias)
+
+
+class TamdCLIPEncoderLayer(ref.CLIPEncoderLayer):
+    """CLIPEncoderLayer.forward, modeling_clip.py:362-383: residual adds folded into the out_proj / fc2 GEMMs."""
+
+    def forward(self, hidden_states, attention_mask, **kwargs):
+        attn, mlp = self.self_attn, self.mlp
+        x = hidden_states
+        act = mlp.config.hidden_act
+        if not (isinstance(attn, TamdCLIPAttention) and isinstance(mlp, TamdCLIPMLP) and _gpu(x)
+                and x.dtype in (torch.bfloat16, torch.float16) and attn.head_dim in (64, 128)
+                and attn.config._attn_implementation == "tamd" and not (self.training and attn.dropout > 0)
+                and isinstance(act, str) and ops.ACT_CODES.get(act, 0) != ops.ACT_NONE
+                and not (attn._forward_hooks or mlp._forward_hooks or kwargs.get("output_attentions", False))):
+            return super().forward(hidden_states, attention_mask, **kwargs)
+        b, s, h = x.shape
+        nh, d = attn.num_heads, attn.head_dim
+        y = ops.layernorm(x, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
+        qkv = attn._fused().linear(y)
+        key_valid = None
+        if attention_mask is not None:
+            from ..attention import _key_valid_from_mask
+            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        causal = bool(kwargs.get("is_causal", attn.is_causal)) and s > 1
+        o = ops.attention(qkv[..., :h].view(b, s, nh, d), qkv[..., h:2 * h].view(b, s, nh, d),
+                          qkv[..., 2 * h:].view(b, s, nh, d), float(attn.scale), causal, key_valid)
+        x = ops.linear(o.view(b, s, h), attn.out_proj.weight, attn.out_proj.bias, residual=x)
+        y = ops.layernorm(x, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
+        hmid = ops.linear(y, mlp.fc1.weight, mlp.fc1.bias, act=ops.ACT_CODES[act])
+        return ops.linear(hmid, mlp.fc2.weight, mlp.fc2.bias, residual=x)
+
+
+REPLACEMENTS = {
+    ref.CLIPAttention: TamdCLIPAttention,
+    ref.CLIPMLP: TamdCLIPMLP,
+    ref.CLIPEncoderLayer: TamdCLIPEncoderLayer,
+}

@@ -107,10 +107,11 @@ def raw_rmsnorm_fwd(x, w, eps, residual=None):
     x2 = _c(x).view(-1, cols)
     r2 = None if residual is None else _c(residual).view(-1, cols)
     be = _prep(x2, w, r2)
+    w = _c(w)
     y = torch.empty_like(x2)
     h = torch.empty_like(x2) if r2 is not None else x2
     rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
-    be.lib.check(be.lib.tamd_rmsnorm_fwd(_p(x2), _p(r2), _p(_c(w)), _p(y), _p(h) if r2 is not None else None,
+    be.lib.check(be.lib.tamd_rmsnorm_fwd(_p(x2), _p(r2), _p(w), _p(y), _p(h) if r2 is not None else None,
                                          _p(rstd), x2.shape[0], cols, float(eps), _code(x2), be.stream(x2)),
                  "tamd_rmsnorm_fwd")
     return y.view(x.shape), h.view(x.shape), rstd
@@ -121,12 +122,13 @@ def raw_rmsnorm_bwd(dy, h, w, rstd, dres=None):
     dy2, h2 = _c(dy).view(-1, cols), _c(h).view(-1, cols)
     dr2 = None if dres is None else _c(dres).view(-1, cols)
     be = _prep(dy2, h2, w, dr2)
+    w = _c(w)
     rows = h2.shape[0]
     dx = torch.empty_like(h2)
     dw = torch.empty_like(w)
     nbytes = be.lib.tamd_norm_bwd_workspace_bytes(rows, cols)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
-    be.lib.check(be.lib.tamd_rmsnorm_bwd(_p(dy2), _p(h2), _p(_c(w)), _p(rstd), _p(dr2), _p(dx), _p(dw), _p(ws), nbytes,
+    be.lib.check(be.lib.tamd_rmsnorm_bwd(_p(dy2), _p(h2), _p(w), _p(rstd), _p(dr2), _p(dx), _p(dw), _p(ws), nbytes,
                                          rows, cols, _code(h2), be.stream(h2)), "tamd_rmsnorm_bwd")
     return dx.view(h.shape), dw
 
@@ -136,11 +138,13 @@ def raw_layernorm_fwd(x, w, b, eps, residual=None):
     x2 = _c(x).view(-1, cols)
     r2 = None if residual is None else _c(residual).view(-1, cols)
     be = _prep(x2, w, b, r2)
+    w = _c(w)
+    b = None if b is None else _c(b)
     y = torch.empty_like(x2)
     h = torch.empty_like(x2) if r2 is not None else x2
     mean = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    be.lib.check(be.lib.tamd_layernorm_fwd(_p(x2), _p(r2), _p(_c(w)), _p(None if b is None else _c(b)), _p(y),
+    be.lib.check(be.lib.tamd_layernorm_fwd(_p(x2), _p(r2), _p(w), _p(b), _p(y),
                                            _p(h) if r2 is not None else None, _p(mean), _p(rstd), x2.shape[0], cols,
                                            float(eps), _code(x2), be.stream(x2)), "tamd_layernorm_fwd")
     return y.view(x.shape), h.view(x.shape), mean, rstd
@@ -151,13 +155,14 @@ def raw_layernorm_bwd(dy, h, w, mean, rstd, dres=None, need_db=True):
     dy2, h2 = _c(dy).view(-1, cols), _c(h).view(-1, cols)
     dr2 = None if dres is None else _c(dres).view(-1, cols)
     be = _prep(dy2, h2, w, dr2)
+    w = _c(w)
     rows = h2.shape[0]
     dx = torch.empty_like(h2)
     dw = torch.empty_like(w)
     db = torch.empty_like(w) if need_db else None
     nbytes = be.lib.tamd_norm_bwd_workspace_bytes(rows, cols)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
-    be.lib.check(be.lib.tamd_layernorm_bwd(_p(dy2), _p(h2), _p(_c(w)), _p(mean), _p(rstd), _p(dr2), _p(dx), _p(dw),
+    be.lib.check(be.lib.tamd_layernorm_bwd(_p(dy2), _p(h2), _p(w), _p(mean), _p(rstd), _p(dr2), _p(dx), _p(dw),
                                            _p(db), _p(ws), nbytes, rows, cols, _code(h2), be.stream(h2)),
                  "tamd_layernorm_bwd")
     return dx.view(h.shape), dw, db
@@ -182,8 +187,9 @@ def raw_embedding_fwd(ids, table):
     ids_c = _c(ids)
     if ids_c.dtype != torch.int64:
         ids_c = ids_c.long()
+    table = _c(table)
     out = torch.empty(*ids.shape, table.shape[1], dtype=table.dtype, device=table.device)
-    be.lib.check(be.lib.tamd_embedding_fwd(_p(ids_c), _p(_c(table)), _p(out), ids_c.numel(), table.shape[0],
+    be.lib.check(be.lib.tamd_embedding_fwd(_p(ids_c), _p(table), _p(out), ids_c.numel(), table.shape[0],
                                            table.shape[1], None, _code(table), be.stream(table)),
                  "tamd_embedding_fwd")
     return out
@@ -210,9 +216,12 @@ def raw_bert_embeddings_fwd(input_ids, token_type_ids, position_ids, word, typ, 
     pre = torch.empty_like(out) if keep_pre_ln else None
     mean = torch.empty(n, dtype=torch.float32, device=word.device)
     rstd = torch.empty_like(mean)
+    # named locals: the converted operands must outlive the launch call
+    iid, tid, pid = _c(input_ids).long(), _c(token_type_ids).long(), _c(position_ids).long()
+    word, typ, pos, ln_w, ln_b = _c(word), _c(typ), _c(pos), _c(ln_w), _c(ln_b)
     be.lib.check(be.lib.tamd_bert_embeddings_fwd(
-        _p(_c(input_ids).long()), _p(_c(token_type_ids).long()), _p(_c(position_ids).long()), _p(_c(word)),
-        _p(_c(typ)), _p(_c(pos)), _p(_c(ln_w)), _p(_c(ln_b)), _p(out), _p(pre), _p(mean), _p(rstd), n, dim,
+        _p(iid), _p(tid), _p(pid), _p(word), _p(typ), _p(pos), _p(ln_w), _p(ln_b), _p(out), _p(pre), _p(mean),
+        _p(rstd), n, dim,
         word.shape[0], typ.shape[0], pos.shape[0], float(eps), _code(word), be.stream(word)),
         "tamd_bert_embeddings_fwd")
     return out, pre, mean, rstd
