@@ -44,7 +44,13 @@ struct WaveState {
   const void* ptr_in[kWave];
 };
 
+struct PendingDma {  // an issued, not yet landed direct-to-LDS load of one lane
+  char* dst;
+  unsigned char data[16];
+};
+
 struct Fiber {
+  std::vector<PendingDma> pending;
   ucontext_t ctx;
   char* stack = nullptr;
   bool done = false;
@@ -149,6 +155,7 @@ inline void run_block(Block* b, const std::function<void()>& body, dim3 bid, dim
   for (int i = 0; i < n; ++i) {
     Fiber& f = b->fibers[i];
     f.done = false;
+    f.pending.clear();
     f.linear = i;
     f.tid = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
     b->waves[i / kWave].live++;
@@ -160,7 +167,11 @@ inline void run_block(Block* b, const std::function<void()>& body, dim3 bid, dim
   }
   while (b->live > 0) {
     const uint64_t before = b->progress;
-    for (int i = 0; i < n; ++i) {
+    // HIPEMU_REVERSE=1 walks the fibers backwards: races between wave groups that share a phase show up in
+    // one of the two orders (the DMA model poisons at issue and lands at the issuer's wait).
+    static const bool reverse = getenv("HIPEMU_REVERSE") != nullptr;
+    for (int k = 0; k < n; ++k) {
+      const int i = reverse ? n - 1 - k : k;
       if (b->fibers[i].done) continue;
       b->cur = i;
       swapcontext(&b->sched, &b->fibers[i].ctx);

@@ -297,16 +297,9 @@ inline u32x2 lds_read8_tr16(const char* smem, unsigned off) {
 // model: the destination is POISONED (0xFFFF = bf16/f16 NaN) at issue and the data lands only at the
 // issuing lane's wait_vmcnt0().  A read before the wait, or another wave still reading the previous
 // contents of the buffer after the issue (WAR), therefore yields NaNs that the parity tests catch.
-struct EmuPendingGlds {
-  char* dst;
-  unsigned char data[16];
-};
-inline thread_local std::vector<std::vector<EmuPendingGlds>> g_pending;  // per fiber of the running block
-inline std::vector<EmuPendingGlds>& emu_pending() {
-  const size_t n = hipemu::g_blk->fibers.size();
-  if (g_pending.size() < n) g_pending.resize(n);
-  return g_pending[hipemu::cur_fiber().linear];
-}
+typedef hipemu::PendingDma EmuPendingGlds;
+inline std::vector<EmuPendingGlds>& emu_pending() { return hipemu::cur_fiber().pending; }
+template <int AUX = 0>
 inline void glds16(const void* gsrc, char* smem, unsigned wave_base_off) {
   const int lane = hipemu::cur_lane();
   // the base must be wave-uniform: check through a collective
@@ -336,12 +329,23 @@ inline void wait_vmcnt0() {
   for (auto& p : q) memcpy(p.dst, p.data, 16);
   q.clear();
 }
+template <int N>
+inline void wait_vmcnt() {  // oldest-first completion until at most N remain in flight
+  auto& q = emu_pending();
+  size_t done = q.size() > (size_t)N ? q.size() - (size_t)N : 0;
+  for (size_t i = 0; i < done; ++i) memcpy(q[i].dst, q[i].data, 16);
+  q.erase(q.begin(), q.begin() + done);
+}
+inline void wait_lgkmcnt0() {}
+inline void raw_barrier() { __syncthreads(); }
+inline void sched_fence() {}
 inline void block_sync() { __syncthreads(); }
 inline void wave_lockstep_point() {
   hipemu::wave_collective([&](hipemu::WaveState&, int) {});
 }
 inline void setprio_hi() {}
 inline void setprio_lo() {}
+inline unsigned long long device_clock() { return 0ull; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_log2(float x) { return log2f(x); }

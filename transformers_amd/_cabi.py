@@ -61,9 +61,11 @@ SIGNATURES = {
     "tamd_cross_entropy_fwd": (c_int, [P, P, P, P, I64, I64, I64, I64, c_int, P]),
     "tamd_cross_entropy_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, c_int, P]),
     "tamd_gemm": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P]),
+    "tamd_gemm_trace": (c_int, [P, P, P, I64, I64, I64, P, P]),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),
     "tamd_attn_bwd": (c_int, [POINTER(AttnBwdParams), P]),
     "tamd_probe": (c_int, [P, P, P, c_int, c_int, P]),
+    "tamd_bw_probe": (c_int, [P, c_size_t, c_int, c_size_t, c_int, c_int, c_int, P, P]),
 }
 
 

@@ -54,9 +54,53 @@ __global__ void probe_kernel(const unsigned int* __restrict__ in, const unsigned
   }
 }
 
+// Bandwidth probe: every wave of every workgroup streams `iters` x 1 KiB pieces of an L2/MALL-resident
+// buffer into LDS (MODE 0: LDS-DMA, MODE 1: global_load -> VGPR -> ds_write) with a GEMM-like address pattern:
+// `seg` contiguous bytes per row (64 / 128 / 1024), rows `row_stride` bytes apart.
+template <int MODE>
+__global__ __launch_bounds__(512) void bw_probe_kernel(const char* __restrict__ buf, size_t bytes, int seg,
+                                                        size_t row_stride, int iters, unsigned int* sink) {
+  TAMD_DYN_SMEM(smem);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lanes_per_row = seg / 16;
+  const int rows_per_inst = 64 / lanes_per_row;
+  const size_t lane_off = (size_t)(lane / lanes_per_row) * row_stride + (size_t)(lane % lanes_per_row) * 16;
+  size_t base = ((size_t)blockIdx.x * 8 + wave) * (size_t)rows_per_inst * row_stride;
+  unsigned acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    const size_t off = (base + (size_t)it * seg + lane_off) % (bytes - 16);
+    const char* src = buf + (off & ~(size_t)15);
+    if (MODE == 0) {
+      glds16(src, smem, (unsigned)(wave * 8 + (it & 7)) * 1024u);
+      if ((it & 7) == 7) wait_vmcnt<4>();
+    } else {
+      const u32x4 v = ld16(src);
+      lds_write16(smem, (unsigned)(wave * 8 + (it & 7)) * 1024u + (unsigned)lane * 16u, v);
+    }
+  }
+  wait_vmcnt<0>();
+  block_sync();
+  acc = lds_read16(smem, (unsigned)threadIdx.x * 16u)[0];
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 }  // namespace tamd
 
 using namespace tamd;
+
+extern "C" int tamd_bw_probe(const void* buf, size_t bytes, int seg, size_t row_stride, int iters, int mode,
+                             int blocks, void* sink, tamd_stream_t stream) {
+  if (!buf || !sink) return TAMD_E_NULL;
+  if (seg != 64 && seg != 128 && seg != 256 && seg != 1024) return TAMD_E_ARG;
+  if (mode == 0)
+    hipLaunchKernelGGL((bw_probe_kernel<0>), dim3((unsigned)blocks), dim3(512), (size_t)65536, TAMD_STREAM(stream),
+                       (const char*)buf, bytes, seg, row_stride, iters, (unsigned int*)sink);
+  else
+    hipLaunchKernelGGL((bw_probe_kernel<1>), dim3((unsigned)blocks), dim3(512), (size_t)65536, TAMD_STREAM(stream),
+                       (const char*)buf, bytes, seg, row_stride, iters, (unsigned int*)sink);
+  return launch_status();
+}
+
 
 // in: 4096 u32 (16 KiB), in2: 64 u32, out: 4096 u32.  One wave.
 extern "C" int tamd_probe(const void* in, const void* in2, void* out, int which, int dtype, tamd_stream_t stream) {

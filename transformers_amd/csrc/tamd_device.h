@@ -118,11 +118,28 @@ __device__ __forceinline__ u32x2 lds_read8_tr16(const char* smem, unsigned off) 
 // Direct-to-LDS 16-byte load: the wave writes 64 x 16 B = 1 KiB contiguous at
 // `smem + wave_base_off` (must be wave-uniform); each lane supplies its own
 // global source address.  Completion is tracked by vmcnt.
+// AUX = cache policy bits of the load (0 default, 1 sc0, 2 nt, 16 sc1).
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, char* smem, unsigned wave_base_off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)(smem + wave_base_off), 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)(smem + wave_base_off), 16, 0, AUX);
 }
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// counted wait: returns when at most N of this wave's vector-memory operations (incl. LDS-DMA) are pending
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkmcnt0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Workgroup barrier WITHOUT the vmcnt(0) drain that __syncthreads() implies while LDS-DMA is in flight
+// (cdna_hip_programming.md §5 "Pipelining across barriers"): the caller places its own counted waits.
+__device__ __forceinline__ void raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// pin the instruction scheduler at a phase boundary (MFMAs are register-only and would otherwise drift)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
 // A wave executes in lockstep on hardware, so LDS writes of one lane are visible to the other lanes of
 // the SAME wave at the next DS instruction (DS ops of a wave retire in order).  This marks such a point
@@ -130,6 +147,9 @@ __device__ __forceinline__ void block_sync() { __syncthreads(); }
 __device__ __forceinline__ void wave_lockstep_point() { __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ void setprio_hi() { __builtin_amdgcn_s_setprio(1); }
 __device__ __forceinline__ void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
+
+// shader clock (s_memtime), for the in-kernel phase traces of the diagnostic GEMM variant
+__device__ __forceinline__ unsigned long long device_clock() { return __builtin_amdgcn_s_memtime(); }
 
 // fast transcendental pieces
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
