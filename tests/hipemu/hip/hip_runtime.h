@@ -29,6 +29,7 @@ inline hipError_t hipGetLastError() { return hipemu::g_fail.exchange(0) ? 719 : 
 #define blockDim (hipemu::g_blk->bdim)
 #define gridDim (hipemu::g_blk->gdim)
 
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 inline void __syncthreads() { hipemu::syncthreads(); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \

@@ -22,7 +22,7 @@ OBJ_DIR = HERE / "_build"
 SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "probe.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
-         "-Wno-unused-result", "-I", str(CSRC), "-I", str(INCLUDE)]
+         "-Wno-unused-result", "-I", str(CSRC), "-I", str(INCLUDE)] + os.environ.get("TAMD_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:
@@ -41,8 +41,17 @@ def _digest(paths) -> str:
     return h.hexdigest()
 
 
+# per-source extra flags, overridable for experiments: TAMD_FLAGS_<stem>="..."
+# attention.hip: keep MFMA results in arch VGPRs (the softmax reads every S/P element with VALU ops; the default
+# AGPR form costs a v_accvgpr_read/write per element): +39 % forward, +11 % backward on MI355X.  The same option
+# crashes clang 22 (ROCm 7.2) on gemm.hip, where it would not matter (accumulators are only touched by MFMA).
+PER_SOURCE_FLAGS: dict = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _compile(hipcc: str, src: Path, obj: Path, verbose: bool) -> None:
-    cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
+    extra = os.environ.get(f"TAMD_FLAGS_{src.stem}", None)
+    extra = extra.split() if extra is not None else PER_SOURCE_FLAGS.get(src.name, [])
+    cmd = [hipcc, *FLAGS, *extra, "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

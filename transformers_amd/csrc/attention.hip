@@ -72,6 +72,44 @@ __device__ __forceinline__ void issue_kv_tile(const T* __restrict__ base, int64_
   }
 }
 
+// Loop-invariant LDS byte offsets of one lane inside a swizzled [64][D] tile (the swizzle terms depend on the
+// lane only), so every tile read in the attention loops is `tile base + offset register + immediate`:
+//   row[ks]   : ds_read_b128 of row l31 (add 32*ROWB for the second 32-row sub-tile), k-step ks
+//   tr[dt][t] : ds_read_b64_tr_b16 of rows 4*hi+kq (+8*t), this lane's 4 columns of d-tile dt; MFMA step j adds
+//               ((j>>1)*32 + (j&1)*16) * ROWB.  The row order delivered matches the C-layout registers
+//               8*(j&1)+jj of sub-tile j>>1 (key/query = sub*32 + 16*(j&1) + 8*(jj>>2) + 4*hi + (jj&3)).
+template <int D>
+struct TileOffsets {
+  unsigned row[D / 16];
+  unsigned tr[D / 32][2];
+  __device__ __forceinline__ void init(int lane) {
+    constexpr int ROWB = D * 2;
+    const int hi = lane >> 5, l31 = lane & 31, kq = (lane & 15) >> 2;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks)
+      row[ks] = (unsigned)l31 * ROWB + (unsigned)(((ks * 2 + hi) ^ row_swz<D>(l31)) * 16);
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt) {
+      const int col = dt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int r = 4 * hi + kq + 8 * t2;
+        tr[dt][t2] = (unsigned)r * ROWB + (unsigned)(((col >> 3) ^ row_swz<D>(r)) * 16) + (unsigned)(col & 7) * 2u;
+      }
+    }
+  }
+  // MFMA A operand [32 d][16 rows] for step j (transposing reads)
+  __device__ __forceinline__ u32x4 read_tr(const char* smem, unsigned tile_off, int dt, int j) const {
+    const unsigned rb = (unsigned)(((j >> 1) * 32 + (j & 1) * 16) * (D * 2));
+    const u32x2 lo = lds_read8_tr16(smem, tile_off + tr[dt][0] + rb);
+    const u32x2 h2 = lds_read8_tr16(smem, tile_off + tr[dt][1] + rb);
+    return u32x4{lo[0], lo[1], h2[0], h2[1]};
+  }
+  __device__ __forceinline__ u32x4 read_row(const char* smem, unsigned tile_off, int sub, int ks) const {
+    return lds_read16(smem, tile_off + row[ks] + (unsigned)(sub * 32 * D * 2));
+  }
+};
+
 template <typename T, int D, bool CAUSAL, bool HAS_MASK>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   constexpr int ROWB = D * 2;
@@ -123,7 +161,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // running max (log2 domain, scaled) and row sum of this lane's key half
 
   int kend = a.seq_k;
   if (CAUSAL) {
@@ -132,6 +170,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
     if (kend < 0) kend = 0;
   }
   const int nkt = (kend + kKB - 1) / kKB;
+
+  TileOffsets<D> toff;
+  toff.init(lane);
+  constexpr float kDeferThr = 6.f;  // skip the O rescale while the row max grows by < 2^6 (cdna guide T13)
 
   auto issue = [&](int t, int buf) {
     const unsigned k_off = (unsigned)buf * 2u * TILEB, v_off = k_off + TILEB;
@@ -156,44 +198,50 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
       for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
-        const int krow = sub * 32 + l31;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int slot = (ks * 2 + hi) ^ row_swz<D>(krow);
-          const u32x4 kf = lds_read16(smem, k_off + (unsigned)krow * ROWB + (unsigned)slot * 16u);
-          s[sub] = mfma32<T>(kf, qf[ks], s[sub]);
-        }
+        for (int ks = 0; ks < KS; ++ks)
+          s[sub] = mfma32<T>(toff.read_row(smem, k_off, sub, ks), qf[ks], s[sub]);
       }
-      // ---- scale to the log2 domain, mask
-      unsigned long long vmask = ~0ull;
-      if (HAS_MASK) {
-        const int kp = kt0 + lane;
-        const bool ok = kp < a.seq_k && a.key_valid[(int64_t)b * a.seq_k + kp] != 0;
-        vmask = ballot64(ok);
-      }
+      // ---- mask (diagonal / ragged / padded tiles only: wave-uniform branch, the common tile has no mask code)
       const bool need_mask = HAS_MASK || (kt0 + kKB > a.seq_k) || (CAUSAL && (kt0 + kKB - 1 > qw0 + off));
-      float mx = -INFINITY;
+      if (need_mask) {
+        unsigned long long vmask = ~0ull;
+        if (HAS_MASK) {
+          const int kp = kt0 + lane;
+          vmask = ballot64(kp < a.seq_k && a.key_valid[(int64_t)b * a.seq_k + kp] != 0);
+        }
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float x = s[sub][r] * a.scale_log2;
-          if (need_mask) {
+          for (int r = 0; r < 16; ++r) {
             const int kl = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // key index inside the tile
             const int kp = kt0 + kl;
             bool vis = kp < a.seq_k;
             if (CAUSAL) vis = vis && (kp <= qrow + off);
             if (HAS_MASK) vis = vis && ((vmask >> kl) & 1ull);
-            x = vis ? x : -INFINITY;
+            s[sub][r] = vis ? s[sub][r] : -INFINITY;
           }
-          s[sub][r] = x;
-          mx = fmaxf(mx, x);
-        }
+      }
+      // ---- online softmax in the exp2 domain: p = exp2(s*c - m), c = scale*log2(e) > 0
+      float mx = s[0][0];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
       mx = fmaxf(mx, swap32_f32(mx));  // the other half-wave holds the other 32 keys of this query
-      const float m_new = fmaxf(m_run, mx);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at 0
-      const float alpha = fast_exp2(m_run - m_use);            // m_run = -inf -> 0
-      m_run = m_new;
+      const float m_tile = mx * a.scale_log2;
+      // deferred rescale: keep the old reference max while no row of the wave outgrows it by 2^thr
+      if (ballot64(m_tile - m_run > kDeferThr) != 0ull) {
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(m_run - m_new);  // m_run = -inf -> 0
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      }
+      const float m_ref = (m_run == -INFINITY) ? 0.f : m_run;  // row fully masked so far: every p is exp2(-inf) = 0
       float psum = 0.f;
       u32x4 pf[4];  // P^T as MFMA B operand: step j covers registers 8*(j&1).. of sub-tile j>>1
 #pragma unroll
@@ -201,9 +249,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
         float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          // the reference rounds softmax probabilities to the storage dtype before P.V; the row sum
-          // uses the unrounded fp32 values like softmax(dtype=float32) does.
-          p[r] = fast_exp2(s[sub][r] - m_use);
+          // the reference rounds softmax probabilities to the storage dtype before P.V; the row sum uses the
+          // unrounded fp32 values like softmax(dtype=float32) does.
+          p[r] = fast_exp2(__builtin_fmaf(s[sub][r], a.scale_log2, -m_ref));
           psum += p[r];
         }
 #pragma unroll
@@ -211,27 +259,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
           pf[sub * 2 + st] = u32x4{pack2<T>(p[8 * st + 0], p[8 * st + 1]), pack2<T>(p[8 * st + 2], p[8 * st + 3]),
                                    pack2<T>(p[8 * st + 4], p[8 * st + 5]), pack2<T>(p[8 * st + 6], p[8 * st + 7])};
       }
-      l_run = l_run * alpha + psum;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+      l_run += psum;
       // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]
       // step (sub, st): P registers r = 8*st + j  <->  key = sub*32 + 16*st + 8*(j>>2) + 4*hi + (j&3)
-      const int kq = (lane & 15) >> 2;  // row of the 4-key block this lane addresses
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int col = dt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-        const unsigned inner = (unsigned)(col & 7) * 2u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int kb = (j >> 1) * 32 + (j & 1) * 16 + 4 * hi + kq;
-          const int s0 = (col >> 3) ^ row_swz<D>(kb);
-          const int s1 = (col >> 3) ^ row_swz<D>(kb + 8);
-          const u32x2 lo = lds_read8_tr16(smem, v_off + (unsigned)kb * ROWB + (unsigned)s0 * 16u + inner);
-          const u32x2 hi2 = lds_read8_tr16(smem, v_off + (unsigned)(kb + 8) * ROWB + (unsigned)s1 * 16u + inner);
-          oacc[dt] = mfma32<T>(u32x4{lo[0], lo[1], hi2[0], hi2[1]}, pf[j], oacc[dt]);
-        }
+        for (int j = 0; j < 4; ++j) oacc[dt] = mfma32<T>(toff.read_tr(smem, v_off, dt, j), pf[j], oacc[dt]);
       }
     }
     wait_vmcnt0();

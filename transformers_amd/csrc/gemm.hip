@@ -395,9 +395,15 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
 
   const int nsub = (int)((g.K + kSubK - 1) / kSubK);
   constexpr int AUX = (VAR & 32) ? 2 : ((VAR & 64) ? 1 : ((VAR & 128) ? 16 : 0));
+  // K-sweep rotation (sum over k is order independent): spreads the instantaneous k-window -- and with it the
+  // L2 / fabric channels being hit -- across XCDs (VAR&2048) and/or across the M-tiles of a patch (VAR&4096)
+  int joff = 0;
+  if (VAR & 2048) joff += xcd * (nsub >> 3);
+  if (VAR & 4096) joff += (tile_m & 7) * (nsub >> 3);
+  auto ksub = [&](int j) { return (VAR & (2048 | 4096)) ? (int64_t)((j + joff) % nsub) * kSubK : (int64_t)j * kSubK; };
   auto issue = [&](int j) {  // this wave's share (2 A + 2 B pieces) of sub-tile j into stage j % 4
     const unsigned st = (unsigned)(j & (kRing - 1)) * kStageBytes;
-    const int64_t k0 = (int64_t)j * kSubK;
+    const int64_t k0 = (j < nsub) ? ksub(j) : (int64_t)j * kSubK;
     pp_issue<T, A_KM, AUX>(A, g.lda, m0, g.M, k0, g.K, smem, st, wave, lane);
     pp_issue<T, B_KN, AUX>(B, g.ldb, n0, g.N, k0, g.K, smem, st + kStageOperand, wave, lane);
   };
@@ -597,6 +603,9 @@ static int gemm_pp_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       case 130: TAMD_GV(130) // sc1 loads
       case 258: TAMD_GV(258) // register-staged loads
       case 1026: TAMD_GV(1026) // loads split between LOAD and COMPUTE phases
+      case 2050: TAMD_GV(2050) // K sweep rotated per XCD
+      case 4098: TAMD_GV(4098) // K sweep rotated per M-tile
+      case 6146: TAMD_GV(6146) // both
       case 514: TAMD_GV(514) // ablation: loads + LDS reads, no MFMA
       case 530: TAMD_GV(530) // ablation: loads only
       default: break;
@@ -628,6 +637,220 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
   if (!akm && bkn) return gemm_pp_launch_epi<T, false, true>(g, epilogue, act, s);
   if (akm && bkn) return gemm_pp_launch_epi<T, true, true>(g, epilogue, act, s);
   return gemm_pp_launch_epi<T, true, false>(g, epilogue, act, s);
+}
+
+}  // namespace tamd
+
+// =====================================================================================================
+// v3: one wave per SIMD -- 4 waves x (128 x 128) with all 512 registers  (TAMD_GEMM=v3)
+// =====================================================================================================
+// What the v2 measurements said (profiles/r01_gemm_variants.md): the loop is bound by the global->LDS feed and
+// by the LDS port, not by MFMA scheduling.  This variant halves the number of waves and doubles the per-wave
+// tile: 256 accumulator registers per wave (the unified 512-entry file of gfx950, one wave per SIMD), so a
+// BK=32 step reads 64 KiB of fragments per CU instead of 96 KiB and every wave issues 8 instead of 4 LDS-DMA
+// pieces per step with nobody else on its SIMD: reads for the next k-step and the next sub-tile's loads are
+// interleaved BETWEEN the MFMAs of the current k-step (register double buffer, sched_group_barrier pattern),
+// one barrier per BK=32 step.  Same LDS ring, images, swizzles and epilogue as v2.
+namespace tamd {
+
+constexpr int kW4Threads = 256;
+
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT>
+__global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
+  TAMD_DYN_SMEM(smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+
+  const int nwg = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, in_xcd = bid >> 3;
+  const int q = nwg >> 3, rr = nwg & 7;
+  const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + in_xcd;
+  constexpr int GROUP_M = 8;
+  const int group_size = GROUP_M * g.tiles_n;
+  const int grp = logical / group_size;
+  const int first_m = grp * GROUP_M;
+  const int gm = (g.tiles_m - first_m < GROUP_M) ? (g.tiles_m - first_m) : GROUP_M;
+  const int tile_m = first_m + (logical % group_size) % gm;
+  const int tile_n = (logical % group_size) / gm;
+  const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+
+  f32x16 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  const int nsub = (int)((g.K + kSubK - 1) / kSubK);
+  // 16 wave-instructions per operand stage, 4 waves: pieces [wave*4, wave*4+4) of A and of B
+  auto issue_part = [&](int j, int part) {  // part 0: A pieces, part 1: B pieces (4 LDS-DMA instructions each)
+    const unsigned st = (unsigned)(j & (kRing - 1)) * kStageBytes;
+    const int64_t k0 = (int64_t)j * kSubK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int inst = wave * 4 + i;
+      if (part == 0)
+        glds16(pp_src<T, A_KM>(A, g.lda, m0, g.M, k0, g.K, inst, lane), smem, st + (unsigned)inst * 1024u);
+      else
+        glds16(pp_src<T, B_KN>(B, g.ldb, n0, g.N, k0, g.K, inst, lane), smem,
+               st + kStageOperand + (unsigned)inst * 1024u);
+    }
+  };
+  u32x4 fx[2][4], fw[2][4];  // [buffer][mi / ni]
+  auto read_frags = [&](int j, int ks, int buf) {
+    const unsigned st = (unsigned)(j & (kRing - 1)) * kStageBytes;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) fw[buf][ni] = pp_frag<B_KN>(smem, st + kStageOperand, wn * 128 + ni * 32, ks, lane);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) fx[buf][mi] = pp_frag<A_KM>(smem, st, wm * 128 + mi * 32, ks, lane);
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma32<T>(fw[buf][ni], fx[buf][mi], acc[ni][mi]);
+  };
+  // interleave pattern for one k-step: 16 MFMA, 8 LDS reads, 4 LDS-DMA  ->  4 x { MFMA x4, DS_READ x2, VMEM x1 }
+  auto pattern = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+    }
+  };
+
+  issue_part(0, 0);
+  issue_part(0, 1);
+  issue_part(1, 0);
+  issue_part(1, 1);
+  issue_part(2, 0);
+  issue_part(2, 1);
+  wait_vmcnt<0>();
+  raw_barrier();
+  read_frags(0, 0, 0);
+  for (int j = 0; j < nsub; ++j) {
+    // k-step 0 of sub-tile j (buffer 0) | fetch k-step 1 fragments, first half of sub-tile j+3's loads
+    sched_fence();
+    read_frags(j, 1, 1);
+    issue_part(j + 3, 0);
+    mma(0);
+    pattern();
+    sched_fence();
+    // hand-off: sub-tile j+1 must have landed for everybody; everybody's reads of sub-tile j are in registers
+    wait_vmcnt<12>();  // own pieces of sub-tile j+1 (issued two iterations ago); j+2 (8) and half of j+3 (4) in flight
+    wait_lgkmcnt0();
+    raw_barrier();
+    sched_fence();
+    // k-step 1 (buffer 1) | fetch k-step 0 of sub-tile j+1, second half of sub-tile j+3's loads
+    read_frags(j + 1, 0, 0);
+    issue_part(j + 3, 1);
+    mma(1);
+    pattern();
+    sched_fence();
+  }
+  wait_vmcnt<0>();
+  wait_lgkmcnt0();
+  raw_barrier();
+
+  // ---- epilogue: two passes of 64 rows through the wave's staging region (128 cols -> 272-byte rows)
+  constexpr int kRowB = 128 * 2 + 16;
+  const unsigned st_off = (unsigned)wave * (64u * kRowB);
+  const T* bias = reinterpret_cast<const T*>(g.bias);
+  T* C = reinterpret_cast<T*>(g.C);
+  const T* R = reinterpret_cast<const T*>(g.R);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int nl = ni * 32 + 8 * qd + 4 * hi;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (EPI == TAMD_EPI_BIAS || EPI == TAMD_EPI_BIAS_ACT || (EPI == TAMD_EPI_RESIDUAL && bias != nullptr)) {
+          const int64_t gn = n0 + wn * 128 + nl;
+          if (gn < g.N) {
+            const u32x2 bq = ld8(bias + gn);
+            bv[0] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] & 0xffffu));
+            bv[1] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] >> 16));
+            bv[2] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] & 0xffffu));
+            bv[3] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] >> 16));
+          }
+        }
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const int mi = half * 2 + m2;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[ni][mi][qd * 4 + e] + bv[e];
+            if (EPI == TAMD_EPI_BIAS_ACT) x = gemm_act<ACT>(round_through<T>(x));
+            v[e] = x;
+          }
+          const u32x2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+          lds_write8(smem, st_off + (unsigned)(m2 * 32 + l31) * kRowB + (unsigned)nl * 2u, pk);
+        }
+      }
+    }
+    wave_lockstep_point();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (lane >> 4), slot = lane & 15;
+      const int64_t gm_ = m0 + wm * 128 + half * 64 + row, gn = n0 + wn * 128 + slot * 8;
+      u32x4 v = lds_read16(smem, st_off + (unsigned)row * kRowB + (unsigned)slot * 16u);
+      if (gm_ < g.M && gn < g.N) {
+        if (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) {
+          const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
+          float a[8], b[8];
+          unpack16<T>(v, a);
+          unpack16<T>(ld16(rp), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          v = pack16<T>(a);
+        }
+        st16(C + gm_ * g.ldc + gn, v);
+      }
+    }
+    wave_lockstep_point();
+  }
+}
+
+template <typename T, bool A_KM, bool B_KN>
+static int gemm_w4_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kW4Threads);
+#define TAMD_G(E_, A_)                                                                                \
+  hipLaunchKernelGGL((gemm_w4_kernel<T, A_KM, B_KN, E_, A_>), grid, block, (size_t)kGemmSmem, s, g); \
+  return launch_status();
+  switch (epilogue) {
+    case TAMD_EPI_NONE: TAMD_G(TAMD_EPI_NONE, TAMD_ACT_NONE)
+    case TAMD_EPI_BIAS: TAMD_G(TAMD_EPI_BIAS, TAMD_ACT_NONE)
+    case TAMD_EPI_RESIDUAL: TAMD_G(TAMD_EPI_RESIDUAL, TAMD_ACT_NONE)
+    case TAMD_EPI_ACCUM: TAMD_G(TAMD_EPI_ACCUM, TAMD_ACT_NONE)
+    case TAMD_EPI_BIAS_ACT:
+      switch (act) {
+        case TAMD_ACT_GELU_ERF: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_GELU_ERF)
+        case TAMD_ACT_GELU_TANH: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_GELU_TANH)
+        case TAMD_ACT_QUICK_GELU: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_QUICK_GELU)
+        case TAMD_ACT_SILU: TAMD_G(TAMD_EPI_BIAS_ACT, TAMD_ACT_SILU)
+        default: return TAMD_E_ARG;
+      }
+    default: return TAMD_E_ARG;
+  }
+#undef TAMD_G
+}
+
+template <typename T>
+static int gemm_w4_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
+  const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
+  if (!akm && !bkn) return gemm_w4_launch_epi<T, false, false>(g, epilogue, act, s);
+  if (!akm && bkn) return gemm_w4_launch_epi<T, false, true>(g, epilogue, act, s);
+  if (akm && bkn) return gemm_w4_launch_epi<T, true, true>(g, epilogue, act, s);
+  return gemm_w4_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
 }  // namespace tamd
@@ -692,13 +915,16 @@ extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias
   // kernel variant: v2 (ping-pong ring, default) or v1 (double-buffered K tiles); read once
   static const int variant = [] {
     const char* e = getenv("TAMD_GEMM");
-    return (e && e[0] == 'v' && e[1] == '1') ? 1 : 2;
+    return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '3') ? e[1] - '0' : 2;
   }();
   if (variant == 1) {
     TAMD_DISPATCH_HALF(dtype, return (gemm_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
+  } else if (variant == 3) {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_w4_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   } else {
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   }
   return TAMD_E_DTYPE;
 }
+
 

@@ -176,5 +176,19 @@ template <typename T>
 __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
   return (unsigned int)elem<T>::from_f32(lo) | ((unsigned int)elem<T>::from_f32(hi) << 16);
 }
+// two fp32 -> one packed register in ONE v_cvt_pk_{bf16,f16}_f32 (vector conversion; the scalar form above
+// costs a convert per element plus shifts/ors)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+template <>
+__device__ __forceinline__ unsigned int pack2<bf16_t>(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
+template <>
+__device__ __forceinline__ unsigned int pack2<f16_t>(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
+}
 
 }  // namespace tamd
