@@ -111,6 +111,8 @@ inline float swap32_f32(float v) {
   return __builtin_bit_cast(float, (lane_id() < 32) ? b : a);
 }
 
+inline int wave_id_uniform() { return (int)(hipemu::cur_fiber().linear / 64); }
+
 inline unsigned long long ballot64(bool pred) {
   const int lane = hipemu::cur_lane();
   unsigned char v = pred ? 1 : 0;

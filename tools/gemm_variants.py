@@ -22,7 +22,7 @@ print(json.dumps({"TAMD_GEMM": os.environ.get("TAMD_GEMM", "v2"), "VAR": os.envi
 '''
 variants = sys.argv[1:] or ["v1", "0", "2", "10", "18", "26"]
 for v in variants:
-    env = {"TAMD_GEMM": v} if v.startswith("v") else {"TAMD_GEMM_VAR": v}
+    env = {"TAMD_GEMM": v} if v.startswith("v") else {"TAMD_GEMM": "v2", "TAMD_GEMM_VAR": v}
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:], flush=True)

@@ -362,6 +362,29 @@ __device__ __forceinline__ u32x4 pp_frag(const char* smem, unsigned off, int rc3
   }
 }
 
+// byte offset of a lane's fragment inside an operand stage (first of the two reads when k-major), and the read
+template <bool KMAJOR>
+__device__ __forceinline__ unsigned pp_frag_off(int rc32, int ks, int lane) {
+  const int hi = lane >> 5;
+  if (KMAJOR) {
+    const int kq = (lane & 15) >> 2;
+    const int col = rc32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int slot = (col >> 3) ^ (kq << 2);
+    return (unsigned)(ks * 16 + hi * 8 + kq) * 512u + (unsigned)slot * 16u + (unsigned)(col & 7) * 2u;
+  }
+  const int row = rc32 + (lane & 31);
+  return (unsigned)row * 64u + (unsigned)(((ks * 2 + hi) ^ ((row >> 2) & 3)) * 16);
+}
+template <bool KMAJOR>
+__device__ __forceinline__ u32x4 pp_frag_at(const char* smem, unsigned off) {
+  if (KMAJOR) {
+    const u32x2 lo = lds_read8_tr16(smem, off);
+    const u32x2 h2 = lds_read8_tr16(smem, off + 4u * 512u);
+    return u32x4{lo[0], lo[1], h2[0], h2[1]};
+  }
+  return lds_read16(smem, off);
+}
+
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, bool TRACE = false, int VAR = 0>
 __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
@@ -480,13 +503,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
     if (!(VAR & 1) && !(VAR & 8) && !(VAR & 256) && !(VAR & 1024)) issue(j + 3);
     TAMD_STAMP(2)
     if (VAR & 1024) wait_vmcnt<6>();
-    if (!(VAR & 256) && !(VAR & 1024)) wait_vmcnt<8>();   // retires this wave's share of sub-tile j+1; j+2, j+3 stay in flight
+    if (VAR & 16384) wait_vmcnt<20>();  // ablation: deeper in-flight window (results are garbage)
+    if (!(VAR & 256) && !(VAR & 1024) && !(VAR & 16384)) wait_vmcnt<8>();   // retires this wave's share of sub-tile j+1; j+2, j+3 stay in flight
     TAMD_STAMP(3)
     wait_lgkmcnt0();   // fragments are in registers: the stage may be recycled after the next barrier
     TAMD_STAMP(4)
     if (VAR & 4) setprio_lo();
     sched_fence();
-    raw_barrier();
+    if (!(VAR & 8192)) raw_barrier();
     TAMD_STAMP(5)
     // ---------------- COMPUTE phase (registers only)
     if (!(VAR & 6)) setprio_hi();
@@ -511,7 +535,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
     if (!(VAR & 6)) setprio_lo();
     sched_fence();
     TAMD_STAMP(6)
-    raw_barrier();
+    if (!(VAR & 8192)) raw_barrier();
     TAMD_STAMP(7)
   }
 #undef TAMD_STAMP
@@ -608,6 +632,9 @@ static int gemm_pp_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       case 6146: TAMD_GV(6146) // both
       case 514: TAMD_GV(514) // ablation: loads + LDS reads, no MFMA
       case 530: TAMD_GV(530) // ablation: loads only
+      case 8722: TAMD_GV(8722) // ablation: loads only, no barriers in the loop
+      case 25106: TAMD_GV(25106) // ablation: loads only, no barriers, 24 pieces in flight per wave
+      case 16914: TAMD_GV(16914) // ablation: loads only, barriers, 24 pieces in flight
       default: break;
     }
   }
@@ -658,7 +685,8 @@ constexpr int kW4Threads = 256;
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT>
 __global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id_uniform();  // SGPR: LDS-DMA destinations (M0) become scalar arithmetic
   const int wm = wave >> 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
 
@@ -686,28 +714,46 @@ __global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  const int nsub = (int)((g.K + kSubK - 1) / kSubK);
-  // 16 wave-instructions per operand stage, 4 waves: pieces [wave*4, wave*4+4) of A and of B
-  auto issue_part = [&](int j, int part) {  // part 0: A pieces, part 1: B pieces (4 LDS-DMA instructions each)
-    const unsigned st = (unsigned)(j & (kRing - 1)) * kStageBytes;
-    const int64_t k0 = (int64_t)j * kSubK;
+  const int nsub = (int)(g.K / kSubK);  // this kernel requires K % 32 == 0 (host dispatch)
+  // ---- per-lane source pointers of this wave's 4 A pieces and 4 B pieces; they advance by a constant per
+  // sub-tile.  Rows/columns outside the matrix point at the zero page with a zero increment.
+  const char* srcp[8];
+  int inc[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int inst = wave * 4 + i;
+    const void* pa = pp_src<T, A_KM>(A, g.lda, m0, g.M, 0, g.K, inst, lane);
+    const void* pb = pp_src<T, B_KN>(B, g.ldb, n0, g.N, 0, g.K, inst, lane);
+    srcp[i] = (const char*)pa;
+    srcp[4 + i] = (const char*)pb;
+    inc[i] = (pa == (const void*)g_zero16) ? 0 : (int)((A_KM ? (int64_t)kSubK * g.lda : (int64_t)kSubK) * 2);
+    inc[4 + i] = (pb == (const void*)g_zero16) ? 0 : (int)((B_KN ? (int64_t)kSubK * g.ldb : (int64_t)kSubK) * 2);
+  }
+  const unsigned piece0 = (unsigned)wave * 4096u;  // this wave's first piece inside an operand stage
+  auto issue_part = [&](int stage, int part) {     // part 0: the 4 A pieces, part 1: the 4 B pieces
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int inst = wave * 4 + i;
-      if (part == 0)
-        glds16(pp_src<T, A_KM>(A, g.lda, m0, g.M, k0, g.K, inst, lane), smem, st + (unsigned)inst * 1024u);
-      else
-        glds16(pp_src<T, B_KN>(B, g.ldb, n0, g.N, k0, g.K, inst, lane), smem,
-               st + kStageOperand + (unsigned)inst * 1024u);
+      const int p = part * 4 + i;
+      glds16(srcp[p], smem, (unsigned)stage * kStageBytes + (unsigned)part * kStageOperand + piece0 + (unsigned)i * 1024u);
+      srcp[p] += inc[p];
     }
   };
+  // ---- loop-invariant fragment offsets inside a stage (swizzles depend on the lane only)
+  unsigned offx[2][4], offw[2][4];  // [ks][mi / ni]
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      offx[ks][t] = pp_frag_off<A_KM>(wm * 128 + t * 32, ks, lane);
+      offw[ks][t] = kStageOperand + pp_frag_off<B_KN>(wn * 128 + t * 32, ks, lane);
+    }
   u32x4 fx[2][4], fw[2][4];  // [buffer][mi / ni]
-  auto read_frags = [&](int j, int ks, int buf) {
-    const unsigned st = (unsigned)(j & (kRing - 1)) * kStageBytes;
+  auto read_frags = [&](int stage, int ks, int buf) {
+    const unsigned st = (unsigned)stage * kStageBytes;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) fw[buf][ni] = pp_frag<B_KN>(smem, st + kStageOperand, wn * 128 + ni * 32, ks, lane);
+    for (int ni = 0; ni < 4; ++ni) fw[buf][ni] = pp_frag_at<B_KN>(smem, st + offw[ks][ni]);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) fx[buf][mi] = pp_frag<A_KM>(smem, st, wm * 128 + mi * 32, ks, lane);
+    for (int mi = 0; mi < 4; ++mi) fx[buf][mi] = pp_frag_at<A_KM>(smem, st + offx[ks][mi]);
   };
   auto mma = [&](int buf) {
 #pragma unroll
@@ -715,44 +761,69 @@ __global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma32<T>(fw[buf][ni], fx[buf][mi], acc[ni][mi]);
   };
-  // interleave pattern for one k-step: 16 MFMA, 8 LDS reads, 4 LDS-DMA  ->  4 x { MFMA x4, DS_READ x2, VMEM x1 }
+  // interleave for one k-step: 16 MFMA with the 8 fragment reads (16 LDS instructions when k-major) and the
+  // 4 LDS-DMA pieces tucked into the MFMA shadows
   auto pattern = [&]() {
+    constexpr int DSN = ((A_KM ? 2 : 1) * 4 + (B_KN ? 2 : 1) * 4) / 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, DSN, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // VMEM read (LDS-DMA)
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // VALU (pointer increments)
     }
   };
 
-  issue_part(0, 0);
-  issue_part(0, 1);
-  issue_part(1, 0);
-  issue_part(1, 1);
-  issue_part(2, 0);
-  issue_part(2, 1);
+  // prologue: sub-tiles 0..2
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j == nsub) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        srcp[p] = (const char*)g_zero16;
+        inc[p] = 0;
+      }
+    }
+    issue_part(j, 0);
+    issue_part(j, 1);
+  }
   wait_vmcnt<0>();
   raw_barrier();
   read_frags(0, 0, 0);
-  for (int j = 0; j < nsub; ++j) {
-    // k-step 0 of sub-tile j (buffer 0) | fetch k-step 1 fragments, first half of sub-tile j+3's loads
-    sched_fence();
-    read_frags(j, 1, 1);
-    issue_part(j + 3, 0);
-    mma(0);
-    pattern();
-    sched_fence();
-    // hand-off: sub-tile j+1 must have landed for everybody; everybody's reads of sub-tile j are in registers
-    wait_vmcnt<12>();  // own pieces of sub-tile j+1 (issued two iterations ago); j+2 (8) and half of j+3 (4) in flight
-    wait_lgkmcnt0();
-    raw_barrier();
-    sched_fence();
-    // k-step 1 (buffer 1) | fetch k-step 0 of sub-tile j+1, second half of sub-tile j+3's loads
-    read_frags(j + 1, 0, 0);
-    issue_part(j + 3, 1);
-    mma(1);
-    pattern();
-    sched_fence();
+  // main loop, unrolled over the 4 ring stages so every LDS address is base register + immediate
+  for (int j0 = 0; j0 < nsub; j0 += kRing) {
+#pragma unroll
+    for (int u = 0; u < kRing; ++u) {
+      const int j = j0 + u;
+      if (j < nsub) {
+        if (j + 3 == nsub) {  // past the last sub-tile: keep the load counts uniform but read the zero page
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            srcp[p] = (const char*)g_zero16;
+            inc[p] = 0;
+          }
+        }
+        // k-step 0 of sub-tile j (buffer 0) | fetch k-step 1 fragments, first half of sub-tile j+3's loads
+        sched_fence();
+        read_frags(u, 1, 1);
+        issue_part((u + 3) & 3, 0);
+        mma(0);
+        pattern();
+        sched_fence();
+        // hand-off: sub-tile j+1 has landed for everybody; everybody's reads of sub-tile j are in registers
+        wait_vmcnt<12>();  // own pieces of sub-tile j+1; sub-tile j+2 (8) and half of j+3 (4) stay in flight
+        wait_lgkmcnt0();
+        raw_barrier();
+        sched_fence();
+        // k-step 1 (buffer 1) | fetch k-step 0 of sub-tile j+1, second half of sub-tile j+3's loads
+        read_frags((u + 1) & 3, 0, 0);
+        issue_part((u + 3) & 3, 1);
+        mma(1);
+        pattern();
+        sched_fence();
+      }
+    }
   }
   wait_vmcnt<0>();
   wait_lgkmcnt0();
@@ -915,11 +986,12 @@ extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias
   // kernel variant: v2 (ping-pong ring, default) or v1 (double-buffered K tiles); read once
   static const int variant = [] {
     const char* e = getenv("TAMD_GEMM");
-    return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '3') ? e[1] - '0' : 2;
+    return (e && e[0] == 'v' && e[1] >= '1' && e[1] <= '3') ? e[1] - '0' : 0;  // 0 = auto
   }();
   if (variant == 1) {
     TAMD_DISPATCH_HALF(dtype, return (gemm_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
-  } else if (variant == 3) {
+  } else if ((variant == 3 || (variant == 0 && flags == 0)) && K % kSubK == 0) {
+    // auto: row-major operands run best on the one-wave-per-SIMD kernel, k-major ones on the ping-pong kernel
     TAMD_DISPATCH_HALF(dtype, return (gemm_w4_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   } else {
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));

@@ -57,6 +57,9 @@ __device__ __forceinline__ void permlane32_swap(unsigned int& a, unsigned int& b
   b = r[1];
 }
 
+// wave index inside the workgroup as a provably wave-uniform (SGPR) value
+__device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // 64-bit mask of the lanes whose predicate is true
 __device__ __forceinline__ unsigned long long ballot64(bool pred) { return __ballot(pred); }
 
