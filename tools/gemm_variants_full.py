@@ -1,4 +1,4 @@
-"""v2 vs v3 on forward and backward (k-major) shapes; one process per variant."""
+"""ping-pong (pp) vs one-wave-per-SIMD (w4) kernel on forward and backward (k-major) shapes; one process per variant."""
 import os, subprocess, sys
 code = r'''
 import sys, torch, json, os
@@ -24,7 +24,7 @@ for name, m, n, k in [("qkv", 32768, 6144, 4096), ("o_proj", 32768, 4096, 4096),
     del x, w, dy
 print(json.dumps({"TAMD_GEMM": os.environ.get("TAMD_GEMM", "v2"), "fwd/dx/dw/relerr": out}))
 '''
-for v in sys.argv[1:] or ["v2", "v3"]:
+for v in sys.argv[1:] or ["pp", "w4"]:
     e = dict(os.environ); e["TAMD_GEMM"] = v
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
     print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-800:], flush=True)
