@@ -227,3 +227,45 @@ def test_gpt2_on_kernels(env):
     o.loss.backward()
     assert rel_err(o.logits, o32.logits) <= 1.1 * rel_err(o_ref.logits, o32.logits) + 1e-3
     _grad_parity(fast, ref, ref32)
+
+
+def test_llava_forward_parity(env):
+    """BASELINE config 5 architecture at test scale: CLIP vision tower (hidden_states[-2] through the output
+    hooks) -> projector -> masked_scatter into the text embeddings -> Llama stack.  Forward only."""
+    from transformers import CLIPVisionConfig, LlavaConfig, LlavaForConditionalGeneration
+
+    torch.manual_seed(6)
+    big = env.big
+    vcfg = CLIPVisionConfig(hidden_size=1024 if big else 128, intermediate_size=4096 if big else 256,
+                            num_hidden_layers=3 if big else 2, num_attention_heads=16 if big else 2,
+                            image_size=336 if big else 56, patch_size=14)
+    tcfg = LlamaConfig(vocab_size=1200, hidden_size=1024 if big else 128, intermediate_size=2816 if big else 256,
+                       num_hidden_layers=2, num_attention_heads=8 if big else 2, num_key_value_heads=8 if big else 2,
+                       head_dim=128 if big else 64, max_position_embeddings=2048, rms_norm_eps=1e-5)
+    cfg = LlavaConfig(vision_config=vcfg, text_config=tcfg, image_token_id=1100, vision_feature_layer=-2,
+                      vision_feature_select_strategy="default", attn_implementation="eager")
+    ref = LlavaForConditionalGeneration(cfg).bfloat16().eval()
+    ref32 = copy.deepcopy(ref).float()
+    fast = copy.deepcopy(ref).to(env.device)
+    n_img = (vcfg.image_size // 14) ** 2  # 576 at 336 px
+    n_txt = 64 if big else 12
+    ids = torch.randint(0, 1000, (1, n_txt))
+    ids = torch.cat([ids[:, :3], torch.full((1, n_img), 1100), ids[:, 3:]], dim=1)
+    px = torch.randn(1, 3, vcfg.image_size, vcfg.image_size)
+    with torch.no_grad():
+        a = ref(input_ids=ids, pixel_values=px.bfloat16(), use_cache=False).logits
+        a32 = ref32(input_ids=ids, pixel_values=px, use_cache=False).logits
+        transformers_amd.accelerate(fast)
+        assert fast.config.text_config._attn_implementation == "tamd"
+        assert fast.config.vision_config._attn_implementation == "tamd"
+        dev = env.device
+        c = fast(input_ids=ids.to(dev), pixel_values=px.bfloat16().to(dev), use_cache=False).logits
+        # integer path: the placeholder positions receive exactly the projected image rows, in order
+        emb = fast.get_input_embeddings()(ids.to(dev))
+        feats = fast.get_image_features(pixel_values=px.bfloat16().to(dev), return_dict=True).pooler_output
+        feats = torch.cat(list(feats), 0) if isinstance(feats, (list, tuple)) else feats
+        mask = (ids == 1100).to(dev)
+        merged = emb.masked_scatter(mask.unsqueeze(-1).expand_as(emb), feats.to(emb.dtype))
+        assert torch.equal(merged[0][mask[0]], feats.reshape(-1, feats.shape[-1]).to(emb.dtype))
+    e_fast, e_ref = rel_err(c, a32), rel_err(a, a32)
+    assert e_fast <= 1.15 * e_ref + 1e-3, (e_fast, e_ref)
