@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 1
+#define TAMD_ABI_VERSION 2
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -194,7 +194,8 @@ enum tamd_gemm_epilogue {
 /* C[M,N] = A[M,K] . B[N,K]^T  with fp32 MFMA accumulation: nn.Linear forward
  * (modeling_llama.py:254-256,280; :174-176; modeling_bert.py:175-177,289,334,347; pytorch_utils.py:117-121)
  * and, through the layout flags, its two backward products dX = dY.W and dW = dY^T.X.
- * bf16/f16 only.  Requirements: K % 8 == 0, N % 8 == 0, lda/ldb/ldc/ldr % 8 == 0.
+ * bf16/f16 only.  Requirements: N % 8 == 0, lda/ldb/ldc/ldr % 8 == 0; K % 8 == 0 unless both operands are
+ * k-major (then K is a row count and unrestricted: dW over a ragged token count); M % 8 == 0 with TAMD_GEMM_A_KM.
  * bias: [N] or NULL; R: [M, ldr] or NULL (for TAMD_EPI_ACCUM, R is ignored and C is read). */
 int tamd_gemm(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act,
@@ -220,6 +221,8 @@ int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N,
  * key_valid: optional [batch, seq_k] uint8 padding mask (1 = attend); NULL = no padding.
  * lse [batch, heads_q, seq_q] fp32 (natural-log sum-exp of the scaled scores) is written for
  * the backward; may be NULL for inference.  head_dim in {64, 128}; bf16/f16. */
+/* 32-bit mixing function of the dropout mask (exported so hosts/tests can rebuild the mask). */
+uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index);
 struct tamd_attn_params {
   const void* q;
   const void* k;
@@ -235,6 +238,11 @@ struct tamd_attn_params {
   float scale;
   int causal;
   int dtype;
+  /* attention dropout (nn.functional.dropout on the probabilities, modeling_llama.py:209, modeling_bert.py:131):
+   * element (b, h, q, k) is kept iff tamd_dropout_hash(seed, ((b*heads_q+h)*seq_q+q)*seq_k+k) >= dropout_p*2^32
+   * and scaled by 1/(1-p); the same counter-based mask is regenerated in the backward.  0 disables. */
+  float dropout_p;
+  uint64_t dropout_seed;
 };
 int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream);
 

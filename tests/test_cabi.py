@@ -15,7 +15,7 @@ HEADER = (ROOT / "include" / "tamd.h").read_text()
 def declared_functions():
     text = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(tamd_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|uint32_t|const char\*)\s+(tamd_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         out[m.group(1)] = n

@@ -221,7 +221,10 @@ GEMM_SHAPES_BIG = [(4096, 4096, 4096), (8192, 6144, 4096), (1000, 1032, 520), (4
 def test_gemm_layouts(env, layout):
     torch.manual_seed(9)
     dev = env.device
-    for (m, n, k) in (GEMM_SHAPES_BIG if env.big else GEMM_SHAPES_SMALL):
+    shapes = list(GEMM_SHAPES_BIG if env.big else GEMM_SHAPES_SMALL)
+    if layout == "a_km|b_kn":  # dW = dY^T.X reduces over tokens: a ragged token count (K % 8 != 0) must work
+        shapes += [(4096, 1024, 8190), (1024, 4096, 4097)] if env.big else [(264, 248, 66), (256, 256, 33)]
+    for (m, n, k) in shapes:
         if "a_km" in layout and m % 8:
             continue
         x = torch.randn(m, k).bfloat16().to(dev)
@@ -272,8 +275,9 @@ def test_linear_autograd(env):
     assert rel_err(bias.grad, br.grad) < 1.5e-2
 
 
-def ref_attention(q, k, v, scale, causal, key_valid):
-    """eager_attention_forward (modeling_llama.py:191-213) in fp32 on [B,S,H,D] tensors."""
+def ref_attention(q, k, v, scale, causal, key_valid, keep=None, drop_p=0.0):
+    """eager_attention_forward (modeling_llama.py:191-213) in fp32 on [B,S,H,D] tensors; `keep` [B,H,Sq,Sk] is an
+    explicit dropout keep mask (nn.functional.dropout semantics: dropped -> 0, kept -> / (1 - p))."""
     b, s, h, d = q.shape
     sk, hkv = k.shape[1], k.shape[2]
     g = h // hkv
@@ -288,7 +292,10 @@ def ref_attention(q, k, v, scale, causal, key_valid):
     if key_valid is not None:
         mask = mask & key_valid[:, None, None, :].bool()
     sc = sc.masked_fill(~mask, float("-inf"))
-    return (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3)
+    pr = torch.softmax(sc, -1)
+    if keep is not None:
+        pr = pr * keep.to(pr.device).float() / (1.0 - drop_p)
+    return (pr @ vf).permute(0, 2, 1, 3)
 
 
 ATTN_CASES_SMALL = [
@@ -332,6 +339,57 @@ def test_attention_fwd_bwd(env):
         ref.backward(do.float())
         for name, a, r in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
             assert rel_err(a, r) < 1e-2, (case, name)
+
+
+DROPOUT_CASES_SMALL = [(1, 130, 130, 2, 1, 64, True, False, 0.1), (2, 96, 160, 2, 2, 128, False, True, 0.5)]
+DROPOUT_CASES_BIG = [(2, 1024, 1024, 8, 2, 128, True, False, 0.1), (4, 512, 512, 12, 12, 64, False, True, 0.1),
+                     (1, 300, 777, 4, 4, 64, True, True, 0.3)]
+
+
+def test_attention_dropout_matches_explicit_mask(env):
+    """Dropout lives inside the kernels: the keep mask is a counter-based hash of (seed, b, h, q, k) that the host
+    can rebuild (ops.dropout_keep_mask), so forward AND backward are checked against eager attention with that
+    exact mask (reference: nn.functional.dropout on the softmax output, modeling_llama.py:209)."""
+    dev = env.device
+    for case in (DROPOUT_CASES_BIG if env.big else DROPOUT_CASES_SMALL):
+        b, sq, sk, hq, hkv, d, causal, use_mask, p = case
+        torch.manual_seed(21)
+        q = torch.randn(b, sq, hq, d).bfloat16().to(dev).requires_grad_(True)
+        k = torch.randn(b, sk, hkv, d).bfloat16().to(dev).requires_grad_(True)
+        v = torch.randn(b, sk, hkv, d).bfloat16().to(dev).requires_grad_(True)
+        kv = None
+        if use_mask:
+            kv = torch.ones(b, sk, dtype=torch.bool, device=dev)
+            kv[0, sk - 9:] = False
+        seed = 0x1234567 * 0x9ABCDEF1 + sq
+        keep = ops.dropout_keep_mask(seed, b, hq, sq, sk, p)
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.02, case      # the hash is unbiased at rate p
+        scale = 1 / math.sqrt(d)
+        o = ops.attention(q, k, v, scale, causal, kv, dropout_p=p, seed=seed)
+        qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        ref = ref_attention(qr, kr, vr, scale, causal, kv, keep=keep, drop_p=p)
+        assert rel_err(o, ref) < 6e-3, case
+        do = torch.randn_like(o)
+        o.backward(do)
+        ref.backward(do.float())
+        for name, a, r in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+            assert rel_err(a, r) < 1.2e-2, (case, name)
+        # a different seed gives a different mask; the same seed repeats bit for bit
+        o2 = ops.attention(q.detach(), k.detach(), v.detach(), scale, causal, kv, dropout_p=p, seed=seed)
+        o3 = ops.attention(q.detach(), k.detach(), v.detach(), scale, causal, kv, dropout_p=p, seed=seed + 1)
+        assert torch.equal(o2, o.detach()) and not torch.equal(o3, o2)
+
+
+def test_dropout_hash_export_matches_host_mirror(env):
+    lib = ops.backend().lib
+    import numpy as np
+    seed = 0xDEADBEEFCAFEF00D
+    idx = [0, 1, 2, 12345, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 17]
+    thr0 = ops.dropout_keep_mask(seed, 1, 1, 1, 3, 0.5)   # indices 0..2
+    for i in range(3):
+        h = lib.tamd_dropout_hash(seed, i)
+        assert bool(thr0.view(-1)[i]) == (h >= 2 ** 31)
+    assert len({lib.tamd_dropout_hash(seed, i) for i in idx}) == len(idx)
 
 
 def test_attention_spike_forces_rescale(env):

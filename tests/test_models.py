@@ -24,7 +24,7 @@ def tiny_llama(big):
                        rms_norm_eps=1e-5, attn_implementation="eager")
 
 
-@pytest.mark.parametrize("padding", [False, True])
+@pytest.mark.parametrize("padding", [False, True, "ragged"])
 def test_llama_forward_backward_parity(env, padding):
     torch.manual_seed(0)
     cfg = tiny_llama(env.big)
@@ -32,6 +32,8 @@ def test_llama_forward_backward_parity(env, padding):
     ref32 = copy.deepcopy(ref).float()
     fast = copy.deepcopy(ref).to(env.device)
     b, s = (4, 1024) if env.big else (2, 96)
+    if padding == "ragged":  # token count not a multiple of 8 (dynamic padding in a DataLoader): tails everywhere
+        b, s = (3, 333) if env.big else (3, 37)
     ids = torch.randint(0, cfg.vocab_size, (b, s))
     labels = ids.clone()
     labels[0, :10] = -100
@@ -180,6 +182,48 @@ def test_bert_masked_lm_parity(env):
     assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
     # key.bias has an exactly-zero gradient (softmax shift invariance): relative error is meaningless there
     _grad_parity(fast, ref, ref32, skip=("key.bias",))
+
+
+def test_training_with_default_dropout_runs_on_kernels(env):
+    """Stock configs train with dropout > 0 (BERT 0.1/0.1; Llama attention_dropout is user-set): the attention
+    keep mask is drawn inside the kernels from a seed taken from torch's RNG, so `torch.manual_seed` repeats a
+    step bit for bit, a different seed changes it, and the loss stays close to the dropout-free value."""
+    from transformers import BertConfig, BertForMaskedLM, LlamaConfig, LlamaForCausalLM
+
+    dev = env.device
+    torch.manual_seed(13)
+    cfg = BertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                     intermediate_size=256, max_position_embeddings=64, attn_implementation="eager")
+    assert cfg.attention_probs_dropout_prob == 0.1 and cfg.hidden_dropout_prob == 0.1
+    bert = transformers_amd.accelerate(BertForMaskedLM(cfg).bfloat16().to(dev)).train()
+    ids = torch.randint(1, 200, (2, 40), device=dev)
+
+    def step(model, seed, **kw):
+        torch.manual_seed(seed)
+        model.zero_grad()
+        out = model(input_ids=ids, labels=ids, **kw)
+        out.loss.backward()
+        return out.loss.item(), [p.grad.clone() for p in model.parameters() if p.grad is not None]
+
+    l1, g1 = step(bert, 100)
+    l2, g2 = step(bert, 100)
+    l3, g3 = step(bert, 101)
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert any(not torch.equal(a, b) for a, b in zip(g1, g3))
+    l_eval = bert.eval()(input_ids=ids, labels=ids).loss.item()
+    assert abs(l1 - l_eval) < 0.25 * abs(l_eval)
+
+    lcfg = LlamaConfig(vocab_size=128, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                       num_attention_heads=2, num_key_value_heads=1, head_dim=64, attention_dropout=0.2,
+                       max_position_embeddings=64, attn_implementation="eager")
+    llama = transformers_amd.accelerate(LlamaForCausalLM(lcfg).bfloat16().to(dev)).train()
+    ids = torch.randint(0, 128, (2, 33), device=dev)
+    l1, g1 = step(llama, 7, use_cache=False)
+    l2, g2 = step(llama, 7, use_cache=False)
+    l3, g3 = step(llama, 8, use_cache=False)
+    assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert any(not torch.equal(a, b) for a, b in zip(g1, g3))  # attention dropout is the only randomness here
+    assert all(torch.isfinite(g).all() for g in g1)
 
 
 def test_clip_vision_tower_hidden_states(env):

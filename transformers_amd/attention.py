@@ -53,9 +53,11 @@ def _key_valid_from_mask(attention_mask: torch.Tensor, batch: int, kv_len: int) 
 
 def tamd_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0,
                            scaling: Optional[float] = None, is_causal: Optional[bool] = None, **kwargs):
-    if dropout and dropout > 0.0:
-        raise TamdError("attn_implementation='tamd' has no attention-dropout path yet: run with "
-                        "attention dropout 0 (model.eval() or config.attention*_dropout = 0)")
+    # reference: nn.functional.dropout(attn_weights, p=dropout, training=module.training) after the softmax
+    # (modeling_llama.py:209); here the keep mask is generated inside the kernels (ops.dropout_keep_mask).
+    drop_p = float(dropout) if (dropout and getattr(module, "training", True)) else 0.0
+    if not 0.0 <= drop_p < 1.0:
+        raise TamdError(f"attention dropout must be in [0, 1), got {drop_p}")
     if not query.is_cuda and ops.backend().name == "hip":
         raise TamdError("attn_implementation='tamd' needs GPU tensors (no CPU fallback); use 'eager' or 'sdpa' on CPU")
     b, hq, sq, d = query.shape
@@ -79,7 +81,7 @@ def tamd_attention_forward(module, query, key, value, attention_mask, dropout: f
         k = k.contiguous()
     if v.stride(3) != 1:
         v = v.contiguous()
-    out = ops.attention(q, k, v, float(scaling), causal, key_valid)
+    out = ops.attention(q, k, v, float(scaling), causal, key_valid, dropout_p=drop_p)
     return out, None
 
 

@@ -40,8 +40,34 @@ struct AttnArgs {
   int batch, heads_q, heads_kv, seq_q, seq_k;
   int64_t qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh;
   float scale_log2;  // scale * log2(e)
+  unsigned drop_thr;  // keep iff hash >= drop_thr (0 = no dropout)
+  float drop_scale;   // 1 / (1 - p)
+  unsigned seed_lo, seed_hi;
   int nqt;           // query tiles per (b, h)
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
+};
+
+// Counter-based dropout mask: 32-bit mix of (seed, element index); identical in forward, backward and on the host
+// (tamd_dropout_hash).  index = ((b*Hq + h)*Sq + q)*Sk + k.
+__host__ __device__ __forceinline__ unsigned dropout_hash(unsigned seed_lo, unsigned seed_hi, unsigned idx_lo,
+                                                          unsigned idx_hi) {
+  unsigned x = (idx_lo ^ seed_lo) * 0x9E3779B1u;
+  x ^= x >> 15;
+  x += (idx_hi * 0x85EBCA77u) ^ seed_hi;
+  x *= 0xC2B2AE3Du;
+  x ^= x >> 13;
+  x *= 0x27D4EB2Fu;
+  x ^= x >> 16;
+  return x;
+}
+// keep-scale of element (row_index*Sk + k): 0 or 1/(1-p)
+struct DropCtx {
+  unsigned thr, seed_lo, seed_hi;
+  float scale;
+  __device__ __forceinline__ float factor(unsigned long long base, int k) const {
+    const unsigned long long idx = base + (unsigned long long)k;
+    return dropout_hash(seed_lo, seed_hi, (unsigned)idx, (unsigned)(idx >> 32)) >= thr ? scale : 0.f;
+  }
 };
 
 // One swizzle serves both read patterns of a [rows][D] tile (rows = keys or queries):
@@ -110,7 +136,7 @@ struct TileOffsets {
   }
 };
 
-template <typename T, int D, bool CAUSAL, bool HAS_MASK>
+template <typename T, int D, bool CAUSAL, bool HAS_MASK, bool DROP>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   constexpr int ROWB = D * 2;
   constexpr int TILEB = kKB * ROWB;       // one K or V tile
@@ -173,6 +199,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
 
   TileOffsets<D> toff;
   toff.init(lane);
+  const DropCtx drop = {a.drop_thr, a.seed_lo, a.seed_hi, a.drop_scale};
+  const unsigned long long drop_base = (((unsigned long long)b * a.heads_q + h) * a.seq_q + (qrow < a.seq_q ? qrow : 0)) *
+                                       (unsigned long long)a.seq_k;
   constexpr float kDeferThr = 6.f;  // skip the O rescale while the row max grows by < 2^6 (cdna guide T13)
 
   auto issue = [&](int t, int buf) {
@@ -208,7 +237,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
         unsigned long long vmask = ~0ull;
         if (HAS_MASK) {
           const int kp = kt0 + lane;
-          vmask = ballot64(kp < a.seq_k && a.key_valid[(int64_t)b * a.seq_k + kp] != 0);
+          vmask = ballot64(kp < a.seq_k && (a.key_valid == nullptr || a.key_valid[(int64_t)b * a.seq_k + kp] != 0));
         }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -253,6 +282,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
           // unrounded fp32 values like softmax(dtype=float32) does.
           p[r] = fast_exp2(__builtin_fmaf(s[sub][r], a.scale_log2, -m_ref));
           psum += p[r];
+          // dropout acts on the probabilities that multiply V, not on the normaliser (softmax, then dropout)
+          if (DROP) p[r] *= drop.factor(drop_base, kt0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi);
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -315,17 +346,25 @@ int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
   const size_t smem = (size_t)4 * kKB * D * 2;  // 2 buffers x (K + V); also covers the O staging (4 x 32 x (2D+16))
   dim3 grid((unsigned)(a.nqt * a.heads_q * a.batch)), block(kAttnThreads);
   const bool mask = a.key_valid != nullptr;
-  if (causal) {
-    if (mask)
-      hipLaunchKernelGGL((attn_fwd_kernel<T, D, true, true>), grid, block, smem, s, a);
+  const bool drop = a.drop_thr != 0;
+#define TAMD_AF(C_, M_, D_) hipLaunchKernelGGL((attn_fwd_kernel<T, D, C_, M_, D_>), grid, block, smem, s, a)
+  if (drop) {  // the dropout variants always carry the padding-mask code (rare path: keep the instantiation count down)
+    if (causal)
+      TAMD_AF(true, true, true);
     else
-      hipLaunchKernelGGL((attn_fwd_kernel<T, D, true, false>), grid, block, smem, s, a);
+      TAMD_AF(false, true, true);
+  } else if (causal) {
+    if (mask)
+      TAMD_AF(true, true, false);
+    else
+      TAMD_AF(true, false, false);
   } else {
     if (mask)
-      hipLaunchKernelGGL((attn_fwd_kernel<T, D, false, true>), grid, block, smem, s, a);
+      TAMD_AF(false, true, false);
     else
-      hipLaunchKernelGGL((attn_fwd_kernel<T, D, false, false>), grid, block, smem, s, a);
+      TAMD_AF(false, false, false);
   }
+#undef TAMD_AF
   return launch_status();
 }
 
@@ -335,6 +374,7 @@ int attn_check(const tamd_attn_params* p) {
   if (p->batch <= 0 || p->heads_q <= 0 || p->heads_kv <= 0 || p->seq_q <= 0 || p->seq_k <= 0) return TAMD_E_SHAPE;
   if (p->heads_q % p->heads_kv != 0) return TAMD_E_SHAPE;
   if (p->dtype != TAMD_BF16 && p->dtype != TAMD_F16) return TAMD_E_DTYPE;
+  if (!(p->dropout_p >= 0.f && p->dropout_p < 1.f)) return TAMD_E_ARG;
   const int64_t strides[] = {p->q_stride_b, p->q_stride_s, p->q_stride_h, p->k_stride_b, p->k_stride_s, p->k_stride_h,
                              p->v_stride_b, p->v_stride_s, p->v_stride_h, p->o_stride_b, p->o_stride_s, p->o_stride_h};
   for (int64_t st : strides)
@@ -369,12 +409,21 @@ AttnArgs make_args(const tamd_attn_params* p) {
   a.oss = p->o_stride_s;
   a.osh = p->o_stride_h;
   a.scale_log2 = p->scale * 1.44269504088896340736f;
+  const double pd = p->dropout_p;
+  a.drop_thr = (pd > 0.0) ? (unsigned)(pd >= 1.0 ? 4294967295.0 : pd * 4294967296.0) : 0u;
+  a.drop_scale = (pd > 0.0 && pd < 1.0) ? (float)(1.0 / (1.0 - pd)) : 1.f;
+  a.seed_lo = (unsigned)p->dropout_seed;
+  a.seed_hi = (unsigned)(p->dropout_seed >> 32);
   a.nqt = (int)ceil_div(p->seq_q, kQB);
   a.xcd_map = ((p->batch * p->heads_kv) % 8 == 0) ? 1 : 0;
   return a;
 }
 
 }  // namespace
+
+extern "C" uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index) {
+  return dropout_hash((unsigned)seed, (unsigned)(seed >> 32), (unsigned)index, (unsigned)(index >> 32));
+}
 
 extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream) {
   const int chk = attn_check(p);

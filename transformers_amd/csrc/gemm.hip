@@ -525,7 +525,11 @@ extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias
                          int act, int dtype, tamd_stream_t stream) {
   if (!A || !B || !C) return TAMD_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0) return TAMD_E_SHAPE;
-  if ((K % 8) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return TAMD_E_SHAPE;
+  // 16-byte accesses run along the contiguous dimension of each operand: K for a row-major operand, M (A) / N (B)
+  // for a k-major one.  With both operands k-major K is a row count and may be anything (dW = dY^T.X over a
+  // ragged number of tokens).
+  const bool k_contig = !(flags & TAMD_GEMM_A_KM) || !(flags & TAMD_GEMM_B_KN);
+  if ((k_contig && (K % 8)) || (N % 8) || (lda % 8) || (ldb % 8) || (ldc % 8)) return TAMD_E_SHAPE;
   if ((flags & TAMD_GEMM_A_KM) && (M % 8)) return TAMD_E_SHAPE;
   if (!aligned16(A) || !aligned16(B) || !aligned16(C)) return TAMD_E_ALIGN;
   if ((epilogue == TAMD_EPI_BIAS || epilogue == TAMD_EPI_BIAS_ACT) && !bias) return TAMD_E_NULL;

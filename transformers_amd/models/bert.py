@@ -30,7 +30,7 @@ class TamdBertSelfAttention(ref.BertSelfAttention):
 
     def forward(self, hidden_states, attention_mask=None, past_key_values=None, **kwargs):
         d = self.attention_head_size
-        if not (_gpu(hidden_states) and past_key_values is None and _no_dropout(self) and d in (64, 128)
+        if not (_gpu(hidden_states) and past_key_values is None and d in (64, 128)
                 and hidden_states.dtype in (torch.bfloat16, torch.float16)
                 and self.config._attn_implementation == "tamd" and not kwargs.get("output_attentions", False)):
             return super().forward(hidden_states, attention_mask=attention_mask, past_key_values=past_key_values,
@@ -45,7 +45,8 @@ class TamdBertSelfAttention(ref.BertSelfAttention):
         if attention_mask is not None:
             from ..attention import _key_valid_from_mask
             key_valid = _key_valid_from_mask(attention_mask, b, s)
-        o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid)
+        o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid,
+                          dropout_p=self.dropout.p if self.training else 0.0)
         return o.view(b, s, h), None
 
 

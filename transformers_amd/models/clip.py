@@ -26,7 +26,7 @@ class TamdCLIPAttention(ref.CLIPAttention):
     def forward(self, hidden_states, attention_mask=None, **kwargs):
         d = self.head_dim
         if not (_gpu(hidden_states) and d in (64, 128) and hidden_states.dtype in (torch.bfloat16, torch.float16)
-                and self.config._attn_implementation == "tamd" and not (self.training and self.dropout > 0)
+                and self.config._attn_implementation == "tamd"
                 and not kwargs.get("output_attentions", False)):
             return super().forward(hidden_states, attention_mask=attention_mask, **kwargs)
         b, s, h = hidden_states.shape
@@ -40,7 +40,8 @@ class TamdCLIPAttention(ref.CLIPAttention):
             from ..attention import _key_valid_from_mask
             key_valid = _key_valid_from_mask(attention_mask, b, s)
         causal = bool(kwargs.get("is_causal", self.is_causal)) and s > 1
-        o = ops.attention(q, k, v, float(self.scale), causal, key_valid)
+        o = ops.attention(q, k, v, float(self.scale), causal, key_valid,
+                          dropout_p=self.dropout if self.training else 0.0)
         return ops.linear(o.view(b, s, h), self.out_proj.weight, self.out_proj.bias), None
 
 

@@ -70,8 +70,7 @@ class TamdLlamaAttention(ref.LlamaAttention):
     def _fast_ok(self, hidden_states, past_key_values) -> bool:
         return (_on_gpu(hidden_states) and past_key_values is None and self.q_proj.bias is None
                 and self.head_dim in (64, 128) and hidden_states.dtype in (torch.bfloat16, torch.float16)
-                and self.config._attn_implementation == "tamd"
-                and not (self.training and self.attention_dropout > 0))
+                and self.config._attn_implementation == "tamd")
 
     def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
         if not self._fast_ok(hidden_states, past_key_values):
@@ -91,7 +90,8 @@ class TamdLlamaAttention(ref.LlamaAttention):
         if attention_mask is not None:
             from ..attention import _key_valid_from_mask
             key_valid = _key_valid_from_mask(attention_mask, b, s)
-        o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid)
+        o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid,
+                          dropout_p=self.attention_dropout if self.training else 0.0)
         out = ops.linear(o.view(b, s, hq * d), self.o_proj.weight)
         return out, None
 
@@ -181,6 +181,7 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
         attn, mlp = self.self_attn, self.mlp
         return (isinstance(attn, TamdLlamaAttention) and isinstance(mlp, TamdLlamaMLP)
                 and attn._fast_ok(hidden_states, past_key_values)
+                and not (attn.training and attn.attention_dropout > 0)  # the per-module path carries dropout
                 and mlp.config.hidden_act in ("silu", "swish") and mlp.gate_proj.bias is None
                 and attn.o_proj.bias is None
                 and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm))

@@ -340,7 +340,7 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
     return out
 
 
-def _attn_params(q, k, v, o, lse, key_valid, scale, causal):
+def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=0):
     """q/k/v/o are [B, S, H, D] *views* (any batch/seq/head strides, D contiguous)."""
     p = _cabi.AttnParams()
     p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
@@ -357,10 +357,12 @@ def _attn_params(q, k, v, o, lse, key_valid, scale, causal):
     p.scale = float(scale)
     p.causal = int(bool(causal))
     p.dtype = _code(q)
+    p.dropout_p = float(dropout_p)
+    p.dropout_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     return p
 
 
-def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None):
+def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None, dropout_p=0.0, seed=0):
     """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32."""
     be = _prep(q, k, v, key_valid, out)
     b, sq, hq, d = q.shape
@@ -368,12 +370,13 @@ def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None
     lse = torch.empty(b, hq, sq, dtype=torch.float32, device=q.device) if need_lse else None
     if key_valid is not None:
         key_valid = _c(key_valid.to(torch.uint8))
-    p = _attn_params(q, k, v, o, lse, key_valid, scale, causal)
+    p = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed)
     be.lib.check(be.lib.tamd_attn_fwd(ctypes.byref(p), be.stream(q)), "tamd_attn_fwd")
     return o, lse
 
 
-def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, dk=None, dv=None):
+def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, dk=None, dv=None,
+                 dropout_p=0.0, seed=0):
     """Gradients written into dq/dk/dv (views with the strides of q/k/v) or freshly allocated."""
     be = _prep(q, k, v, o, lse, dout, key_valid)
     if dout.stride() != o.stride():
@@ -389,7 +392,7 @@ def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, 
         key_valid = _c(key_valid.to(torch.uint8))
     delta = torch.empty_like(lse)
     bp = _cabi.AttnBwdParams()
-    bp.fwd = _attn_params(q, k, v, o, lse, key_valid, scale, causal)
+    bp.fwd = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed)
     bp.dout, bp.dq, bp.dk, bp.dv, bp.delta = (dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                               delta.data_ptr())
     be.lib.check(be.lib.tamd_attn_bwd(ctypes.byref(bp), be.stream(q)), "tamd_attn_bwd")
@@ -562,24 +565,51 @@ class AttentionFn(torch.autograd.Function):
     models/llama/modeling_llama.py:191-213 and siblings."""
 
     @staticmethod
-    def forward(ctx, q, k, v, key_valid, scale, causal):
+    def forward(ctx, q, k, v, key_valid, scale, causal, dropout_p=0.0, seed=0):
         need = any(ctx.needs_input_grad[:3])
-        o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need)
+        o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need, dropout_p=dropout_p, seed=seed)
         if need:
             ctx.save_for_backward(q, k, v, o, lse, key_valid)
-        ctx.meta = (scale, causal)
+        ctx.meta = (scale, causal, dropout_p, seed)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, key_valid = ctx.saved_tensors
-        scale, causal = ctx.meta
-        dq, dk, dv = raw_attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid)
-        return dq, dk, dv, None, None, None
+        scale, causal, dropout_p, seed = ctx.meta
+        dq, dk, dv = raw_attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid, dropout_p=dropout_p, seed=seed)
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention(q, k, v, scale, causal, key_valid=None):
-    return AttentionFn.apply(q, k, v, key_valid, scale, causal)
+def dropout_seed() -> int:
+    """One 63-bit seed per attention call from torch's CPU generator: `torch.manual_seed` makes runs repeatable,
+    and activation checkpointing (which restores the CPU RNG state before recomputing) regenerates the same mask."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int, p: float) -> torch.Tensor:
+    """The kernels' keep mask [B,H,Sq,Sk] (bool), rebuilt on the host with the exported hash -- for tests/debugging."""
+    import numpy as np
+
+    idx = np.arange(batch * heads * seq_q * seq_k, dtype=np.uint64)
+    lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+    slo, shi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = (lo ^ slo) * np.uint32(0x9E3779B1)
+        x ^= x >> np.uint32(15)
+        x += (hi * np.uint32(0x85EBCA77)) ^ shi
+        x *= np.uint32(0xC2B2AE3D)
+        x ^= x >> np.uint32(13)
+        x *= np.uint32(0x27D4EB2F)
+        x ^= x >> np.uint32(16)
+    thr = np.uint32(min(4294967295.0, float(np.float32(p)) * 4294967296.0))
+    return torch.from_numpy((x >= thr).reshape(batch, heads, seq_q, seq_k))
+
+
+def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None):
+    if dropout_p > 0.0 and seed is None:
+        seed = dropout_seed()
+    return AttentionFn.apply(q, k, v, key_valid, scale, causal, float(dropout_p), int(seed or 0))
 
 
 class SwiGLUFn(torch.autograd.Function):
