@@ -295,6 +295,9 @@ inline u32x2 lds_read8_tr16(const char* smem, unsigned off) {
   memcpy(&v, hipemu::cur_wave().out[lane], 8);
   return v;
 }
+inline u32x2 lds_read8_tr16_untracked(const char* smem, unsigned off, int imm) {
+  return lds_read8_tr16(smem, off + (unsigned)imm);
+}
 // direct-to-LDS 16-byte load: LDS destination = wave-uniform base + lane*16.  Adversarial timing
 // model: the destination is POISONED (0xFFFF = bf16/f16 NaN) at issue and the data lands only at the
 // issuing lane's wait_vmcnt0().  A read before the wait, or another wave still reading the previous

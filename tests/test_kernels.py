@@ -236,6 +236,49 @@ def test_gemm_layouts(env, layout):
         assert rel_err(c, ref) < 4e-3, (layout, m, n, k)  # bf16 output rounding only (fp32 accumulation)
 
 
+@pytest.mark.parametrize("sched", ["pp", "w4", "w4p", "x"])
+def test_gemm_schedules_agree(env, sched):
+    """The three schedules of the row-major GEMM (ping-pong, one-wave-per-SIMD with 32-deep stages, and with
+    64-deep full-line stages) on ragged M/N, stage counts around the ring size, and every epilogue."""
+    torch.manual_seed(19)
+    dev = env.device
+    shapes = ([(4096, 4096, 4096), (1000, 1032, 320), (4100, 264, 832), (256, 256, 64)] if env.big else
+              [(256, 256, 64), (264, 248, 128), (130, 520, 192), (72, 264, 320), (300, 136, 384), (64, 72, 704)])
+    for (m, n, k) in shapes:
+        x = torch.randn(m, k).bfloat16().to(dev)
+        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+        ref = x.float() @ w.float().t()
+        c = ops.raw_gemm(x, w, sched=sched)
+        assert rel_err(c, ref) < 4e-3, (sched, m, n, k)
+        assert torch.equal(c, ops.raw_gemm(x, w, sched="pp")), (sched, m, n, k)  # same fp32 k-order per output
+    if sched == "x":  # the full-line kernel also takes k-major operands (the backward products)
+        for (m, n, k) in ([(4096, 1024, 4096), (1000, 1032, 320), (264, 4104, 832)] if env.big else
+                          [(256, 256, 64), (264, 248, 128), (136, 520, 192), (72, 264, 320), (304, 136, 384)]):
+            x = torch.randn(m, k).bfloat16().to(dev)
+            w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+            xt, wt = x.t().contiguous(), w.t().contiguous()
+            base = ops.raw_gemm(x, w, sched="pp")
+            assert torch.equal(ops.raw_gemm(x, wt, b_kn=True, sched="x"), base), ("b_kn", m, n, k)
+            assert torch.equal(ops.raw_gemm(xt, wt, a_km=True, b_kn=True, sched="x"), base), ("a_km|b_kn", m, n, k)
+            assert torch.equal(ops.raw_gemm(xt, w, a_km=True, sched="x"), base), ("a_km", m, n, k)
+    m, n, k = shapes[1]
+    x = torch.randn(m, k).bfloat16().to(dev)
+    w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+    bias = torch.randn(n).bfloat16().to(dev)
+    res = torch.randn(m, n).bfloat16().to(dev)
+    for kw in (dict(bias=bias, epilogue=ops.EPI_BIAS), dict(residual=res, epilogue=ops.EPI_RESIDUAL),
+               dict(bias=bias, epilogue=ops.EPI_BIAS_ACT, act=ops.ACT_GELU_TANH)):
+        assert torch.equal(ops.raw_gemm(x, w, sched=sched, **kw), ops.raw_gemm(x, w, sched="pp", **kw)), kw
+    out = res.clone()
+    ops.raw_gemm(x, w, epilogue=ops.EPI_ACCUM, out=out, sched=sched)
+    out2 = res.clone()
+    ops.raw_gemm(x, w, epilogue=ops.EPI_ACCUM, out=out2, sched="pp")
+    assert torch.equal(out, out2)
+    # f16 too
+    c16 = ops.raw_gemm(x.half(), w.half(), sched=sched)
+    assert rel_err(c16, x.half().float() @ w.half().float().t()) < 2e-3
+
+
 def test_gemm_epilogues(env):
     torch.manual_seed(10)
     dev = env.device

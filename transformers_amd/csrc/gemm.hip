@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
 // here than on the ping-pong kernel: twice the LDS read instructions per fragment).
 constexpr int kW4Threads = 256;
 
-template <typename T, int EPI, int ACT>
+template <typename T, int EPI, int ACT, bool PIN>
 __global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
@@ -410,6 +410,49 @@ __global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
       const int j = j0 + u;
       if (j < nsub) {
         if (j + 3 == nsub) park();
+        if (PIN) {
+          // explicitly pinned interleave (see gemm_w4x_kernel): 8 MFMA pairs, reads in gaps 0..5, pieces in 2..5
+          const unsigned str = (unsigned)u * kStageBytes, stn = (unsigned)((u + 1) & 3) * kStageBytes;
+          const unsigned stl = (unsigned)((u + 3) & 3) * kStageBytes;
+          auto pair = [&](int buf, int p) {
+            const int ni = p >> 1, mi = (p & 1) * 2;
+            acc[ni][mi] = mfma32<T>(fw[buf][ni], fx[buf][mi], acc[ni][mi]);
+            acc[ni][mi + 1] = mfma32<T>(fw[buf][ni], fx[buf][mi + 1], acc[ni][mi + 1]);
+          };
+          auto rd1 = [&](unsigned st, int ks, int buf, int q) {
+            if (q & 1)
+              fx[buf][q >> 1] = lds_read16(smem, st + offx[ks][q >> 1]);
+            else
+              fw[buf][q >> 1] = lds_read16(smem, st + offw[ks][q >> 1]);
+          };
+          auto piece = [&](int part, int i) {
+            const int p = part * 4 + i;
+            glds16(srcp[p], smem, stl + (unsigned)part * kStageOperand + piece0 + (unsigned)i * 1024u);
+            srcp[p] += inc[p];
+          };
+          sched_fence();
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            pair(0, p);
+            sched_fence();
+            if (p < 2) rd1(str, 1, 1, 2 * p), rd1(str, 1, 1, 2 * p + 1);
+            if (p >= 2 && p < 6) rd1(str, 1, 1, p + 2), piece(0, p - 2);
+            sched_fence();
+          }
+          wait_vmcnt<12>();
+          wait_lgkmcnt0();
+          raw_barrier();
+          sched_fence();
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+            pair(1, p);
+            sched_fence();
+            if (p < 2) rd1(stn, 0, 0, 2 * p), rd1(stn, 0, 0, 2 * p + 1);
+            if (p >= 2 && p < 6) rd1(stn, 0, 0, p + 2), piece(1, p - 2);
+            sched_fence();
+          }
+          continue;
+        }
         // k-step 0 of sub-tile j (buffer 0) | fetch k-step 1 fragments, first half of sub-tile j+3's loads
         sched_fence();
         feed(u, 1, 1, (u + 3) & 3, 0);
@@ -424,6 +467,220 @@ __global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
         feed((u + 1) & 3, 0, 0, (u + 3) & 3, 1);
         mma(1);
         sched_fence();
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  wait_lgkmcnt0();
+  raw_barrier();
+  gemm_epilogue<T, EPI, ACT, 4, 4>(g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128,
+                                   n0 + wn * 128, lane);
+}
+
+// ============================================================================================ full-line feed
+// Same 4 waves x (128 x 128) shape as gemm_w4_kernel, but a ring stage is 64 k deep so one operand row of a stage
+// is exactly one 128-byte L2 line, and one LDS-DMA wave-instruction covers 8 rows x 128 B = 8 whole lines.  The
+// BK=32 kernels request every line in two 64-byte halves, one k-step apart: rocprofv3 shows 2.0x the
+// TCP_TCC_READ_REQ of hipBLASLt's MT256x256x64 kernel for the same bytes (profiles/r01_gemm_pmc.txt), and the L2
+// request path, not the schedule, bounds the loop (profiles/r01_gemm_variants.md).
+// LDS: 5 half-slots of 32 KiB = all 160 KiB.  Operand-stage A_j lives in slot (2j) % 5, B_j in (2j+1) % 5; row r of
+// an operand stage is 128 B at r*128, logical 16-byte chunk c at slot c ^ ((r>>1)&7) (applied on the source
+// address, undone on the fragment read; 16 consecutive rows x one chunk cover all 64 banks once).
+// Schedule of stage s (4 k-steps of 16; fragments double-buffered one k-step ahead):
+//     k-step 0,1 : 16 MFMA | 8 fragment reads | 4 pieces each of A_{s+2}   (into the slot B_{s-1} vacated)
+//     k-step 2   : 16 MFMA | 8 fragment reads (the last reads of stage s)
+//     hand-off   : vmcnt(8) retires this wave's B_{s+1} (A_{s+1} is older), lgkmcnt(0), barrier
+//     k-step 3   : 16 MFMA | 8 fragment reads of stage s+1 | 8 pieces of B_{s+2} (into the slot A_s vacated)
+// so 8-16 pieces per wave (32-64 KiB per CU) are in flight across every barrier, one barrier per 64 k.
+// Rows past M / N are clamped to the last valid row (their products land in rows / columns the epilogue never
+// stores); requires K % 64 == 0 (host dispatch).
+constexpr int kXK = 64;
+constexpr unsigned kXHalf = 256u * kXK * 2u;  // one operand of one stage: 32 KiB
+constexpr int kXSlots = 5;
+constexpr int kXSmem = kXSlots * (int)kXHalf;  // 163840 = the whole LDS of a CU
+
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT>
+__global__ __launch_bounds__(kW4Threads, 1) void gemm_w4x_kernel(GemmArgs g) {
+  TAMD_DYN_SMEM(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id_uniform();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  int tile_m, tile_n;
+  gemm_tile_of_block(g, blockIdx.x, &tile_m, &tile_n);
+  const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+
+  f32x16 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  const int nst = (int)(g.K / kXK);
+  // per-lane source pointers: this wave's 8 A pieces ([0..7]) and 8 B pieces ([8..15]) of an operand stage.
+  //   row-major operand: piece i = rows (wave*8+i)*8 .. +7, lane -> (row = lane>>3, physical chunk = lane&7);
+  //                      next stage = +128 B
+  //   k-major operand  : stage = [64 k][256 cols] (512-byte k-rows, chunk slot' = slot ^ ((k&3)<<2) as in the
+  //                      ping-pong kernel); piece i = k-rows (wave*8+i)*2 .. +1, lane -> (k = lane>>5, physical
+  //                      chunk = lane&31); next stage = +64 rows
+  // Rows / column chunks outside the matrix are clamped to the last valid one.
+  const char* srcp[16];
+  int64_t kinc_a = A_KM ? (int64_t)kXK * g.lda * 2 : kXK * 2;  // bytes per stage; 0 once parked
+  int64_t kinc_b = B_KN ? (int64_t)kXK * g.ldb * 2 : kXK * 2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = (wave * 8 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int kr = (wave * 8 + i) * 2 + (lane >> 5);
+    const int col = ((lane & 31) ^ ((kr & 3) << 2)) * 8;
+    if (A_KM) {
+      const int64_t gc = (m0 + col < g.M) ? m0 + col : g.M - 8;
+      srcp[i] = (const char*)(A + (int64_t)kr * g.lda + gc);
+    } else {
+      const int64_t ra = (m0 + row < g.M) ? m0 + row : g.M - 1;
+      srcp[i] = (const char*)(A + ra * g.lda + c * 8);
+    }
+    if (B_KN) {
+      const int64_t gc = (n0 + col < g.N) ? n0 + col : g.N - 8;
+      srcp[8 + i] = (const char*)(B + (int64_t)kr * g.ldb + gc);
+    } else {
+      const int64_t rb = (n0 + row < g.N) ? n0 + row : g.N - 1;
+      srcp[8 + i] = (const char*)(B + rb * g.ldb + c * 8);
+    }
+  }
+  auto park = [&]() {  // past the last stage: keep the load counts uniform but read the zero page
+#pragma unroll
+    for (int p = 0; p < 16; ++p) srcp[p] = (const char*)g_zero16;
+    kinc_a = 0;
+    kinc_b = 0;
+  };
+  const unsigned piece0 = (unsigned)wave * 8192u;  // this wave's first piece inside an operand stage
+  auto issue = [&](int p, int slot) {              // piece p (0..15) of this wave into half-slot `slot`
+    glds16(srcp[p], smem, (unsigned)slot * kXHalf + piece0 + (unsigned)(p & 7) * 1024u);
+    srcp[p] += (p < 8) ? kinc_a : kinc_b;
+  };
+  // fragment offsets inside a half-slot.  row-major: one per k-step (row (wm|wn)*128 + t*32 + l31: t is the
+  // immediate t*4096); k-major: one per 32-column block t (k-step ks is the immediate ks*8192)
+  unsigned offx[4], offw[4];
+  {
+    const unsigned sw = (unsigned)(l31 >> 1) & 7u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned ch = ((unsigned)(j * 2 + hi) ^ sw) * 16u;
+      offx[j] = A_KM ? pp_frag_off<true>(wm * 128 + j * 32, 0, lane) : (unsigned)(wm * 128 + l31) * 128u + ch;
+      offw[j] = B_KN ? pp_frag_off<true>(wn * 128 + j * 32, 0, lane) : (unsigned)(wn * 128 + l31) * 128u + ch;
+    }
+  }
+  // k-major fragments: two transposing 8-byte reads (k rows +0..3 and +4..7), issued untracked (tamd_device.h:
+  // the compiler would drain vmcnt in front of each); every k-step therefore opens with an explicit lgkmcnt(0)
+  auto frag_km = [&](unsigned off, int imm) -> u32x4 {
+    const u32x2 lo = lds_read8_tr16_untracked(smem, off, imm);
+    const u32x2 h2 = lds_read8_tr16_untracked(smem, off, imm + 4 * 512);
+    return u32x4{lo[0], lo[1], h2[0], h2[1]};
+  };
+  auto frag_a = [&](int slot, int ks, int i) -> u32x4 {
+    if (A_KM) return frag_km((unsigned)slot * kXHalf + offx[i], ks * 8192);
+    return lds_read16(smem, (unsigned)slot * kXHalf + offx[ks] + (unsigned)i * 4096u);
+  };
+  auto frag_b = [&](int slot, int ks, int i) -> u32x4 {
+    if (B_KN) return frag_km((unsigned)slot * kXHalf + offw[i], ks * 8192);
+    return lds_read16(smem, (unsigned)slot * kXHalf + offw[ks] + (unsigned)i * 4096u);
+  };
+  auto kstep_open = [&]() {  // fragments of this k-step (read during the previous one) are in registers
+    if (A_KM || B_KN) wait_lgkmcnt0();
+    sched_fence();
+  };
+  u32x4 fx[2][4], fw[2][4];  // [buffer][mi / ni]
+  // One k-step = 16 MFMAs issued as 8 pairs; between consecutive pairs exactly one small group of feed
+  // instructions, pinned with sched_barrier(0) so the matrix pipe (one wave per SIMD: nobody else fills it) never
+  // waits behind a clump of LDS / LDS-DMA issues.  pair p covers acc[p>>1][2*(p&1) .. +1].
+  auto mfma_pair = [&](int buf, int p) {
+    const int ni = p >> 1, mi = (p & 1) * 2;
+    acc[ni][mi] = mfma32<T>(fw[buf][ni], fx[buf][mi], acc[ni][mi]);
+    acc[ni][mi + 1] = mfma32<T>(fw[buf][ni], fx[buf][mi + 1], acc[ni][mi + 1]);
+  };
+  // fragment read number q (0..7) of k-step ks of stage slots (sa, sb) into buffer buf: w0 x0 w1 x1 ...
+  auto rd1 = [&](int sa, int sb, int ks, int buf, int q) {
+    const int i = q >> 1;
+    if (q & 1)
+      fx[buf][i] = frag_a(sa, ks, i);
+    else
+      fw[buf][i] = frag_b(sb, ks, i);
+  };
+  // prologue: A_0 B_0 A_1 B_1 into half-slots 0..3
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j == nst) park();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) issue(p, 2 * j + (p >> 3));
+  }
+  wait_vmcnt<0>();
+  raw_barrier();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) rd1(0, 1, 0, 0, q);
+  for (int s0 = 0; s0 < nst; s0 += kXSlots) {
+#pragma unroll
+    for (int u = 0; u < kXSlots; ++u) {
+      const int s = s0 + u;
+      if (s < nst) {
+        const int sa = (2 * u) % kXSlots, sb = (2 * u + 1) % kXSlots;                  // A_s, B_s
+        const int sa1 = (2 * u + 2) % kXSlots, sb1 = (2 * u + 3) % kXSlots;            // A_{s+1}, B_{s+1}
+        const int sa2 = (2 * u + 4) % kXSlots;                                         // A_{s+2} (= slot of B_{s-1})
+        const int sb2 = sa;                                                            // B_{s+2} (= slot of A_s)
+        if (s + 2 == nst) park();
+        // The 8 fragment reads of a k-step go into its first six gaps (2 2 1 1 1 1) so the last one has more than
+        // an LDS latency to land before the next k-step's first MFMA; LDS-DMA pieces fill gaps 2..5.
+        // k-step 0 | fragments of k-step 1, A_{s+2} pieces 0..3
+        sched_fence();
+        kstep_open();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          mfma_pair(0, p);
+          sched_fence();
+          if (p < 2) rd1(sa, sb, 1, 1, 2 * p), rd1(sa, sb, 1, 1, 2 * p + 1);
+          if (p >= 2 && p < 6) rd1(sa, sb, 1, 1, p + 2), issue(p - 2, sa2);
+          sched_fence();
+        }
+        // k-step 1 | fragments of k-step 2, A_{s+2} pieces 4..7
+        kstep_open();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          mfma_pair(1, p);
+          sched_fence();
+          if (p < 2) rd1(sa, sb, 2, 0, 2 * p), rd1(sa, sb, 2, 0, 2 * p + 1);
+          if (p >= 2 && p < 6) rd1(sa, sb, 2, 0, p + 2), issue(4 + p - 2, sa2);
+          sched_fence();
+        }
+        // k-step 2 | fragments of k-step 3: the last reads of stage s
+        kstep_open();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          mfma_pair(0, p);
+          sched_fence();
+          if (p < 2) rd1(sa, sb, 3, 1, 2 * p), rd1(sa, sb, 3, 1, 2 * p + 1);
+          if (p >= 2 && p < 6) rd1(sa, sb, 3, 1, p + 2);
+          sched_fence();
+        }
+        // hand-off: stage s+1 has landed for everybody; everybody's reads of stage s are in registers
+        wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 pieces of A_{s+2} stay in flight
+        wait_lgkmcnt0();
+        raw_barrier();
+        sched_fence();
+        // k-step 3 | fragments of k-step 0 of stage s+1, B_{s+2} pieces 0..7 into the slot A_s vacated
+        kstep_open();
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          mfma_pair(1, p);
+          sched_fence();
+          if (p < 2) rd1(sa1, sb1, 0, 0, 2 * p), rd1(sa1, sb1, 0, 0, 2 * p + 1);
+          if (p >= 2 && p < 6) rd1(sa1, sb1, 0, 0, p + 2);
+          issue(8 + p, sb2);
+          sched_fence();
+        }
       }
     }
   }
@@ -471,14 +728,33 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
   return gemm_pp_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
-template <typename T>
+template <typename T, bool PIN>
 static int gemm_w4_launch(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kW4Threads);
-#define TAMD_G(E_, A_)                                                                    \
-  hipLaunchKernelGGL((gemm_w4_kernel<T, E_, A_>), grid, block, (size_t)kGemmSmem, s, g); \
+#define TAMD_G(E_, A_)                                                                         \
+  hipLaunchKernelGGL((gemm_w4_kernel<T, E_, A_, PIN>), grid, block, (size_t)kGemmSmem, s, g); \
   return launch_status();
   TAMD_EPI_SWITCH(TAMD_G)
 #undef TAMD_G
+}
+
+template <typename T, bool A_KM, bool B_KN>
+static int gemm_w4x_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kW4Threads);
+#define TAMD_G(E_, A_)                                                                              \
+  hipLaunchKernelGGL((gemm_w4x_kernel<T, A_KM, B_KN, E_, A_>), grid, block, (size_t)kXSmem, s, g); \
+  return launch_status();
+  TAMD_EPI_SWITCH(TAMD_G)
+#undef TAMD_G
+}
+
+template <typename T>
+static int gemm_w4x_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
+  const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
+  if (!akm && !bkn) return gemm_w4x_launch_epi<T, false, false>(g, epilogue, act, s);
+  if (!akm && bkn) return gemm_w4x_launch_epi<T, false, true>(g, epilogue, act, s);
+  if (akm && bkn) return gemm_w4x_launch_epi<T, true, true>(g, epilogue, act, s);
+  return gemm_w4x_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
 }  // namespace tamd
@@ -537,14 +813,20 @@ extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias
   if (epilogue == TAMD_EPI_RESIDUAL && (!R || (ldr % 8) || !aligned16(R))) return R ? TAMD_E_ALIGN : TAMD_E_NULL;
   GemmArgs g;
   gemm_fill_args(&g, A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr);
-  // schedule: TAMD_GEMM=pp | w4 forces one kernel (A/B measurements); default picks by operand layout
+  // schedule: TAMD_GEMM=pp | w4 | x (full-line feed) forces one kernel (A/B measurements); default picks by operand layout
   static const int forced = [] {
     const char* e = getenv("TAMD_GEMM");
-    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'w' ? 2 : 0));
+    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 'w' ? (e[1] == '4' && e[2] == 'p' ? 4 : 2) : 0)));
   }();
+  const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
+  flags &= 0xff;
   const bool w4_ok = flags == 0 && K % kSubK == 0;
-  if (w4_ok && forced != 1) {
-    TAMD_DISPATCH_HALF(dtype, return (gemm_w4_launch<T>(g, epilogue, act, TAMD_STREAM(stream))));
+  if (K % kXK == 0 && (sched == 3 || (sched == 0 && flags == 0))) {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_w4x_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
+  } else if (w4_ok && sched == 4) {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_w4_launch<T, true>(g, epilogue, act, TAMD_STREAM(stream))));
+  } else if (w4_ok && sched != 1) {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_w4_launch<T, false>(g, epilogue, act, TAMD_STREAM(stream))));
   } else {
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   }

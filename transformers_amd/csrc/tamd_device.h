@@ -118,6 +118,20 @@ __device__ __forceinline__ u32x2 lds_read8_tr16(const char* smem, unsigned off) 
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + off));
   return __builtin_bit_cast(u32x2, v);
 }
+// The same instruction issued behind the compiler's back.  Why: with LDS-DMA loads in flight, LLVM's waitcnt
+// insertion puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 it knows about whenever it cannot
+// rule out that the read touches an LDS-DMA destination (seen in gemm_w4x_kernel: 43-73 drains inside the loop,
+// i.e. no load pipelining at all).  The caller orders reads against landed data itself (counted vmcnt + barrier),
+// and must place wait_lgkmcnt0() before the first use of the result: the compiler does not know the register
+// is filled asynchronously.
+// `imm` (0..65535) must fold to a constant after inlining: it becomes the instruction's offset field.
+__device__ __forceinline__ u32x2 lds_read8_tr16_untracked(const char* smem, unsigned off, int imm) {
+  typedef __attribute__((address_space(3))) const char lds_char;
+  const unsigned addr = (unsigned)reinterpret_cast<__UINTPTR_TYPE__>((lds_char*)smem) + off;
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(imm) : "memory");
+  return v;
+}
 // Direct-to-LDS 16-byte load: the wave writes 64 x 16 B = 1 KiB contiguous at
 // `smem + wave_base_off` (must be wave-uniform); each lane supplies its own
 // global source address.  Completion is tracked by vmcnt.

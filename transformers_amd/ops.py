@@ -323,7 +323,11 @@ def gemm_supported(m, n, k, dtype) -> bool:
     return dtype in (torch.bfloat16, torch.float16) and k % 8 == 0 and n % 8 == 0 and m > 0
 
 
-def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None):
+GEMM_SCHED = {None: 0, "pp": 1 << 8, "w4": 2 << 8, "x": 3 << 8, "w4p": 4 << 8}  # diagnostic schedule hints (include/tamd.h)
+
+
+def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None,
+             sched=None):
     """C[M,N] = epi(A . B^T).  a: [M,K] (or [K,M] if a_km); b: [N,K] (or [K,N] if b_kn)."""
     be = _prep(a, b, bias, residual, out)
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -333,7 +337,7 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
         raise TamdError(f"gemm K mismatch: {tuple(a.shape)} x {tuple(b.shape)} (a_km={a_km}, b_kn={b_kn})")
     if out is None:
         out = torch.empty(m, n, dtype=a.dtype, device=a.device)
-    flags = (GEMM_A_KM if a_km else 0) | (GEMM_B_KN if b_kn else 0)
+    flags = (GEMM_A_KM if a_km else 0) | (GEMM_B_KN if b_kn else 0) | GEMM_SCHED[sched]
     ldr = residual.stride(0) if residual is not None else 0
     be.lib.check(be.lib.tamd_gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), m, n, k_a, a.stride(0), b.stride(0),
                                   out.stride(0), ldr, flags, epilogue, act, _code(a), be.stream(a)), "tamd_gemm")
