@@ -55,6 +55,21 @@ def flops_per_token(c) -> float:
     return 3.0 * (l * per_layer + 2 * h * v)
 
 
+def gemm_traffic():
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); written by
+    tools/prof_traffic.py into profiles/.  None when no profile of the current kernel is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return {"unit": "bytes/launch", "hbm_bytes": t["hbm_bytes_per_launch"],
+                "fetch_bytes": t["fetch_bytes_per_launch"], "write_bytes": t["write_bytes_per_launch"],
+                "source": "profiles/r01_gemm_traffic.json"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 class GemmTimer:
     """HIP-event timing of every MFMA-GEMM launch inside the timed region (stream = torch's current stream,
     which is the stream the C-ABI launches on)."""
@@ -78,7 +93,7 @@ class GemmTimer:
             s.record()
             out = inner(a, b, a_km=a_km, b_kn=b_kn, **kw)
             e.record()
-            timer.records.append((2.0 * m * n * k, s, e))
+            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n)))
             return out
 
         ops.raw_gemm = timed_gemm
@@ -89,7 +104,7 @@ class GemmTimer:
             return None
         fl = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return dict(launches=len(self.records), flops=fl, ms=ms)
+        return dict(launches=len(self.records), flops=fl, ms=ms, bytes=sum(r[3] for r in self.records))
 
 
 def cpu_baseline(cfg_dict, threads=None):
@@ -208,11 +223,13 @@ def main():
         roofline = None
         if gs:
             ach = gs["flops"] / (gs["ms"] * 1e-3) / 1e12
-            roofline = dict(bound="mfma", kernel="tamd::gemm_kernel (csrc/gemm.hip, all layouts/epilogues)",
+            roofline = dict(bound="mfma", kernel="tamd::gemm_fl_kernel (csrc/gemm.hip; forward, dX and dW layouts, "
+                                                 "all epilogues; avg over the launches of a step)",
                             achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS,
-                            traffic=None, launches_per_step=gs["launches"] // args.steps,
+                            traffic=gemm_traffic(), launches_per_step=gs["launches"] // args.steps,
                             avg_launch_ms=gs["ms"] / gs["launches"],
                             avg_launch_tflop=gs["flops"] / gs["launches"] / 1e12,
+                            avg_launch_algorithmic_bytes=gs["bytes"] / gs["launches"],
                             gemm_share_of_step_time=gs["ms"] * 1e-3 / dt)
         line = {
             "metric": "fwd+bwd tokens/sec (whole job), Llama-3-8B seq=4096",

@@ -182,12 +182,10 @@ int tamd_cross_entropy_bwd(const void* logits, const int64_t* labels, const floa
 enum tamd_gemm_flags {
   TAMD_GEMM_A_KM = 1, /* A stored [K, M] (k-major rows) instead of [M, K] */
   TAMD_GEMM_B_KN = 2, /* B stored [K, N] instead of [N, K]               */
-  /* diagnostic schedule hints (A/B measurements, tests); 0 = library default.  A hint that does not apply to the
-   * operand layout / K is ignored. */
-  TAMD_GEMM_SCHED_PP = 1 << 8,  /* 8-wave ping-pong kernel (every layout)                          */
-  TAMD_GEMM_SCHED_W4 = 2 << 8,  /* one wave per SIMD, 32-deep stages (row-major, K % 32 == 0)      */
-  TAMD_GEMM_SCHED_X = 3 << 8,   /* one wave per SIMD, 64-deep full-line stages (row-major, K % 64) */
-  TAMD_GEMM_SCHED_W4P = 4 << 8  /* W4 with the explicitly pinned MFMA / feed interleave              */
+  /* diagnostic schedule hints (A/B measurements, tests); 0 = library default (full-line kernel when K % 64 == 0,
+   * else ping-pong).  A hint that does not apply to K is ignored. */
+  TAMD_GEMM_SCHED_PP = 1 << 8, /* 8-wave ping-pong kernel, 32-deep stages (every layout, any K)                */
+  TAMD_GEMM_SCHED_FL = 3 << 8  /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
 };
 enum tamd_gemm_epilogue {
   TAMD_EPI_NONE = 0,

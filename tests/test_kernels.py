@@ -236,10 +236,10 @@ def test_gemm_layouts(env, layout):
         assert rel_err(c, ref) < 4e-3, (layout, m, n, k)  # bf16 output rounding only (fp32 accumulation)
 
 
-@pytest.mark.parametrize("sched", ["pp", "w4", "w4p", "x"])
+@pytest.mark.parametrize("sched", ["pp", "fl", None])
 def test_gemm_schedules_agree(env, sched):
-    """The three schedules of the row-major GEMM (ping-pong, one-wave-per-SIMD with 32-deep stages, and with
-    64-deep full-line stages) on ragged M/N, stage counts around the ring size, and every epilogue."""
+    """The two GEMM kernels (ping-pong with 32-deep stages; one-wave-per-SIMD with 64-deep full-line stages) and the
+    default dispatch agree bit for bit on ragged M/N, stage counts around the ring size, every layout and epilogue."""
     torch.manual_seed(19)
     dev = env.device
     shapes = ([(4096, 4096, 4096), (1000, 1032, 320), (4100, 264, 832), (256, 256, 64)] if env.big else
@@ -251,16 +251,16 @@ def test_gemm_schedules_agree(env, sched):
         c = ops.raw_gemm(x, w, sched=sched)
         assert rel_err(c, ref) < 4e-3, (sched, m, n, k)
         assert torch.equal(c, ops.raw_gemm(x, w, sched="pp")), (sched, m, n, k)  # same fp32 k-order per output
-    if sched == "x":  # the full-line kernel also takes k-major operands (the backward products)
+    if sched != "pp":  # k-major operands (the backward products)
         for (m, n, k) in ([(4096, 1024, 4096), (1000, 1032, 320), (264, 4104, 832)] if env.big else
                           [(256, 256, 64), (264, 248, 128), (136, 520, 192), (72, 264, 320), (304, 136, 384)]):
             x = torch.randn(m, k).bfloat16().to(dev)
             w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
             xt, wt = x.t().contiguous(), w.t().contiguous()
             base = ops.raw_gemm(x, w, sched="pp")
-            assert torch.equal(ops.raw_gemm(x, wt, b_kn=True, sched="x"), base), ("b_kn", m, n, k)
-            assert torch.equal(ops.raw_gemm(xt, wt, a_km=True, b_kn=True, sched="x"), base), ("a_km|b_kn", m, n, k)
-            assert torch.equal(ops.raw_gemm(xt, w, a_km=True, sched="x"), base), ("a_km", m, n, k)
+            assert torch.equal(ops.raw_gemm(x, wt, b_kn=True, sched=sched), base), ("b_kn", m, n, k)
+            assert torch.equal(ops.raw_gemm(xt, wt, a_km=True, b_kn=True, sched=sched), base), ("a_km|b_kn", m, n, k)
+            assert torch.equal(ops.raw_gemm(xt, w, a_km=True, sched=sched), base), ("a_km", m, n, k)
     m, n, k = shapes[1]
     x = torch.randn(m, k).bfloat16().to(dev)
     w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)

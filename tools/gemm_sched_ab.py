@@ -36,9 +36,9 @@ for name, m, n, k in SHAPES:
     dy = torch.randn(m, n, device=dev).bfloat16()
     fl = 2.0 * m * n * k
     prods = {
-        "fwd": (("pp", "w4", "x"), lambda s: ops.raw_gemm(x, w, sched=s), lambda: torch.mm(x, w.t())),
-        "dx": (("pp", "x"), lambda s: ops.raw_gemm(dy, w, b_kn=True, sched=s), lambda: torch.mm(dy, w)),
-        "dw": (("pp", "x"), lambda s: ops.raw_gemm(dy, x, a_km=True, b_kn=True, sched=s), lambda: torch.mm(dy.t(), x)),
+        "fwd": (("pp", "fl"), lambda s: ops.raw_gemm(x, w, sched=s), lambda: torch.mm(x, w.t())),
+        "dx": (("pp", "fl"), lambda s: ops.raw_gemm(dy, w, b_kn=True, sched=s), lambda: torch.mm(dy, w)),
+        "dw": (("pp", "fl"), lambda s: ops.raw_gemm(dy, x, a_km=True, b_kn=True, sched=s), lambda: torch.mm(dy.t(), x)),
     }
     for prod in which:
         scheds, ours, ref = prods[prod]

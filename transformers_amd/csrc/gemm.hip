@@ -26,9 +26,11 @@
 //     wave's tile in LDS and writes full row segments (bias / activation / residual / accumulate fused there);
 //   * workgroup ids are remapped XCD-aware (8 XCDs, private L2s): each XCD owns a contiguous chunk of a grouped
 //     (8 M-tiles wide) tile order, so concurrently resident tiles share A/B panels in L2 (84.6 % hits measured).
-// Two schedules (profiles/r01_gemm_variants.md has the measurements that led here):
-//   gemm_pp_kernel  8 waves, 2 groups one phase apart (ping-pong): k-major operand modes (backward GEMMs)
-//   gemm_w4_kernel  4 waves x (128 x 128), one wave per SIMD, 512 registers: row-major operands (forward GEMMs)
+// Two kernels (profiles/r01_gemm_variants.md has the measurements that led here):
+//   gemm_fl_kernel  4 waves x (128 x 128), one wave per SIMD, 512 registers, 64-deep "full-line" stages: every
+//                   layout when K % 64 == 0 (all Llama / BERT / CLIP / GPT-2 products, forward and backward)
+//   gemm_pp_kernel  8 waves, 2 groups one phase apart (ping-pong), 32-deep stages: any K (ragged token counts in
+//                   dW, odd hidden sizes)
 #include <stdlib.h>
 
 #include "common.h"
@@ -296,193 +298,13 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
   gemm_epilogue<T, EPI, ACT, 2, 4>(g, acc, smem, (unsigned)wave * kStageWaveBytes, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
-// ============================================================================================ one wave per SIMD
-// 4 waves x (128 x 128): 256 accumulator registers per wave (the unified 512-entry file of gfx950), so a BK=32
-// step reads 64 KiB of fragments per CU instead of 96 KiB.  Nobody shares the SIMD, so the wave hides its own
-// latencies: the fragment reads of the NEXT k-step and this wave's 8 LDS-DMA pieces of sub-tile j+3 are written
-// in program order as { 2 reads, 1 piece } x 4 per k-step and slotted between the 16 MFMAs of the CURRENT k-step
-// (register double buffer + sched_group_barrier pattern); one barrier per BK=32 step; the loop is unrolled over
-// the 4 ring stages so every LDS address is base register + immediate; per-lane source pointers advance by a
-// constant.  Requires K % 32 == 0 (host dispatch); row-major operands only (the k-major modes measured slower
-// here than on the ping-pong kernel: twice the LDS read instructions per fragment).
-constexpr int kW4Threads = 256;
-
-template <typename T, int EPI, int ACT, bool PIN>
-__global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
-  TAMD_DYN_SMEM(smem);
-  const int lane = threadIdx.x & 63;
-  const int wave = wave_id_uniform();  // SGPR: LDS-DMA destinations (M0) become scalar arithmetic
-  const int wm = wave >> 1, wn = wave & 1;
-  int tile_m, tile_n;
-  gemm_tile_of_block(g, blockIdx.x, &tile_m, &tile_n);
-  const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
-  const T* A = reinterpret_cast<const T*>(g.A);
-  const T* B = reinterpret_cast<const T*>(g.B);
-
-  f32x16 acc[4][4];  // [ni][mi]
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
-
-  const int nsub = (int)(g.K / kSubK);
-  // per-lane source pointers of this wave's 4 A pieces and 4 B pieces (16 wave-instructions per operand stage,
-  // 4 waves); rows outside the matrix point at the zero page with a zero increment
-  const char* srcp[8];
-  int inc[8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const void* pa = pp_src<T, false>(A, g.lda, m0, g.M, 0, g.K, wave * 4 + i, lane);
-    const void* pb = pp_src<T, false>(B, g.ldb, n0, g.N, 0, g.K, wave * 4 + i, lane);
-    srcp[i] = (const char*)pa;
-    srcp[4 + i] = (const char*)pb;
-    inc[i] = (pa == (const void*)g_zero16) ? 0 : kSubK * 2;
-    inc[4 + i] = (pb == (const void*)g_zero16) ? 0 : kSubK * 2;
-  }
-  auto park = [&]() {  // past the last sub-tile: keep the load counts uniform but read the zero page
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      srcp[p] = (const char*)g_zero16;
-      inc[p] = 0;
-    }
-  };
-  const unsigned piece0 = (unsigned)wave * 4096u;  // this wave's first piece inside an operand stage
-  unsigned offx[2][4], offw[2][4];                 // loop-invariant fragment offsets inside a stage [ks][mi/ni]
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      offx[ks][t] = pp_frag_off<false>(wm * 128 + t * 32, ks, lane);
-      offw[ks][t] = kStageOperand + pp_frag_off<false>(wn * 128 + t * 32, ks, lane);
-    }
-  u32x4 fx[2][4], fw[2][4];  // [buffer][mi / ni]
-  // one k-step's worth of feeding, in the order the instructions should appear (the compiler keeps LDS reads and
-  // LDS-DMA in program order): { 2 fragment reads, 1 LDS-DMA piece } x 4
-  auto feed = [&](int rstage, int ks, int buf, int lstage, int part) {
-    const unsigned st = (unsigned)rstage * kStageBytes;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fw[buf][i] = lds_read16(smem, st + offw[ks][i]);
-      fx[buf][i] = lds_read16(smem, st + offx[ks][i]);
-      const int p = part * 4 + i;
-      glds16(srcp[p], smem, (unsigned)lstage * kStageBytes + (unsigned)part * kStageOperand + piece0 + (unsigned)i * 1024u);
-      srcp[p] += inc[p];
-    }
-  };
-  auto mma = [&](int buf) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = mfma32<T>(fw[buf][ni], fx[buf][mi], acc[ni][mi]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                         // 16 MFMA with the feed tucked into their shadows
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
-      __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);  // SALU (M0 of the LDS-DMA destination)
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read (LDS-DMA)
-      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU (pointer increment)
-    }
-  };
-
-  // prologue: sub-tiles 0..2 into stages 0..2
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (j == nsub) park();
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      glds16(srcp[p], smem, (unsigned)j * kStageBytes + (unsigned)(p >> 2) * kStageOperand + piece0 + (unsigned)(p & 3) * 1024u);
-      srcp[p] += inc[p];
-    }
-  }
-  wait_vmcnt<0>();
-  raw_barrier();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    fw[0][i] = lds_read16(smem, offw[0][i]);
-    fx[0][i] = lds_read16(smem, offx[0][i]);
-  }
-  for (int j0 = 0; j0 < nsub; j0 += kRing) {
-#pragma unroll
-    for (int u = 0; u < kRing; ++u) {
-      const int j = j0 + u;
-      if (j < nsub) {
-        if (j + 3 == nsub) park();
-        if (PIN) {
-          // explicitly pinned interleave (see gemm_w4x_kernel): 8 MFMA pairs, reads in gaps 0..5, pieces in 2..5
-          const unsigned str = (unsigned)u * kStageBytes, stn = (unsigned)((u + 1) & 3) * kStageBytes;
-          const unsigned stl = (unsigned)((u + 3) & 3) * kStageBytes;
-          auto pair = [&](int buf, int p) {
-            const int ni = p >> 1, mi = (p & 1) * 2;
-            acc[ni][mi] = mfma32<T>(fw[buf][ni], fx[buf][mi], acc[ni][mi]);
-            acc[ni][mi + 1] = mfma32<T>(fw[buf][ni], fx[buf][mi + 1], acc[ni][mi + 1]);
-          };
-          auto rd1 = [&](unsigned st, int ks, int buf, int q) {
-            if (q & 1)
-              fx[buf][q >> 1] = lds_read16(smem, st + offx[ks][q >> 1]);
-            else
-              fw[buf][q >> 1] = lds_read16(smem, st + offw[ks][q >> 1]);
-          };
-          auto piece = [&](int part, int i) {
-            const int p = part * 4 + i;
-            glds16(srcp[p], smem, stl + (unsigned)part * kStageOperand + piece0 + (unsigned)i * 1024u);
-            srcp[p] += inc[p];
-          };
-          sched_fence();
-#pragma unroll
-          for (int p = 0; p < 8; ++p) {
-            pair(0, p);
-            sched_fence();
-            if (p < 2) rd1(str, 1, 1, 2 * p), rd1(str, 1, 1, 2 * p + 1);
-            if (p >= 2 && p < 6) rd1(str, 1, 1, p + 2), piece(0, p - 2);
-            sched_fence();
-          }
-          wait_vmcnt<12>();
-          wait_lgkmcnt0();
-          raw_barrier();
-          sched_fence();
-#pragma unroll
-          for (int p = 0; p < 8; ++p) {
-            pair(1, p);
-            sched_fence();
-            if (p < 2) rd1(stn, 0, 0, 2 * p), rd1(stn, 0, 0, 2 * p + 1);
-            if (p >= 2 && p < 6) rd1(stn, 0, 0, p + 2), piece(1, p - 2);
-            sched_fence();
-          }
-          continue;
-        }
-        // k-step 0 of sub-tile j (buffer 0) | fetch k-step 1 fragments, first half of sub-tile j+3's loads
-        sched_fence();
-        feed(u, 1, 1, (u + 3) & 3, 0);
-        mma(0);
-        sched_fence();
-        // hand-off: sub-tile j+1 has landed for everybody; everybody's reads of sub-tile j are in registers
-        wait_vmcnt<12>();  // own pieces of sub-tile j+1; sub-tile j+2 (8) and half of j+3 (4) stay in flight
-        wait_lgkmcnt0();
-        raw_barrier();
-        sched_fence();
-        // k-step 1 (buffer 1) | fetch k-step 0 of sub-tile j+1, second half of sub-tile j+3's loads
-        feed((u + 1) & 3, 0, 0, (u + 3) & 3, 1);
-        mma(1);
-        sched_fence();
-      }
-    }
-  }
-  wait_vmcnt<0>();
-  wait_lgkmcnt0();
-  raw_barrier();
-  gemm_epilogue<T, EPI, ACT, 4, 4>(g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128,
-                                   n0 + wn * 128, lane);
-}
-
 // ============================================================================================ full-line feed
-// Same 4 waves x (128 x 128) shape as gemm_w4_kernel, but a ring stage is 64 k deep so one operand row of a stage
-// is exactly one 128-byte L2 line, and one LDS-DMA wave-instruction covers 8 rows x 128 B = 8 whole lines.  The
-// BK=32 kernels request every line in two 64-byte halves, one k-step apart: rocprofv3 shows 2.0x the
-// TCP_TCC_READ_REQ of hipBLASLt's MT256x256x64 kernel for the same bytes (profiles/r01_gemm_pmc.txt), and the L2
-// request path, not the schedule, bounds the loop (profiles/r01_gemm_variants.md).
+// 4 waves x (128 x 128): 256 accumulator registers per wave (the unified 512-entry file of gfx950), one wave per
+// SIMD.  A ring stage is 64 k deep so one row-major operand row of a stage is exactly one 128-byte L2 line and
+// one LDS-DMA wave-instruction covers 8 rows x 128 B = 8 whole lines (k-major stages are 512-byte k-rows: whole
+// lines too).  32-deep stages request every line in two 64-byte halves, one k-step apart: rocprofv3 shows 2.0x
+// the TCP_TCC_READ_REQ of hipBLASLt's MT256x256x64 kernel for the same bytes (profiles/r01_gemm_pmc.txt), and the
+// L2 request path, not the schedule, bounded that loop (profiles/r01_gemm_variants.md): +14-30 % from this alone.
 // LDS: 5 half-slots of 32 KiB = all 160 KiB.  Operand-stage A_j lives in slot (2j) % 5, B_j in (2j+1) % 5; row r of
 // an operand stage is 128 B at r*128, logical 16-byte chunk c at slot c ^ ((r>>1)&7) (applied on the source
 // address, undone on the fragment read; 16 consecutive rows x one chunk cover all 64 banks once).
@@ -494,13 +316,14 @@ __global__ __launch_bounds__(kW4Threads, 1) void gemm_w4_kernel(GemmArgs g) {
 // so 8-16 pieces per wave (32-64 KiB per CU) are in flight across every barrier, one barrier per 64 k.
 // Rows past M / N are clamped to the last valid row (their products land in rows / columns the epilogue never
 // stores); requires K % 64 == 0 (host dispatch).
+constexpr int kFlThreads = 256;
 constexpr int kXK = 64;
 constexpr unsigned kXHalf = 256u * kXK * 2u;  // one operand of one stage: 32 KiB
 constexpr int kXSlots = 5;
 constexpr int kXSmem = kXSlots * (int)kXHalf;  // 163840 = the whole LDS of a CU
 
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT>
-__global__ __launch_bounds__(kW4Threads, 1) void gemm_w4x_kernel(GemmArgs g) {
+__global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
@@ -728,33 +551,23 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
   return gemm_pp_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
-template <typename T, bool PIN>
-static int gemm_w4_launch(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kW4Threads);
-#define TAMD_G(E_, A_)                                                                         \
-  hipLaunchKernelGGL((gemm_w4_kernel<T, E_, A_, PIN>), grid, block, (size_t)kGemmSmem, s, g); \
-  return launch_status();
-  TAMD_EPI_SWITCH(TAMD_G)
-#undef TAMD_G
-}
-
 template <typename T, bool A_KM, bool B_KN>
-static int gemm_w4x_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kW4Threads);
+static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
 #define TAMD_G(E_, A_)                                                                              \
-  hipLaunchKernelGGL((gemm_w4x_kernel<T, A_KM, B_KN, E_, A_>), grid, block, (size_t)kXSmem, s, g); \
+  hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, E_, A_>), grid, block, (size_t)kXSmem, s, g); \
   return launch_status();
   TAMD_EPI_SWITCH(TAMD_G)
 #undef TAMD_G
 }
 
 template <typename T>
-static int gemm_w4x_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
+static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
   const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
-  if (!akm && !bkn) return gemm_w4x_launch_epi<T, false, false>(g, epilogue, act, s);
-  if (!akm && bkn) return gemm_w4x_launch_epi<T, false, true>(g, epilogue, act, s);
-  if (akm && bkn) return gemm_w4x_launch_epi<T, true, true>(g, epilogue, act, s);
-  return gemm_w4x_launch_epi<T, true, false>(g, epilogue, act, s);
+  if (!akm && !bkn) return gemm_fl_launch_epi<T, false, false>(g, epilogue, act, s);
+  if (!akm && bkn) return gemm_fl_launch_epi<T, false, true>(g, epilogue, act, s);
+  if (akm && bkn) return gemm_fl_launch_epi<T, true, true>(g, epilogue, act, s);
+  return gemm_fl_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
 }  // namespace tamd
@@ -813,20 +626,16 @@ extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias
   if (epilogue == TAMD_EPI_RESIDUAL && (!R || (ldr % 8) || !aligned16(R))) return R ? TAMD_E_ALIGN : TAMD_E_NULL;
   GemmArgs g;
   gemm_fill_args(&g, A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr);
-  // schedule: TAMD_GEMM=pp | w4 | x (full-line feed) forces one kernel (A/B measurements); default picks by operand layout
+  // schedule: the full-line kernel whenever K % 64 == 0, else the ping-pong kernel.  TAMD_GEMM=pp in the
+  // environment or a TAMD_GEMM_SCHED_* hint in `flags` forces one (A/B measurements, tests).
   static const int forced = [] {
     const char* e = getenv("TAMD_GEMM");
-    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 'w' ? (e[1] == '4' && e[2] == 'p' ? 4 : 2) : 0)));
+    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : 0));
   }();
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
-  const bool w4_ok = flags == 0 && K % kSubK == 0;
-  if (K % kXK == 0 && (sched == 3 || (sched == 0 && flags == 0))) {
-    TAMD_DISPATCH_HALF(dtype, return (gemm_w4x_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
-  } else if (w4_ok && sched == 4) {
-    TAMD_DISPATCH_HALF(dtype, return (gemm_w4_launch<T, true>(g, epilogue, act, TAMD_STREAM(stream))));
-  } else if (w4_ok && sched != 1) {
-    TAMD_DISPATCH_HALF(dtype, return (gemm_w4_launch<T, false>(g, epilogue, act, TAMD_STREAM(stream))));
+  if (K % kXK == 0 && sched != 1) {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_fl_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   } else {
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   }

@@ -323,7 +323,7 @@ def gemm_supported(m, n, k, dtype) -> bool:
     return dtype in (torch.bfloat16, torch.float16) and k % 8 == 0 and n % 8 == 0 and m > 0
 
 
-GEMM_SCHED = {None: 0, "pp": 1 << 8, "w4": 2 << 8, "x": 3 << 8, "w4p": 4 << 8}  # diagnostic schedule hints (include/tamd.h)
+GEMM_SCHED = {None: 0, "pp": 1 << 8, "fl": 3 << 8}  # diagnostic schedule hints (include/tamd.h)
 
 
 def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None,
