@@ -258,7 +258,7 @@ struct tamd_attn_bwd_params {
   void* dq;                    /* strides = q strides */
   void* dk;                    /* strides = k strides */
   void* dv;                    /* strides = v strides */
-  float* delta;                /* workspace [batch, heads_q, seq_q] fp32 */
+  float* delta;                /* workspace, 2 x [batch, heads_q, seq_q] fp32: rowsum(dO*O), then lse*log2(e) */
 };
 int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream);
 

@@ -47,6 +47,7 @@ struct WaveState {
 struct PendingDma {  // an issued, not yet landed direct-to-LDS load of one lane
   char* dst;
   unsigned char data[16];
+  int size = 16;
 };
 
 struct Fiber {

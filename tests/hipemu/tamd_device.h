@@ -298,6 +298,14 @@ inline u32x2 lds_read8_tr16(const char* smem, unsigned off) {
 inline u32x2 lds_read8_tr16_untracked(const char* smem, unsigned off, int imm) {
   return lds_read8_tr16(smem, off + (unsigned)imm);
 }
+inline u32x4 lds_read16_untracked(const char* smem, unsigned off, int imm) {
+  return lds_read16(smem, off + (unsigned)imm);
+}
+inline unsigned lds_base_u32(const char* smem) { return (unsigned)(smem - hipemu::g_blk->dyn_smem); }
+inline u32x4 lds_read16_abs(unsigned addr, int imm) { return lds_read16(hipemu::g_blk->dyn_smem, addr + (unsigned)imm); }
+inline u32x2 lds_read8_tr16_abs(unsigned addr, int imm) {
+  return lds_read8_tr16(hipemu::g_blk->dyn_smem, addr + (unsigned)imm);
+}
 // direct-to-LDS 16-byte load: LDS destination = wave-uniform base + lane*16.  Adversarial timing
 // model: the destination is POISONED (0xFFFF = bf16/f16 NaN) at issue and the data lands only at the
 // issuing lane's wait_vmcnt0().  A read before the wait, or another wave still reading the previous
@@ -329,16 +337,41 @@ inline void glds16(const void* gsrc, char* smem, unsigned wave_base_off) {
   memset(p.dst, 0xff, 16);
   emu_pending().push_back(p);
 }
+// 4-byte variant (global_load_lds_dword): LDS destination = wave-uniform base + lane*4
+inline void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
+  const int lane = hipemu::cur_lane();
+  unsigned base = wave_base_off;
+  memcpy(hipemu::cur_wave().in[lane], &base, 4);
+  hipemu::wave_collective([&](hipemu::WaveState& w, int n) {
+    unsigned b0;
+    memcpy(&b0, w.in[0], 4);
+    for (int l = 1; l < n; ++l) {
+      unsigned bl;
+      memcpy(&bl, w.in[l], 4);
+      if (bl != b0) {
+        fprintf(stderr, "hipemu: glds4 LDS base not wave-uniform (lane %d: %u vs %u)\n", l, bl, b0);
+        hipemu::g_fail.store(1);
+      }
+    }
+  });
+  emu_check_bounds(smem + wave_base_off + lane * 4, 4, "glds4");
+  EmuPendingGlds p;
+  p.dst = smem + wave_base_off + lane * 4;
+  p.size = 4;
+  memcpy(p.data, gsrc, 4);
+  memset(p.dst, 0xff, 4);
+  emu_pending().push_back(p);
+}
 inline void wait_vmcnt0() {
   auto& q = emu_pending();
-  for (auto& p : q) memcpy(p.dst, p.data, 16);
+  for (auto& p : q) memcpy(p.dst, p.data, (size_t)p.size);
   q.clear();
 }
 template <int N>
 inline void wait_vmcnt() {  // oldest-first completion until at most N remain in flight
   auto& q = emu_pending();
   size_t done = q.size() > (size_t)N ? q.size() - (size_t)N : 0;
-  for (size_t i = 0; i < done; ++i) memcpy(q[i].dst, q[i].data, 16);
+  for (size_t i = 0; i < done; ++i) memcpy(q[i].dst, q[i].data, (size_t)q[i].size);
   q.erase(q.begin(), q.begin() + done);
 }
 inline void wait_lgkmcnt0() {}

@@ -19,7 +19,7 @@ CSRC = HERE / "csrc"
 INCLUDE = HERE.parent / "include"
 LIB = HERE / "libtamd.so"
 OBJ_DIR = HERE / "_build"
-SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "probe.hip"]
+SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "probe.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wno-unused-result", "-I", str(CSRC), "-I", str(INCLUDE)] + os.environ.get("TAMD_EXTRA_HIPCC_FLAGS", "").split()
@@ -45,7 +45,8 @@ def _digest(paths) -> str:
 # attention.hip: keep MFMA results in arch VGPRs (the softmax reads every S/P element with VALU ops; the default
 # AGPR form costs a v_accvgpr_read/write per element): +39 % forward, +11 % backward on MI355X.  The same option
 # crashes clang 22 (ROCm 7.2) on gemm.hip, where it would not matter (accumulators are only touched by MFMA).
-PER_SOURCE_FLAGS: dict = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+PER_SOURCE_FLAGS: dict = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+                          "attention_bwd_dkdv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 
 def _compile(hipcc: str, src: Path, obj: Path, verbose: bool) -> None:

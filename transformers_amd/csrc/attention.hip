@@ -20,121 +20,9 @@
 //   * fp32 online softmax in the exp2 domain (scale*log2e folded), fp32 accumulators, P rounded to the
 //     storage dtype before PV exactly as the reference rounds softmax(...).to(query.dtype);
 //   * the O tile is normalised, rounded, staged through LDS and written as full rows.
-#include "common.h"
+#include "attention_common.h"
 
 namespace tamd {
-
-constexpr int kAttnThreads = 256;
-constexpr int kQB = 128;   // query rows per workgroup (32 per wave)
-constexpr int kKB = 64;    // keys per tile
-
-__device__ __attribute__((aligned(16))) static const unsigned int g_zero16a[4] = {0u, 0u, 0u, 0u};
-
-struct AttnArgs {
-  const void* q;
-  const void* k;
-  const void* v;
-  void* o;
-  float* lse;
-  const uint8_t* key_valid;
-  int batch, heads_q, heads_kv, seq_q, seq_k;
-  int64_t qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh;
-  float scale_log2;  // scale * log2(e)
-  unsigned drop_thr;  // keep iff hash >= drop_thr (0 = no dropout)
-  float drop_scale;   // 1 / (1 - p)
-  unsigned seed_lo, seed_hi;
-  int nqt;           // query tiles per (b, h)
-  int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
-};
-
-// Counter-based dropout mask: 32-bit mix of (seed, element index); identical in forward, backward and on the host
-// (tamd_dropout_hash).  index = ((b*Hq + h)*Sq + q)*Sk + k.
-__host__ __device__ __forceinline__ unsigned dropout_hash(unsigned seed_lo, unsigned seed_hi, unsigned idx_lo,
-                                                          unsigned idx_hi) {
-  unsigned x = (idx_lo ^ seed_lo) * 0x9E3779B1u;
-  x ^= x >> 15;
-  x += (idx_hi * 0x85EBCA77u) ^ seed_hi;
-  x *= 0xC2B2AE3Du;
-  x ^= x >> 13;
-  x *= 0x27D4EB2Fu;
-  x ^= x >> 16;
-  return x;
-}
-// keep-scale of element (row_index*Sk + k): 0 or 1/(1-p)
-struct DropCtx {
-  unsigned thr, seed_lo, seed_hi;
-  float scale;
-  __device__ __forceinline__ float factor(unsigned long long base, int k) const {
-    const unsigned long long idx = base + (unsigned long long)k;
-    return dropout_hash(seed_lo, seed_hi, (unsigned)idx, (unsigned)(idx >> 32)) >= thr ? scale : 0.f;
-  }
-};
-
-// One swizzle serves both read patterns of a [rows][D] tile (rows = keys or queries):
-//   ds_read_b128 of 16 distinct rows at one logical slot  -> needs a bijection of the row bits onto slots,
-//   ds_read_b64_tr_b16 of 4 consecutive rows x 64 B       -> needs the low row bits on the 64-byte window bits.
-template <int D>
-__device__ __forceinline__ int row_swz(int row) {
-  return D == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));
-}
-
-// one [64][D] tile: global rows `key0 + r` (stride `stride` elements) -> LDS at tile_off, swizzled by SWZ
-template <typename T, int D>
-__device__ __forceinline__ void issue_kv_tile(const T* __restrict__ base, int64_t stride, int key0, int nkeys,
-                                              char* smem, unsigned tile_off, int wave, int lane) {
-  constexpr int ROWB = D * 2;            // bytes per row
-  constexpr int SLOTS = ROWB / 16;       // 16-byte slots per row
-  constexpr int RPI = 1024 / ROWB;       // rows per wave instruction
-  constexpr int NI = (kKB * ROWB) / 1024 / 4;  // instructions per wave (4 waves)
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int inst = wave * NI + i;
-    const int r = inst * RPI + lane / SLOTS;
-    const int p = lane % SLOTS;
-    const int s = p ^ row_swz<D>(r);
-    const int key = key0 + r;
-    const void* src = (key < nkeys) ? (const void*)(base + (int64_t)key * stride + s * 8) : (const void*)g_zero16a;
-    glds16(src, smem, tile_off + (unsigned)inst * 1024u);
-  }
-}
-
-// Loop-invariant LDS byte offsets of one lane inside a swizzled [64][D] tile (the swizzle terms depend on the
-// lane only), so every tile read in the attention loops is `tile base + offset register + immediate`:
-//   row[ks]   : ds_read_b128 of row l31 (add 32*ROWB for the second 32-row sub-tile), k-step ks
-//   tr[dt][t] : ds_read_b64_tr_b16 of rows 4*hi+kq (+8*t), this lane's 4 columns of d-tile dt; MFMA step j adds
-//               ((j>>1)*32 + (j&1)*16) * ROWB.  The row order delivered matches the C-layout registers
-//               8*(j&1)+jj of sub-tile j>>1 (key/query = sub*32 + 16*(j&1) + 8*(jj>>2) + 4*hi + (jj&3)).
-template <int D>
-struct TileOffsets {
-  unsigned row[D / 16];
-  unsigned tr[D / 32][2];
-  __device__ __forceinline__ void init(int lane) {
-    constexpr int ROWB = D * 2;
-    const int hi = lane >> 5, l31 = lane & 31, kq = (lane & 15) >> 2;
-#pragma unroll
-    for (int ks = 0; ks < D / 16; ++ks)
-      row[ks] = (unsigned)l31 * ROWB + (unsigned)(((ks * 2 + hi) ^ row_swz<D>(l31)) * 16);
-#pragma unroll
-    for (int dt = 0; dt < D / 32; ++dt) {
-      const int col = dt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        const int r = 4 * hi + kq + 8 * t2;
-        tr[dt][t2] = (unsigned)r * ROWB + (unsigned)(((col >> 3) ^ row_swz<D>(r)) * 16) + (unsigned)(col & 7) * 2u;
-      }
-    }
-  }
-  // MFMA A operand [32 d][16 rows] for step j (transposing reads)
-  __device__ __forceinline__ u32x4 read_tr(const char* smem, unsigned tile_off, int dt, int j) const {
-    const unsigned rb = (unsigned)(((j >> 1) * 32 + (j & 1) * 16) * (D * 2));
-    const u32x2 lo = lds_read8_tr16(smem, tile_off + tr[dt][0] + rb);
-    const u32x2 h2 = lds_read8_tr16(smem, tile_off + tr[dt][1] + rb);
-    return u32x4{lo[0], lo[1], h2[0], h2[1]};
-  }
-  __device__ __forceinline__ u32x4 read_row(const char* smem, unsigned tile_off, int sub, int ks) const {
-    return lds_read16(smem, tile_off + row[ks] + (unsigned)(sub * 32 * D * 2));
-  }
-};
 
 template <typename T, int D, bool CAUSAL, bool HAS_MASK, bool DROP>
 __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {

@@ -1,0 +1,501 @@
+// attention_bwd_dkdv.hip -- dK / dV of the flash attention backward (kernel 3 of attention_bwd.inc's plan).
+//
+// Contract (SURVEY.md section 8a "Backward contract"; the reference differentiates eager_attention_forward,
+// models/llama/modeling_llama.py:191-213, by autograd):
+//   P = exp(scale*S - lse);  dV = P^T dO;  dP = dO V^T;  dS = P * (dP - delta);  dK = scale * dS^T Q
+//   (GQA: summed over the query heads of the group; dropout: P and dP are multiplied by keep/(1-p)).
+//
+// One workgroup = 128 keys of one (batch, kv-head), 4 waves x 32 keys, ONE wave per SIMD (dK/dV accumulators 128
+// registers + K/V fragments of the wave's keys 64 registers, resident for the whole kernel).  A wave alone on its
+// SIMD has nobody to hide its latencies behind and only ~5 free issue slots per MFMA, so the loop over (64-row
+// Q/dO tile, query head of the group) is built as a software pipeline and trimmed for instruction count:
+//   * tiles are walked from the LAST q-tile down, heads innermost: all workgroups of a (batch, kv-head) group then
+//     request the same Q/dO tile at about the same time and 31 of 32 CUs of the XCD hit in L2 (walking up from each
+//     workgroup's own first visible tile streamed Q/dO from MALL/HBM 16 times over: 8.8 GB per launch);
+//   * Q/dO tiles and the lse*log2e / delta rows stream global -> LDS by LDS-DMA only (16-byte pieces for the tiles,
+//     4-byte pieces for the statistics), two tiles ahead of the compute, one barrier per tile.  (Fetching the
+//     statistics with ordinary loads made the s_waitcnt for their data drain every LDS-DMA piece issued before
+//     them -- vmcnt retires in order -- so no tile load ever overlapped compute.)
+//   * the 64 MFMAs of a tile are issued as 16 groups of 4; the LDS fragments of group n+1 are requested before
+//     the MFMAs of group n issue, into the other half of a two-group register ring;
+//   * every LDS read of the loop is issued untracked (tamd_device.h) and tied to counted s_waitcnt lgkmcnt(N)
+//     through register dependencies: the compiler drains vmcnt in front of every ds_read_b64_tr_b16 it can see
+//     while LDS-DMA is in flight, and its own lgkmcnt(0) for one tracked read would drain the reads issued ahead;
+//   * softmax-backward arithmetic of sub-tile s (4 chunks of 4 query rows) is interleaved with the MFMAs of the
+//     next phase (sched_group_barrier), branch-free (the mask test costs 2 VALU per element on every tile, a
+//     branch would cut the interleave), packed-f32 VALU off (-fno-slp-vectorize: an anti-lever beside MFMAs);
+//   * the loop is unrolled over the two LDS buffers so every LDS offset is an immediate; per-lane global offsets of
+//     the LDS-DMA pieces are loop invariants; (head, tile) counters instead of divisions.
+// Measured on MI355X at the Llama-3-8B shape (tools/attn_bench.py, tools/attn_dkdv_dbg.py): whole backward 5.98 ->
+// 4.16 ms (460 -> 661 TFLOP/s); ablations of the final kernel: -0.57 ms without the softmax arithmetic, -0.44
+// without LDS fragment reads, -0.61 without MFMA: issue-slot-bound, not pipe-bound.
+// S = Q.K^T is computed un-swapped so a lane owns a key column: the P and dS registers are directly the MFMA B
+// operands of dV^T[d][key] += dO^T[d][q].P[q][key] and dK^T[d][key] += Q^T[d][q].dS[q][key].
+#include "attention_common.h"
+
+namespace tamd {
+
+__device__ __attribute__((aligned(16))) static const unsigned int g_pinf32[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u,
+                                                                                0x7f800000u};
+
+// s_waitcnt lgkmcnt(N) that the four fragments depend on: MFMAs consuming them cannot be scheduled above it
+template <int N>
+__device__ __forceinline__ void wait_frags(u32x4& f0, u32x4& f1, u32x4& f2, u32x4& f3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "n"(N) : "memory");
+#else
+  (void)f0;
+  (void)f1;
+  (void)f2;
+  (void)f3;
+#endif
+}
+
+// DBG (diagnostic builds, TAMD_DKDV_DBG=n, wrong results): 1 no softmax arithmetic, 2 no LDS fragment reads,
+// 4 no MFMA, 8 no tile loads after the prologue, 16 no barrier
+// order-only dependency: the registers are "produced" here, after every earlier volatile asm (the waits)
+__device__ __forceinline__ void after_wait(u32x4& x0, u32x4& x1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x0), "+v"(x1)::"memory");
+#else
+  (void)x0;
+  (void)x1;
+#endif
+}
+
+template <typename T, int D, bool CAUSAL, bool HAS_MASK, bool DROP, int DBG = 0>
+__global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdArgs g, int nkvt) {
+  const AttnArgs& a = g.f;
+  constexpr int ROWB = D * 2, TILEB = kQT * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
+  constexpr int BUFB = 2 * TILEB + 2 * kQT * 4;  // Q tile + dO tile + lse[64] + delta[64]
+  constexpr int NGA = KS / 2;                    // MFMA groups of one S/dP sub-tile (2 k-steps x {S, dP} each)
+  constexpr int NGC = DT;                        // MFMA groups of one half of dV/dK (2 d-tiles x {dV, dK} each)
+  static_assert(KS % 2 == 0 && DT % 2 == 0, "head_dim must be a multiple of 64");
+  TAMD_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id_uniform();
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int group = a.heads_q / a.heads_kv;
+  int b, hkv, kvt;
+  {
+    const int bid = blockIdx.x;
+    int gi, within;
+    if (a.xcd_map) {
+      const int xcd = bid & 7, j = bid >> 3;
+      gi = (j / nkvt) * 8 + xcd;
+      within = j % nkvt;
+    } else {
+      gi = bid / nkvt;
+      within = bid % nkvt;
+    }
+    b = gi / a.heads_kv;
+    hkv = gi % a.heads_kv;
+    kvt = within;  // early key blocks see the most queries under a causal mask: they come first
+  }
+  const int k0 = kvt * kKVB, kw0 = k0 + wave * 32, krow = kw0 + l31;
+  const int off = a.seq_k - a.seq_q;
+  const T* K = reinterpret_cast<const T*>(a.k) + (int64_t)b * a.ksb + (int64_t)hkv * a.ksh;
+  const T* V = reinterpret_cast<const T*>(a.v) + (int64_t)b * a.vsb + (int64_t)hkv * a.vsh;
+
+  // K / V fragments of this lane's key (MFMA B operands), resident in registers for the whole kernel
+  u32x4 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const bool ok = krow < a.seq_k;
+    kf[ks] = ok ? ld16(K + (int64_t)krow * a.kss + ks * 16 + hi * 8) : u32x4{0, 0, 0, 0};
+    vf[ks] = ok ? ld16(V + (int64_t)krow * a.vss + ks * 16 + hi * 8) : u32x4{0, 0, 0, 0};
+  }
+  bool key_ok = krow < a.seq_k;
+  if (HAS_MASK && a.key_valid != nullptr)
+    key_ok = key_ok && a.key_valid[(int64_t)b * a.seq_k + (krow < a.seq_k ? krow : 0)] != 0;
+  const DropCtx drop = {a.drop_thr, a.seed_lo, a.seed_hi, a.drop_scale};
+
+  TileOffsets<D> toff;
+  toff.init(lane);
+  f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dkacc[dt][r] = 0.f;
+      dvacc[dt][r] = 0.f;
+    }
+
+  // query tiles that can see any key of this block
+  int qt_first = 0;
+  if (CAUSAL) {
+    const int qmin = k0 - off;  // first query row that sees key k0
+    qt_first = qmin > 0 ? qmin / kQT : 0;
+  }
+  const int nqt64 = (a.seq_q + kQT - 1) / kQT;
+  const int per_head = nqt64 > qt_first ? nqt64 - qt_first : 0;
+  const int niter = per_head * group;
+
+  // loop-invariant byte offsets of this lane inside a [64][D] global tile, one per LDS-DMA piece of this wave (the
+  // generic issue_kv_tile recomputes rows, swizzles and 64-bit products per piece and per tile: ~150 instructions
+  // a tile, all of them exposed on a one-wave-per-SIMD kernel)
+  constexpr int SLOTS = ROWB / 16, RPI = 1024 / ROWB, NI = (kQT * ROWB) / 1024 / 4;
+  const int lane_row = lane / SLOTS;
+  unsigned pq[NI], po[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int r = (wave * NI + i) * RPI + lane_row;
+    const unsigned sl = (unsigned)((lane % SLOTS) ^ row_swz<D>(r)) * 16u;
+    pq[i] = (unsigned)r * (unsigned)a.qss * 2u + sl;
+    po[i] = (unsigned)r * (unsigned)a.oss * 2u + sl;
+  }
+  // tile `it` -> LDS buffer `buf`.  Order: q-tiles from the LAST one down to the first visible one, the query
+  // heads of the group innermost.  Every workgroup of a (batch, kv-head) group then walks the same (tile, head)
+  // sequence from the same starting point, so the 32 CUs of an XCD request a Q/dO tile at about the same time and
+  // 31 of them hit in L2; walking up from each workgroup's own first visible tile (the previous order) streamed
+  // the tiles from MALL/HBM 16 times over: 8.8 GB per launch, a 1.05 ms floor at the Llama-3-8B shape.
+  // (a padding tile it >= niter -- the loop runs an even number of tiles -- addresses rows past seq_q only: zeros)
+  int iss_h = 0, iss_qt = nqt64 - 1;  // (head, q-tile) of the next tile to issue: no division in the loop
+  auto issue = [&](int it, int buf) {
+    const bool pad = it >= niter;
+    const int hg = pad ? 0 : iss_h, qt = pad ? nqt64 : iss_qt;
+    if (++iss_h == group) {
+      iss_h = 0;
+      --iss_qt;
+    }
+    const int h = hkv * group + hg;
+    const char* bq = (const char*)(reinterpret_cast<const T*>(a.q) + (int64_t)b * a.qsb + (int64_t)h * a.qsh +
+                                   (int64_t)qt * kQT * a.qss);
+    const char* bo = (const char*)(reinterpret_cast<const T*>(g.dout) + (int64_t)b * a.osb + (int64_t)h * a.osh +
+                                   (int64_t)qt * kQT * a.oss);
+    const unsigned q_off = (unsigned)buf * BUFB, do_off = q_off + TILEB, st_off = do_off + TILEB;
+    const int rows_left = a.seq_q - qt * kQT;  // wave-uniform
+    if (rows_left >= kQT) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) glds16(bq + pq[i], smem, q_off + (unsigned)(wave * NI + i) * 1024u);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) glds16(bo + po[i], smem, do_off + (unsigned)(wave * NI + i) * 1024u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const bool ok = (wave * NI + i) * RPI + lane_row < rows_left;
+        glds16(ok ? (const void*)(bq + pq[i]) : (const void*)g_zero16a, smem, q_off + (unsigned)(wave * NI + i) * 1024u);
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const bool ok = (wave * NI + i) * RPI + lane_row < rows_left;
+        glds16(ok ? (const void*)(bo + po[i]) : (const void*)g_zero16a, smem, do_off + (unsigned)(wave * NI + i) * 1024u);
+      }
+    }
+    if (wave < 2) {  // wave 0: lse of the tile's 64 rows, wave 1: delta; rows past seq_q read +inf / 0 (p = 0)
+      const int qr = qt * kQT + lane;
+      const float* src = (const float*)g.delta + (wave ? 0 : (int64_t)a.batch * a.heads_q * a.seq_q) +
+                         ((int64_t)b * a.heads_q + h) * a.seq_q + qr;  // wave 0: lse*log2(e) (second half)
+      const void* p = (qr < a.seq_q) ? (const void*)src : (wave ? (const void*)g_zero16a : (const void*)g_pinf32);
+      glds4(p, smem, st_off + (unsigned)wave * (kQT * 4));
+    }
+  };
+
+  // absolute LDS addresses of this lane's fragment reads (untracked reads take base + 16-bit immediate)
+  const unsigned lds0 = lds_base_u32(smem);
+  unsigned rowaddr[KS], traddr[DT][2];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) rowaddr[ks] = lds0 + toff.row[ks];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    traddr[dt][0] = lds0 + toff.tr[dt][0];
+    traddr[dt][1] = lds0 + toff.tr[dt][1];
+  }
+  const unsigned stataddr[2] = {lds0 + (unsigned)hi * 16u + (unsigned)(2 * TILEB),
+                                lds0 + (unsigned)hi * 16u + (unsigned)(BUFB + 2 * TILEB)};
+  auto mm = [&](u32x4 x, u32x4 y, f32x16 c) -> f32x16 {
+    if (DBG & 4) {
+      c[0] += u32_as_f32(x[0] ^ y[0]);
+      return c;
+    }
+    return mfma32<T>(x, y, c);
+  };
+  u32x4 fa[4], fb[4];  // two-group fragment ring: even groups use fa, odd groups fb (16 groups per tile: even)
+  // S/dP group ga (0..NGA-1) of sub-tile `sub`: fragments Q(ks0) dO(ks0) Q(ks0+1) dO(ks0+1), ks0 = 2*ga
+  auto load_rows = [&](u32x4 (&f)[4], unsigned q_off, unsigned do_off, int sub, int ga) {
+    if (DBG & 2) return;
+    const int si = sub * 32 * ROWB;
+    f[0] = lds_read16_abs(rowaddr[2 * ga], (int)q_off + si);
+    f[1] = lds_read16_abs(rowaddr[2 * ga], (int)do_off + si);
+    f[2] = lds_read16_abs(rowaddr[2 * ga + 1], (int)q_off + si);
+    f[3] = lds_read16_abs(rowaddr[2 * ga + 1], (int)do_off + si);
+  };
+  // dV/dK group (d-tile pair dtp, MFMA step j): fragments dO^T(dt0,j) Q^T(dt0,j) dO^T(dt1,j) Q^T(dt1,j)
+  // (the loop is unrolled over the two LDS buffers, so tile offsets are constants and ride in the offset field)
+  auto tr_frag = [&](unsigned tile_off, int dt, int j) -> u32x4 {
+    const int imm = ((j >> 1) * 32 + (j & 1) * 16) * ROWB + (int)tile_off;
+    const u32x2 lo = lds_read8_tr16_abs(traddr[dt][0], imm);
+    const u32x2 h2 = lds_read8_tr16_abs(traddr[dt][1], imm);
+    return u32x4{lo[0], lo[1], h2[0], h2[1]};
+  };
+  auto load_tr = [&](u32x4 (&f)[4], unsigned q_off, unsigned do_off, int dtp, int j) {
+    if (DBG & 2) return;
+    f[0] = tr_frag(do_off, 2 * dtp, j);
+    f[1] = tr_frag(q_off, 2 * dtp, j);
+    f[2] = tr_frag(do_off, 2 * dtp + 1, j);
+    f[3] = tr_frag(q_off, 2 * dtp + 1, j);
+  };
+
+  if (niter > 0) issue(0, 0);
+  if (niter > 0) issue(1, 1);  // (a padding tile when niter == 1)
+  wait_vmcnt0();
+  block_sync();
+  // Straight-line loop body (no per-wave skip of fully masked tiles: the causal mask zeroes them, and the two
+  // waves it concerns lose one tile per head; any divergent path through the body makes the compiler shuffle the
+  // 128 accumulator registers at every back edge).  Group 0's fragments are requested one tile ahead, into fa.
+  if (niter > 0) load_rows(fa, 0u, (unsigned)TILEB, 0, 0);
+  const int niter2 = (niter + 1) & ~1;  // even: an odd count gets one all-zero padding tile
+  int cmp_h = 0, cmp_qt = nqt64 - 1;    // (head, q-tile) of the tile being computed
+  for (int it0 = 0; it0 < niter2; it0 += 2) {
+#pragma unroll
+   for (int cur = 0; cur < 2; ++cur) {
+    const int it = it0 + cur;
+    const unsigned q_off = (unsigned)cur * BUFB, do_off = q_off + TILEB, st_off = do_off + TILEB;
+    const unsigned nq_off = (unsigned)(cur ^ 1) * BUFB, ndo_off = nq_off + TILEB;
+    const int qt0 = it < niter ? cmp_qt * kQT : nqt64 * kQT;
+    const int hcur = hkv * group + (it < niter ? cmp_h : 0);
+    if (++cmp_h == group) {
+      cmp_h = 0;
+      --cmp_qt;
+    }
+    // hand-off, placed before the last MFMA group of the tile: by then every fragment of this tile is in
+    // registers, so the buffer can take tile it+2 at once; tile it+1 (requested one tile ago) must have landed
+    auto hand_off = [&]() {
+      wait_vmcnt0();
+      wait_lgkmcnt0();
+      if (!(DBG & 16)) raw_barrier();
+      sched_fence();
+      if (it + 2 < niter2 && !(DBG & 8)) issue(it + 2, cur);
+    };
+    // key visible to local query row r of this tile iff mask_lim <= r (padding / out-of-range keys: never)
+    const int mask_lim = key_ok ? (CAUSAL ? krow - (qt0 + off) : -0x40000000) : 0x40000000;
+    sched_fence();
+
+    f32x16 s[2], dp[2];
+    u32x4 pf[4], dsf[4];
+    // softmax backward of 4 consecutive query rows (chunk qd) of sub-tile `sub`: C-layout registers qd*4 .. +3 of
+    // P and dS, rounded and packed at once into B operand sub*2 + (qd>>1), dwords (qd&1)*2 .. +1
+    // lse / delta of 4 consecutive query rows of chunk qd (16 bytes each; lane part of the address = 16*hi)
+    auto stat_reads = [&](int sub, int qd, u32x4& l4, u32x4& d4) {
+      if (DBG & 1) return;
+      const int imm = (sub * 32 + 8 * qd) * 4;  // (st_off of the second buffer does not fit the 16-bit offset field)
+      l4 = lds_read16_abs(stataddr[cur], imm);
+      d4 = lds_read16_abs(stataddr[cur], imm + kQT * 4);
+    };
+    auto softmax_chunk = [&](int sub, int qd, const u32x4& l4, const u32x4& d4) {
+      if (DBG & 1) {
+        const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
+        pf[op][w] = f32_as_u32(s[sub][qd * 4]);
+        pf[op][w + 1] = f32_as_u32(s[sub][qd * 4 + 1]);
+        dsf[op][w] = f32_as_u32(dp[sub][qd * 4]);
+        dsf[op][w + 1] = f32_as_u32(dp[sub][qd * 4 + 1]);
+        return;
+      }
+      float p[4], ds[4];
+      const int ql = sub * 32 + 8 * qd + 4 * hi;  // 4 consecutive query rows (r&3)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = qd * 4 + e;
+        float x = s[sub][r];
+        // branch-free: a branch here would cut the MFMA / VALU interleave into pieces; the test costs 2 VALU per
+        // element on every tile (mask_lim is -2^30 on tiles that need no mask)
+        x = (mask_lim <= ql + e) ? x : -INFINITY;
+        const float pe = fast_exp2(__builtin_fmaf(x, a.scale_log2, -u32_as_f32(l4[e])));
+        float keep = 1.f;
+        if (DROP) {
+          const int qg = qt0 + ql + e;  // global query row
+          const unsigned long long base =
+              (((unsigned long long)b * a.heads_q + hcur) * a.seq_q + (qg < a.seq_q ? qg : 0)) * (unsigned long long)a.seq_k;
+          keep = drop.factor(base, krow < a.seq_k ? krow : 0);
+        }
+        p[e] = pe * keep;  // dV uses the dropped probabilities
+        ds[e] = pe * (dp[sub][r] * keep - u32_as_f32(d4[e]));
+      }
+      const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
+      pf[op][w] = pack2<T>(p[0], p[1]);
+      pf[op][w + 1] = pack2<T>(p[2], p[3]);
+      dsf[op][w] = pack2<T>(ds[0], ds[1]);
+      dsf[op][w + 1] = pack2<T>(ds[2], ds[3]);
+    };
+
+    // one MFMA, then a slice of the chunk's arithmetic, four times: the wave has the SIMD to itself, so the VALU
+    // work must sit inside the MFMA shadows of its own instruction stream
+    auto mfma_valu_interleave = [&]() {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // DS read (lse / delta rows)
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);                  // TRANS (v_exp)
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                  // VALU
+      }
+    };
+    // ---- phases A0, A1: S and dP of the two 32-row sub-tiles; A1 carries the softmax backward of sub-tile 0
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[sub][r] = 0.f;
+        dp[sub][r] = 0.f;
+      }
+#pragma unroll
+      for (int ga = 0; ga < NGA; ++ga) {
+        const int gidx = sub * NGA + ga;  // group index inside the tile (parity picks the ring half)
+        u32x4(&fc)[4] = (gidx & 1) ? fb : fa;
+        u32x4(&fn)[4] = (gidx & 1) ? fa : fb;
+        constexpr int NCH_A = 4 / NGA;  // softmax chunks carried by one A1 group
+        u32x4 l4[NCH_A], d4[NCH_A];
+        // every LDS read of the loop is untracked; issue order = completion order:
+        //   statistics of this group's chunks | next group's fragments | (wait: all but the newest batch)
+        if (sub == 1) {
+#pragma unroll
+          for (int c = 0; c < NCH_A; ++c) stat_reads(0, ga * NCH_A + c, l4[c], d4[c]);
+        }
+        if (ga + 1 < NGA)
+          load_rows(fn, q_off, do_off, sub, ga + 1);
+        else if (sub == 0)
+          load_rows(fn, q_off, do_off, 1, 0);
+        else
+          load_tr(fn, q_off, do_off, 0, 0);
+        sched_fence();
+        if (sub == 1 && ga == NGA - 1)
+          wait_frags<8>(fc[0], fc[1], fc[2], fc[3]);
+        else
+          wait_frags<4>(fc[0], fc[1], fc[2], fc[3]);
+        if (sub == 1) {
+#pragma unroll
+          for (int c = 0; c < NCH_A; ++c) after_wait(l4[c], d4[c]);
+        }
+        sched_fence();
+        s[sub] = mm(fc[0], kf[2 * ga], s[sub]);
+        dp[sub] = mm(fc[1], vf[2 * ga], dp[sub]);
+        s[sub] = mm(fc[2], kf[2 * ga + 1], s[sub]);
+        dp[sub] = mm(fc[3], vf[2 * ga + 1], dp[sub]);
+        if (sub == 1) {  // softmax backward of sub-tile 0 in the shadow of these MFMAs (NGA = 2: two chunks)
+#pragma unroll
+          for (int c = 0; c < NCH_A; ++c) softmax_chunk(0, ga * NCH_A + c, l4[c], d4[c]);
+          mfma_valu_interleave();
+        }
+        sched_fence();
+      }
+    }
+    // ---- phases C0, C1: dV += dO^T P, dK += Q^T dS over the two halves of the tile's query rows; C0 carries
+    // the softmax backward of sub-tile 1; the hand-off sits before the last group
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int gc = 0; gc < NGC; ++gc) {
+        const int gidx = 2 * NGA + half * NGC + gc;
+        const int dtp = gc >> 1, j = half * 2 + (gc & 1);
+        u32x4(&fc)[4] = (gidx & 1) ? fb : fa;
+        u32x4(&fn)[4] = (gidx & 1) ? fa : fb;
+        const bool last = (half == 1 && gc == NGC - 1);
+        constexpr int NCH_C = 4 / NGC;
+        u32x4 l4[NCH_C], d4[NCH_C];
+        if (half == 0) {
+#pragma unroll
+          for (int c = 0; c < NCH_C; ++c) stat_reads(1, gc * NCH_C + c, l4[c], d4[c]);
+        }
+        if (last) {
+          hand_off();  // waits lgkmcnt(0): this group's fragments are in registers
+          load_rows(fn, nq_off, ndo_off, 0, 0);  // group 0 of tile it+1 (stale but harmless after the last tile)
+          sched_fence();
+          wait_frags<15>(fc[0], fc[1], fc[2], fc[3]);  // dependency only (nothing left to wait for)
+        } else {
+          const int gn = gc + 1 < NGC ? gc + 1 : 0, hn = gc + 1 < NGC ? half : 1;
+          load_tr(fn, q_off, do_off, gn >> 1, hn * 2 + (gn & 1));
+          sched_fence();
+          wait_frags<8>(fc[0], fc[1], fc[2], fc[3]);  // all but the 8 reads just issued
+        }
+        if (half == 0) {
+#pragma unroll
+          for (int c = 0; c < NCH_C; ++c) after_wait(l4[c], d4[c]);
+        }
+        sched_fence();
+        dvacc[2 * dtp] = mm(fc[0], pf[j], dvacc[2 * dtp]);
+        dkacc[2 * dtp] = mm(fc[1], dsf[j], dkacc[2 * dtp]);
+        dvacc[2 * dtp + 1] = mm(fc[2], pf[j], dvacc[2 * dtp + 1]);
+        dkacc[2 * dtp + 1] = mm(fc[3], dsf[j], dkacc[2 * dtp + 1]);
+        if (half == 0) {  // softmax backward of sub-tile 1 in the shadow of these MFMAs
+#pragma unroll
+          for (int c = 0; c < NCH_C; ++c) softmax_chunk(1, gc * NCH_C + c, l4[c], d4[c]);
+          mfma_valu_interleave();
+        }
+        sched_fence();
+      }
+    }
+   }
+  }
+  // the last hand-off left nothing in flight; every wave is past its LDS reads only after a barrier
+  wait_vmcnt0();
+  block_sync();
+  T* dK = reinterpret_cast<T*>(g.dk) + (int64_t)b * a.ksb + (int64_t)hkv * a.ksh;
+  T* dV = reinterpret_cast<T*>(g.dv) + (int64_t)b * a.vsb + (int64_t)hkv * a.vsh;
+  const unsigned st = (unsigned)wave * (32u * OROWB);
+  store_rows_via_lds<T, D>(dkacc, g.scale, smem, st, dK, a.kss, kw0, a.seq_k, lane);
+  wave_lockstep_point();
+  store_rows_via_lds<T, D>(dvacc, 1.f, smem, st, dV, a.vss, kw0, a.seq_k, lane);
+}
+
+template <typename T, int D>
+static int dkdv_launch(const AttnBwdArgs& g, bool causal, hipStream_t s) {
+  const AttnArgs& a = g.f;
+  const bool mask = a.key_valid != nullptr;
+  const bool drop = a.drop_thr != 0;
+  const int nkvt = (int)ceil_div(a.seq_k, kKVB);
+  const size_t smem = (size_t)2 * (2 * kQT * D * 2 + 2 * kQT * 4);
+  dim3 grid((unsigned)(nkvt * a.heads_kv * a.batch)), block(kAttnThreads);
+#define TAMD_KV(C_, M_, D_) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, C_, M_, D_>), grid, block, smem, s, g, nkvt)
+  if (drop) {  // the dropout variants always carry the padding-mask code
+    if (causal)
+      TAMD_KV(true, true, true);
+    else
+      TAMD_KV(false, true, true);
+  } else if (causal) {
+    static const int dbg = [] {
+      const char* e = getenv("TAMD_DKDV_DBG");
+      return e ? atoi(e) : 0;
+    }();
+#define TAMD_KVD(N_) \
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, false, false, N_>), grid, block, smem, s, g, nkvt)
+    if (mask)
+      TAMD_KV(true, true, false);
+    else if (dbg == 1)
+      TAMD_KVD(1);
+    else if (dbg == 2)
+      TAMD_KVD(2);
+    else if (dbg == 4)
+      TAMD_KVD(4);
+    else if (dbg == 8)
+      TAMD_KVD(8);
+    else if (dbg == 16)
+      TAMD_KVD(16);
+    else if (dbg == 3)
+      TAMD_KVD(3);
+    else if (dbg == 7)
+      TAMD_KVD(7);
+    else if (dbg == 6)
+      TAMD_KVD(6);
+    else
+      TAMD_KV(true, false, false);
+#undef TAMD_KVD
+  } else {
+    if (mask)
+      TAMD_KV(false, true, false);
+    else
+      TAMD_KV(false, false, false);
+  }
+#undef TAMD_KV
+  return launch_status();
+}
+
+int attn_bwd_dkdv_launch(const AttnBwdArgs& g, int dtype, int head_dim, bool causal, hipStream_t s) {
+  if (head_dim == 128) {
+    TAMD_DISPATCH_HALF(dtype, return (dkdv_launch<T, 128>(g, causal, s)));
+  } else {
+    TAMD_DISPATCH_HALF(dtype, return (dkdv_launch<T, 64>(g, causal, s)));
+  }
+  return TAMD_E_DTYPE;
+}
+
+}  // namespace tamd

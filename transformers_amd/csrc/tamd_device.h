@@ -132,6 +132,31 @@ __device__ __forceinline__ u32x2 lds_read8_tr16_untracked(const char* smem, unsi
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(imm) : "memory");
   return v;
 }
+// ds_read_b128 issued the same way (lets a kernel keep ALL its LDS reads out of the compiler's lgkmcnt bookkeeping,
+// so that no compiler-placed lgkmcnt(0) drains reads the kernel issued ahead on purpose).
+__device__ __forceinline__ u32x4 lds_read16_untracked(const char* smem, unsigned off, int imm) {
+  typedef __attribute__((address_space(3))) const char lds_char;
+  const unsigned addr = (unsigned)reinterpret_cast<__UINTPTR_TYPE__>((lds_char*)smem) + off;
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(imm) : "memory");
+  return v;
+}
+// LDS byte address of the dynamic shared array (what ds_* instructions take)
+__device__ __forceinline__ unsigned lds_base_u32(const char* smem) {
+  typedef __attribute__((address_space(3))) const char lds_char;
+  return (unsigned)reinterpret_cast<__UINTPTR_TYPE__>((lds_char*)smem);
+}
+// ... and with the absolute LDS byte address already in a register (no per-read address arithmetic)
+__device__ __forceinline__ u32x4 lds_read16_abs(unsigned addr, int imm) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(imm) : "memory");
+  return v;
+}
+__device__ __forceinline__ u32x2 lds_read8_tr16_abs(unsigned addr, int imm) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(imm) : "memory");
+  return v;
+}
 // Direct-to-LDS 16-byte load: the wave writes 64 x 16 B = 1 KiB contiguous at
 // `smem + wave_base_off` (must be wave-uniform); each lane supplies its own
 // global source address.  Completion is tracked by vmcnt.
@@ -140,6 +165,11 @@ template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, char* smem, unsigned wave_base_off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)(smem + wave_base_off), 16, 0, AUX);
+}
+// 4-byte variant (global_load_lds_dword): the wave writes 64 x 4 B = 256 B contiguous at smem + wave_base_off
+__device__ __forceinline__ void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)(smem + wave_base_off), 4, 0, 0);
 }
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // counted wait: returns when at most N of this wave's vector-memory operations (incl. LDS-DMA) are pending

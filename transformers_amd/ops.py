@@ -394,7 +394,7 @@ def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, 
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
     if key_valid is not None:
         key_valid = _c(key_valid.to(torch.uint8))
-    delta = torch.empty_like(lse)
+    delta = torch.empty((2,) + tuple(lse.shape), dtype=torch.float32, device=lse.device)  # delta | lse*log2(e)
     bp = _cabi.AttnBwdParams()
     bp.fwd = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed)
     bp.dout, bp.dq, bp.dk, bp.dv, bp.delta = (dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
