@@ -337,6 +337,11 @@ inline void glds16(const void* gsrc, char* smem, unsigned wave_base_off) {
   memset(p.dst, 0xff, 16);
   emu_pending().push_back(p);
 }
+// buffer-addressed variant: the instruction immediate is added to the global AND the LDS address
+template <int IMM>
+inline void glds16_buf(const void* base, unsigned voff, char* smem, unsigned lds_base_off) {
+  glds16<0>(reinterpret_cast<const char*>(base) + voff + IMM, smem, lds_base_off + (unsigned)IMM);
+}
 // 4-byte variant (global_load_lds_dword): LDS destination = wave-uniform base + lane*4
 inline void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   const int lane = hipemu::cur_lane();

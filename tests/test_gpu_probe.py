@@ -34,13 +34,15 @@ def _inputs(which, rng):
     elif which == 2:
         # per-lane 8-byte-aligned byte offsets: the strided/swizzled pattern of frag_tr plus random ones
         in2 = (rng.integers(0, 2048, size=64).astype(np.uint32)) * 8
-    elif which == 4:
+    elif which in (4, 5):
         in2 = (rng.permutation(512)[:64].astype(np.uint32)) * 16
+    elif which == 6:
+        in2 = (rng.permutation(500)[:64].astype(np.uint32)) * 16  # + immediates up to 3072 + 2048: inside 16 KiB
     return inp, in2
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
 def test_hardware_matches_cpu_model(which):
     from emu_backend import get_emu
 

@@ -314,6 +314,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
 //     hand-off   : vmcnt(8) retires this wave's B_{s+1} (A_{s+1} is older), lgkmcnt(0), barrier
 //     k-step 3   : 16 MFMA | 8 fragment reads of stage s+1 | 8 pieces of B_{s+2} (into the slot A_s vacated)
 // so 8-16 pieces per wave (32-64 KiB per CU) are in flight across every barrier, one barrier per 64 k.
+// (That was the first version; the shipped schedule spreads the pieces 4 per k-step -- B_{s+1}[4:8] | A_{s+2}[0:4] |
+// A_{s+2}[4:8] | B_{s+2}[0:4] -- and feeds through buffer_load ... lds: wave-uniform operand base stepped per
+// stage, loop-invariant 32-bit lane offsets, one M0 per 4 pieces via the shared immediate.)
 // Rows past M / N are clamped to the last valid row (their products land in rows / columns the epilogue never
 // stores); requires K % 64 == 0 (host dispatch).
 constexpr int kFlThreads = 256;
@@ -322,8 +325,13 @@ constexpr unsigned kXHalf = 256u * kXK * 2u;  // one operand of one stage: 32 Ki
 constexpr int kXSlots = 5;
 constexpr int kXSmem = kXSlots * (int)kXHalf;  // 163840 = the whole LDS of a CU
 
-template <typename T, bool A_KM, bool B_KN, int EPI, int ACT>
+// DBG (diagnostic instantiations, TAMD_GEMM_DBG=n, wrong results): 1 no LDS-DMA after the prologue, 2 no LDS
+// fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier
+// FEED 0: global_load_lds with per-lane 64-bit pointers; FEED 1: buffer_load ... lds (tamd_device.h glds16_buf): wave-
+// uniform operand base stepped per stage, loop-invariant 32-bit lane offsets, one M0 per 4 pieces.
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
+  constexpr int SCHED = 1, FEED = 1;  // the measured winners (profiles/r01_gemm_variants.md); 0/0 = first version
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
@@ -351,40 +359,75 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   //                      ping-pong kernel); piece i = k-rows (wave*8+i)*2 .. +1, lane -> (k = lane>>5, physical
   //                      chunk = lane&31); next stage = +64 rows
   // Rows / column chunks outside the matrix are clamped to the last valid one.
-  const char* srcp[16];
+  const char* srcp[FEED == 0 ? 16 : 1];
+  unsigned voff[FEED == 1 ? 16 : 1];  // FEED 1: byte offset from the operand base + 4096 - 1024*(piece & 3)
   int64_t kinc_a = A_KM ? (int64_t)kXK * g.lda * 2 : kXK * 2;  // bytes per stage; 0 once parked
   int64_t kinc_b = B_KN ? (int64_t)kXK * g.ldb * 2 : kXK * 2;
+  // FEED 1 operand bases (tile origin - 4096 B so that no lane offset goes negative after the immediate is taken out)
+  const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096;
+  const char* base_b = (const char*)(B_KN ? B + n0 : B + n0 * g.ldb) - 4096;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (wave * 8 + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     const int kr = (wave * 8 + i) * 2 + (lane >> 5);
     const int col = ((lane & 31) ^ ((kr & 3) << 2)) * 8;
-    if (A_KM) {
-      const int64_t gc = (m0 + col < g.M) ? m0 + col : g.M - 8;
-      srcp[i] = (const char*)(A + (int64_t)kr * g.lda + gc);
+    const int64_t gca = (m0 + col < g.M) ? m0 + col : g.M - 8;
+    const int64_t ra = (m0 + row < g.M) ? m0 + row : g.M - 1;
+    const int64_t gcb = (n0 + col < g.N) ? n0 + col : g.N - 8;
+    const int64_t rb = (n0 + row < g.N) ? n0 + row : g.N - 1;
+    if (FEED == 0) {
+      srcp[i] = A_KM ? (const char*)(A + (int64_t)kr * g.lda + gca) : (const char*)(A + ra * g.lda + c * 8);
+      srcp[8 + i] = B_KN ? (const char*)(B + (int64_t)kr * g.ldb + gcb) : (const char*)(B + rb * g.ldb + c * 8);
     } else {
-      const int64_t ra = (m0 + row < g.M) ? m0 + row : g.M - 1;
-      srcp[i] = (const char*)(A + ra * g.lda + c * 8);
-    }
-    if (B_KN) {
-      const int64_t gc = (n0 + col < g.N) ? n0 + col : g.N - 8;
-      srcp[8 + i] = (const char*)(B + (int64_t)kr * g.ldb + gc);
-    } else {
-      const int64_t rb = (n0 + row < g.N) ? n0 + row : g.N - 1;
-      srcp[8 + i] = (const char*)(B + rb * g.ldb + c * 8);
+      const int64_t oa = A_KM ? (int64_t)kr * g.lda + (gca - m0) : (ra - m0) * g.lda + c * 8;
+      const int64_t ob = B_KN ? (int64_t)kr * g.ldb + (gcb - n0) : (rb - n0) * g.ldb + c * 8;
+      voff[i] = (unsigned)(oa * 2 + 4096 - (i & 3) * 1024);
+      voff[8 + i] = (unsigned)(ob * 2 + 4096 - (i & 3) * 1024);
     }
   }
-  auto park = [&]() {  // past the last stage: keep the load counts uniform but read the zero page
+  // past the last stage: keep the load counts uniform but read the zero page (FEED 1: re-read the last stage)
+  auto park_a = [&]() {
+    if (FEED == 0) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) srcp[p] = (const char*)g_zero16;
+      for (int p = 0; p < 8; ++p) srcp[p] = (const char*)g_zero16;
+    } else {
+      base_a -= kinc_a;
+    }
     kinc_a = 0;
+  };
+  auto park_b = [&]() {
+    if (FEED == 0) {
+#pragma unroll
+      for (int p = 8; p < 16; ++p) srcp[p] = (const char*)g_zero16;
+    } else {
+      base_b -= kinc_b;
+    }
     kinc_b = 0;
   };
+  auto park = [&]() {
+    park_a();
+    park_b();
+  };
   const unsigned piece0 = (unsigned)wave * 8192u;  // this wave's first piece inside an operand stage
+  bool dma_on = true;
   auto issue = [&](int p, int slot) {              // piece p (0..15) of this wave into half-slot `slot`
-    glds16(srcp[p], smem, (unsigned)slot * kXHalf + piece0 + (unsigned)(p & 7) * 1024u);
-    srcp[p] += (p < 8) ? kinc_a : kinc_b;
+    if ((DBG & 1) && !dma_on) return;
+    if (FEED == 0) {
+      glds16(srcp[p], smem, (unsigned)slot * kXHalf + piece0 + (unsigned)(p & 7) * 1024u);
+      srcp[p] += (p < 8) ? kinc_a : kinc_b;
+    } else {
+      const unsigned dst = (unsigned)slot * kXHalf + piece0 + (unsigned)((p & 7) >> 2) * 4096u;  // + immediate
+      const char* base = (p < 8) ? base_a : base_b;
+      switch (p & 3) {
+        case 0: glds16_buf<0>(base, voff[p], smem, dst); break;
+        case 1: glds16_buf<1024>(base, voff[p], smem, dst); break;
+        case 2: glds16_buf<2048>(base, voff[p], smem, dst); break;
+        default: glds16_buf<3072>(base, voff[p], smem, dst); break;
+      }
+      if (p == 7) base_a += kinc_a;   // every piece of the operand stage is out: step to the next stage
+      if (p == 15) base_b += kinc_b;
+    }
   };
   // fragment offsets inside a half-slot.  row-major: one per k-step (row (wm|wn)*128 + t*32 + l31: t is the
   // immediate t*4096); k-major: one per 32-column block t (k-step ks is the immediate ks*8192)
@@ -428,6 +471,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   };
   // fragment read number q (0..7) of k-step ks of stage slots (sa, sb) into buffer buf: w0 x0 w1 x1 ...
   auto rd1 = [&](int sa, int sb, int ks, int buf, int q) {
+    if ((DBG & 2) && !dma_on) return;
     const int i = q >> 1;
     if (q & 1)
       fx[buf][i] = frag_a(sa, ks, i);
@@ -439,12 +483,13 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   for (int j = 0; j < 2; ++j) {
     if (j == nst) park();
 #pragma unroll
-    for (int p = 0; p < 16; ++p) issue(p, 2 * j + (p >> 3));
+    for (int p = 0; p < (SCHED == 1 && j == 1 ? 12 : 16); ++p) issue(p, 2 * j + (p >> 3));
   }
   wait_vmcnt<0>();
   raw_barrier();
 #pragma unroll
   for (int q = 0; q < 8; ++q) rd1(0, 1, 0, 0, q);
+  dma_on = false;
   for (int s0 = 0; s0 < nst; s0 += kXSlots) {
 #pragma unroll
     for (int u = 0; u < kXSlots; ++u) {
@@ -454,10 +499,12 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
         const int sa1 = (2 * u + 2) % kXSlots, sb1 = (2 * u + 3) % kXSlots;            // A_{s+1}, B_{s+1}
         const int sa2 = (2 * u + 4) % kXSlots;                                         // A_{s+2} (= slot of B_{s-1})
         const int sb2 = sa;                                                            // B_{s+2} (= slot of A_s)
-        if (s + 2 == nst) park();
         // The 8 fragment reads of a k-step go into its first six gaps (2 2 1 1 1 1) so the last one has more than
         // an LDS latency to land before the next k-step's first MFMA; LDS-DMA pieces fill gaps 2..5.
-        // k-step 0 | fragments of k-step 1, A_{s+2} pieces 0..3
+        // SCHED 0: k-steps 0,1 carry A_{s+2} (4 pieces each), k-step 3 all 8 pieces of B_{s+2}.
+        // SCHED 1: 4 pieces in every k-step: B_{s+1}[4:8] | A_{s+2}[0:4] | A_{s+2}[4:8] | B_{s+2}[0:4].
+        if (SCHED == 0 && s + 2 == nst) park();
+        // k-step 0 | fragments of k-step 1
         sched_fence();
         kstep_open();
 #pragma unroll
@@ -465,17 +512,30 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
           mfma_pair(0, p);
           sched_fence();
           if (p < 2) rd1(sa, sb, 1, 1, 2 * p), rd1(sa, sb, 1, 1, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa, sb, 1, 1, p + 2), issue(p - 2, sa2);
+          if (p >= 2 && p < 6) {
+            rd1(sa, sb, 1, 1, p + 2);
+            if (SCHED == 0)
+              issue(p - 2, sa2);
+            else
+              issue(12 + p - 2, sb1);
+          }
           sched_fence();
         }
-        // k-step 1 | fragments of k-step 2, A_{s+2} pieces 4..7
+        if (SCHED == 1 && s + 2 == nst) park();
+        // k-step 1 | fragments of k-step 2
         kstep_open();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           mfma_pair(1, p);
           sched_fence();
           if (p < 2) rd1(sa, sb, 2, 0, 2 * p), rd1(sa, sb, 2, 0, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa, sb, 2, 0, p + 2), issue(4 + p - 2, sa2);
+          if (p >= 2 && p < 6) {
+            rd1(sa, sb, 2, 0, p + 2);
+            if (SCHED == 0)
+              issue(4 + p - 2, sa2);
+            else
+              issue(p - 2, sa2);
+          }
           sched_fence();
         }
         // k-step 2 | fragments of k-step 3: the last reads of stage s
@@ -485,15 +545,18 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
           mfma_pair(0, p);
           sched_fence();
           if (p < 2) rd1(sa, sb, 3, 1, 2 * p), rd1(sa, sb, 3, 1, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa, sb, 3, 1, p + 2);
+          if (p >= 2 && p < 6) {
+            rd1(sa, sb, 3, 1, p + 2);
+            if (SCHED == 1) issue(4 + p - 2, sa2);
+          }
           sched_fence();
         }
         // hand-off: stage s+1 has landed for everybody; everybody's reads of stage s are in registers
-        wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 pieces of A_{s+2} stay in flight
+        if (!(DBG & 4)) wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 newest (A_{s+2}) stay in flight
         wait_lgkmcnt0();
-        raw_barrier();
+        if (!(DBG & 8)) raw_barrier();
         sched_fence();
-        // k-step 3 | fragments of k-step 0 of stage s+1, B_{s+2} pieces 0..7 into the slot A_s vacated
+        // k-step 3 | fragments of k-step 0 of stage s+1, B_{s+2} pieces into the slot A_s vacated
         kstep_open();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -501,7 +564,8 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
           sched_fence();
           if (p < 2) rd1(sa1, sb1, 0, 0, 2 * p), rd1(sa1, sb1, 0, 0, 2 * p + 1);
           if (p >= 2 && p < 6) rd1(sa1, sb1, 0, 0, p + 2);
-          issue(8 + p, sb2);
+          if (SCHED == 0) issue(8 + p, sb2);
+          if (SCHED == 1 && p >= 2 && p < 6) issue(8 + p - 2, sb2);
           sched_fence();
         }
       }
@@ -554,6 +618,24 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
 template <typename T, bool A_KM, bool B_KN>
 static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
+  static const int dbg = [] {
+    const char* e = getenv("TAMD_GEMM_DBG");
+    return e ? atoi(e) : 0;
+  }();
+  if (dbg && epilogue == TAMD_EPI_NONE && !A_KM && !B_KN) {
+#define TAMD_GD(N_)                                                                                             \
+  hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, N_>), grid, block, (size_t)kXSmem, \
+                     s, g);                                                                                     \
+  return launch_status();
+    switch (dbg) {
+      case 1: TAMD_GD(1)
+      case 2: TAMD_GD(2)
+      case 12: TAMD_GD(12)
+      case 15: TAMD_GD(15)
+      default: break;
+    }
+#undef TAMD_GD
+  }
 #define TAMD_G(E_, A_)                                                                              \
   hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, E_, A_>), grid, block, (size_t)kXSmem, s, g); \
   return launch_status();

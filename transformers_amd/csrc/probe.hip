@@ -51,6 +51,36 @@ __global__ void probe_kernel(const unsigned int* __restrict__ in, const unsigned
       const u32x4 v = lds_read16(smem, (unsigned)i * 16u);
       st16(out + i * 4, v);
     }
+  } else if (which == 5) {  // 4-byte direct-to-LDS load: wave-uniform base + lane*4
+    for (int i = lane; i < 256; i += 64) lds_write16(smem, (unsigned)i * 16u, u32x4{0xdeadbeefu, 1, 2, 3});
+    block_sync();
+    glds4(reinterpret_cast<const char*>(in) + (in2[lane] & ~3u), smem, 512u);
+    wait_vmcnt0();
+    block_sync();
+    for (int i = lane; i < 256; i += 64) st16(out + i * 4, lds_read16(smem, (unsigned)i * 16u));
+  } else if (which == 6) {  // buffer-addressed direct-to-LDS loads with immediates; reads through the asm wrappers
+    for (int i = lane; i < 512; i += 64) lds_write16(smem, (unsigned)i * 16u, u32x4{0xdeadbeefu, 4, 5, 6});
+    block_sync();
+    const char* base = reinterpret_cast<const char*>(in);
+    glds16_buf<0>(base, in2[lane], smem, 1024u);
+    glds16_buf<1024>(base, in2[lane], smem, 1024u);
+    glds16_buf<3072>(base + 2048, in2[lane], smem, 2048u);
+    wait_vmcnt0();
+    block_sync();
+    const unsigned lds0 = lds_base_u32(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const u32x4 v = lds_read16_abs(lds0 + (unsigned)lane * 16u, j * 1024);
+      wait_lgkmcnt0();  // untracked read: the compiler does not wait for it
+      st16(out + (j * 64 + lane) * 4, v);
+    }
+    const u32x2 t = lds_read8_tr16_abs(lds0 + ((in2[lane] >> 1) & 0x7f8u), 1024);
+    const u32x2 t2 = lds_read8_tr16_untracked(smem, (in2[lane] >> 1) & 0x7f8u, 2048);
+    wait_lgkmcnt0();
+    out[2048 + lane * 2] = t[0];
+    out[2048 + lane * 2 + 1] = t[1];
+    out[2304 + lane * 2] = t2[0];
+    out[2304 + lane * 2 + 1] = t2[1];
   }
 }
 

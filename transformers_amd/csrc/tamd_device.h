@@ -166,6 +166,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* smem, unsigned wa
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)(smem + wave_base_off), 16, 0, AUX);
 }
+// Buffer-addressed LDS-DMA (buffer_load_dwordx4 ... offen lds): wave-uniform `base` (SGPR resource), per-lane 32-bit
+// byte offset `voff`, and an instruction immediate IMM (< 4096) that the hardware adds to BOTH addresses:
+//     global source = base + voff + IMM          LDS destination = smem + lds_base_off + IMM + lane*16
+// so one M0 value serves several pieces (IMM = 0, 1024, 2048, 3072) and no per-lane 64-bit pointer has to be kept
+// or advanced: the stage-to-stage step goes into `base`.  (tests/test_gpu_probe.py checks this against silicon.)
+template <int IMM>
+__device__ __forceinline__ void glds16_buf(const void* base, unsigned voff, char* smem, unsigned lds_base_off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_base_off), 16,
+                                           (int)voff, 0, IMM, 0);
+}
 // 4-byte variant (global_load_lds_dword): the wave writes 64 x 4 B = 256 B contiguous at smem + wave_base_off
 __device__ __forceinline__ void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
