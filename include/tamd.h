@@ -262,6 +262,19 @@ struct tamd_attn_bwd_params {
 };
 int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream);
 
+/* ------------------------------------------------------------------ optimizer */
+
+/* One torch.optim.AdamW step on one tensor (the optimizer Trainer builds by default, trainer.py:1783-1799; update rule
+ * torch/optim/adam.py `_single_tensor_adam`, decoupled weight decay), fused-kernel semantics: fp32 arithmetic, each
+ * stored tensor rounded once.
+ *   p *= 1 - lr*wd;  m += (1-b1)*(g*grad_scale - m);  v = b2*v + (1-b2)*(g*grad_scale)^2;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)          step >= 1 is the NEW step count.
+ * p, g in `dtype`; m, v in `state_dtype` (= dtype, or TAMD_F32 master-precision moments).  n % 8 == 0 for 16-bit
+ * dtype with 16-bit states, n % 4 == 0 otherwise; 16-byte aligned pointers. */
+int tamd_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, int64_t step, double grad_scale, int dtype, int state_dtype,
+                    tamd_stream_t stream);
+
 /* ------------------------------------------------------------------ diagnostics */
 
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,

@@ -184,6 +184,22 @@ def main():
     merged = emb.masked_scatter(mask, feats)  # models/llava/modeling_llava.py:244-248
     save("llava_merge", ids=ids.numpy(), embeds=f32(emb), feats=f32(feats), merged=f32(merged))
 
+    # ---- 12. torch.optim.AdamW (what Trainer builds by default, trainer.py:1783-1799): 3 steps, fp32, single-tensor
+    torch.manual_seed(12)
+    p0 = torch.randn(64, 48)
+    w = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([w], lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, foreach=False, fused=False)
+    grads, params = [], []
+    for _ in range(3):
+        gr = torch.randn(64, 48) * 0.5
+        w.grad = gr.clone()
+        opt.step()
+        grads.append(f32(gr))
+        params.append(f32(w.data.clone()))
+    st = opt.state[w]
+    save("adamw_f32", p0=f32(p0), grads=np.stack(grads), params=np.stack(params), exp_avg=f32(st["exp_avg"]),
+         exp_avg_sq=f32(st["exp_avg_sq"]), hyper=np.array([3e-3, 0.9, 0.95, 1e-8, 0.1], dtype=np.float64))
+
 
 if __name__ == "__main__":
     sys.exit(main())

@@ -201,3 +201,31 @@ def test_gpt2_golden_cpu_plumbing():
     with torch.no_grad():
         lg = m(torch.from_numpy(g["ids"])).logits
     assert np.allclose(lg.numpy(), g["logits"], atol=1e-5)
+
+
+def test_oracle_adamw_golden():
+    """torch.optim.AdamW (single-tensor, fp32) for three steps vs the oracle's restatement of the update rule."""
+    g = load("adamw_f32")
+    lr, b1, b2, eps, wd = (float(x) for x in g["hyper"])
+    p, m, v = g["p0"], np.zeros_like(g["p0"]), np.zeros_like(g["p0"])
+    for t in range(3):
+        p, m, v = orc.adamw_step(p, g["grads"][t], m, v, lr, b1, b2, eps, wd, t + 1)
+        assert nrel(p, g["params"][t]) < 5e-7, t
+    assert nrel(m, g["exp_avg"]) < 5e-7 and nrel(v, g["exp_avg_sq"]) < 5e-7  # a few fp32 ulps (lerp form)
+
+
+def test_kernel_adamw_golden(env):
+    """The fused AdamW kernel against the same golden run (fp32 storage: no rounding beyond fp32 arithmetic)."""
+    import transformers_amd
+
+    g = load("adamw_f32")
+    lr, b1, b2, eps, wd = (float(x) for x in g["hyper"])
+    w = torch.nn.Parameter(torch.from_numpy(g["p0"]).to(env.device))
+    opt = transformers_amd.TamdAdamW([w], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    for t in range(3):
+        w.grad = torch.from_numpy(g["grads"][t]).to(env.device)
+        opt.step()
+        assert nrel(w.detach().cpu().numpy(), g["params"][t]) < 5e-7, t
+    st = opt.state[w]
+    assert nrel(st["exp_avg"].cpu().numpy(), g["exp_avg"]) < 5e-7
+    assert nrel(st["exp_avg_sq"].cpu().numpy(), g["exp_avg_sq"]) < 5e-7

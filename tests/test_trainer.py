@@ -52,6 +52,28 @@ def test_trainer_runs_unchanged_on_accelerated_model(tmp_path):
     assert torch.equal(att._fused().weight()[: att.q_proj.weight.shape[0]], att.q_proj.weight)
 
 
+@pytest.mark.timeout(600)
+def test_trainer_with_fused_adamw(tmp_path):
+    """`Trainer(optimizers=(TamdAdamW(...), None))`: the reference loop drives our fused optimizer step (section 8 f2);
+    the fused QKV / gate|up buffers are updated through the per-parameter views."""
+    from emu_backend import emu_backend
+
+    with emu_backend():
+        model = transformers_amd.accelerate(_model())
+        before = copy.deepcopy(model.state_dict())
+        opt = transformers_amd.TamdAdamW(model.parameters(), lr=1e-2, weight_decay=0.01)
+        args = TrainingArguments(output_dir=str(tmp_path), max_steps=2, per_device_train_batch_size=4,
+                                 report_to=[], use_cpu=True, bf16=False, save_strategy="no", logging_steps=1,
+                                 dataloader_pin_memory=False, disable_tqdm=True, lr_scheduler_type="constant")
+        out = Trainer(model=model, args=args, train_dataset=Toy(256), optimizers=(opt, None)).train()
+    assert out.global_step == 2 and torch.isfinite(torch.tensor(out.training_loss))
+    changed = [k for k, v in model.state_dict().items() if not torch.equal(v, before[k])]
+    assert len(changed) >= len(before) - 2
+    att = model.model.layers[0].self_attn
+    assert att._fused()._coherent()
+    assert all(s["exp_avg"].dtype == torch.bfloat16 for s in opt.state.values())
+
+
 def test_gradient_checkpointing_recomputes_through_fused_layer():
     from emu_backend import emu_backend
 

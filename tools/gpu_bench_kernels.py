@@ -112,6 +112,20 @@ def bench_hbm():
     gs = torch.ones(1, device=dev)
     t = timeit(lambda: ops.raw_cross_entropy_bwd(logits, labels, lse, gs), iters=5)
     emit(kernel="cross_entropy_bwd", ms=t * 1e3, gbps=2 * logits.numel() * 2 / t / 1e9)
+    n = 1 << 29  # one 1 GiB bf16 tensor (the 8B model is 16 of these)
+    pw = torch.randn(n, device=dev).bfloat16()
+    pg = torch.randn(n, device=dev).bfloat16()
+    pm = torch.zeros(n, device=dev).bfloat16()
+    pv = torch.zeros(n, device=dev).bfloat16()
+    kw = dict(lr=1e-4, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.1, step=3)
+    t = timeit(lambda: ops.raw_adamw_step_(pw, pg, pm, pv, **kw), iters=5)
+    emit(kernel="adamw_step(bf16 states)", ms=t * 1e3, gbps=7 * n * 2 / t / 1e9)
+    ta = torch.nn.Parameter(pw.clone())
+    ta.grad = pg
+    topt = torch.optim.AdamW([ta], lr=1e-4, betas=(0.9, 0.95), weight_decay=0.1, fused=True)
+    t = timeit(lambda: topt.step(), iters=5)
+    emit(kernel="torch AdamW(fused=True), same tensor", ms=t * 1e3, gbps=7 * n * 2 / t / 1e9)
+    del pw, pg, pm, pv, ta, topt
     t = timeit(lambda: x.clone())
     emit(kernel="torch_clone(ref copy)", ms=t * 1e3, gbps=2 * x.numel() * 2 / t / 1e9)
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     "tamd_bias_act_fwd": (c_int, [P, P, P, I64, I64, c_int, c_int, P]),
     "tamd_bias_act_bwd": (c_int, [P, P, P, P, I64, I64, c_int, c_int, P]),
     "tamd_add": (c_int, [P, P, P, I64, c_int, P]),
+    "tamd_adamw_step": (c_int, [P, P, P, P, I64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                ctypes.c_double, I64, ctypes.c_double, c_int, c_int, P]),
     "tamd_colsum_workspace_bytes": (c_size_t, [I64, I64]),
     "tamd_colsum": (c_int, [P, P, P, c_size_t, I64, I64, I64, c_int, P]),
     "tamd_transpose": (c_int, [P, P, I64, I64, I64, I64, c_int, P]),

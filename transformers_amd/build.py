@@ -19,7 +19,7 @@ CSRC = HERE / "csrc"
 INCLUDE = HERE.parent / "include"
 LIB = HERE / "libtamd.so"
 OBJ_DIR = HERE / "_build"
-SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "probe.hip"]
+SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip", "probe.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wno-unused-result", "-I", str(CSRC), "-I", str(INCLUDE)] + os.environ.get("TAMD_EXTRA_HIPCC_FLAGS", "").split()

@@ -278,6 +278,19 @@ def raw_add(a, b):
     return out
 
 
+def raw_adamw_step_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """In-place fused AdamW step on one tensor (p, m, v updated); torch.optim.AdamW semantics, include/tamd.h."""
+    be = _prep(p, g, m, v)
+    for t in (p, g, m, v):
+        if not t.is_contiguous():
+            raise TamdError("adamw_step needs contiguous tensors (parameters, gradients and moments)")
+    if g.dtype != p.dtype or m.dtype != v.dtype or m.dtype not in (p.dtype, torch.float32):
+        raise TamdError(f"adamw_step dtypes: p/g {p.dtype}/{g.dtype}, m/v {m.dtype}/{v.dtype}")
+    be.lib.check(be.lib.tamd_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2),
+                                        float(eps), float(weight_decay), int(step), float(grad_scale), _code(p),
+                                        _code(m), be.stream(p)), "tamd_adamw_step")
+
+
 def raw_colsum(x2d):
     be = _prep(x2d)
     rows, cols = x2d.shape
