@@ -16,11 +16,12 @@ import oracle as orc  # noqa: E402
 HYP = dict(lr=2e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)
 
 
-def _bf16_ulp_close(a, b, frac=0.01):
-    """a, b bf16 tensors: equal except for at most `frac` of the elements, and those by one bf16 ulp."""
+def _bf16_ulp_close(a, b, frac=0.01, atol=0.0):
+    """a, b bf16 tensors: equal except for at most `frac` of the elements, and those by one bf16 ulp (+ `atol`: near a
+    zero crossing of p the ulp of p says nothing about the rounding of the update that was subtracted)."""
     a, b = a.float().cpu(), b.float().cpu()
     diff = (a - b).abs()
-    ulp = torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-30
+    ulp = torch.maximum(a.abs(), b.abs()) * 2.0 ** -7 + 1e-30 + atol
     assert (diff <= ulp).all(), (diff / ulp).max().item()
     assert (diff > 0).float().mean().item() <= frac
 
@@ -101,4 +102,6 @@ def test_adamw_bf16_vs_torch_fused_on_gpu():
         a.grad, b.grad = g.clone(), g.clone()
         ours.step()
         ref.step()
-    _bf16_ulp_close(a.detach(), b.detach(), frac=0.02)
+    # torch's fused kernel applies the decay as p - lr*wd*p and keeps its own operation order: differences are one
+    # rounding of the update term (lr * O(1) * 2^-8 ~ 1e-5) or one bf16 ulp of p
+    _bf16_ulp_close(a.detach(), b.detach(), frac=0.05, atol=2e-5)

@@ -323,11 +323,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     auto mfma_valu_interleave = [&]() {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // DS read (lse / delta rows)
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);  // VALU
-        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);                  // TRANS (v_exp)
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x402, 14, 0);  // VALU or TRANS, in the scheduler's own order (a fixed
+                                                             // exp slot put every v_exp next to its consumer: 46
+                                                             // trans-use hazard NOPs per tile)
       }
     };
     // ---- phases A0, A1: S and dP of the two 32-row sub-tiles; A1 carries the softmax backward of sub-tile 0
