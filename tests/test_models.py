@@ -122,6 +122,58 @@ def test_state_dict_keys_and_fused_views_roundtrip(env):
     assert type(fast.model.layers[0]).__name__ == "LlamaDecoderLayer"
 
 
+def _load_tamd(path, env):
+    from transformers import AutoModelForCausalLM
+
+    m = AutoModelForCausalLM.from_pretrained(path, dtype=torch.bfloat16, attn_implementation="tamd").to(env.device)
+    if not env.big:  # CPU model: safetensors hands out memory-mapped (unaligned) storage; a GPU copy is always aligned
+        for prm in m.parameters():
+            prm.data = prm.data.clone()
+    return transformers_amd.accelerate(m).eval()
+
+
+def test_save_pretrained_from_pretrained_roundtrip(env, tmp_path):
+    """checkpoints written from an accelerated model (parameters are views of fused QKV /
+    gate|up buffers) are ordinary per-parameter safetensors that the reference loads back, and a model loaded with
+    `from_pretrained(..., attn_implementation="tamd")` and accelerated gives bit-identical logits."""
+    torch.manual_seed(6)
+    cfg = tiny_llama(False)
+    LlamaForCausalLM(cfg).bfloat16().save_pretrained(tmp_path / "a")  # a reference checkpoint
+    fast = _load_tamd(tmp_path / "a", env)
+    assert fast.config._attn_implementation == "tamd"
+    ids = torch.randint(0, cfg.vocab_size, (2, 48)).to(env.device)
+    with torch.no_grad():
+        want = fast(input_ids=ids, use_cache=False).logits
+    fast.save_pretrained(tmp_path / "b")  # after a forward: the fused buffers exist and own the storage
+    back = _load_tamd(tmp_path / "b", env)
+    for (k, x), (_, y) in zip(fast.state_dict().items(), back.state_dict().items()):
+        assert torch.equal(x.cpu(), y.cpu()), k
+    with torch.no_grad():
+        got = back(input_ids=ids, use_cache=False).logits
+    assert torch.equal(got, want)
+
+
+def test_idle_output_recorder_hooks_do_not_disable_the_fused_layer(env):
+    """The reference leaves its output-capturing hooks on the attention modules after the first call that asks for
+    hidden states (utils/output_capturing.py:100-119); they are idle afterwards and must not push every later call
+    onto the module-by-module path.  A user hook still does."""
+    cfg = tiny_llama(False)
+    m = transformers_amd.accelerate(LlamaForCausalLM(cfg).bfloat16().to(env.device)).eval()
+    ids = torch.randint(0, cfg.vocab_size, (1, 32)).to(env.device)
+    probe = torch.zeros(1, 1, cfg.hidden_size, dtype=torch.bfloat16, device=env.device)
+    layer = m.model.layers[0]
+    with torch.no_grad():
+        plain = m(input_ids=ids, use_cache=False).logits
+        hs = m(input_ids=ids, use_cache=False, output_hidden_states=True)
+        assert len(hs.hidden_states) == cfg.num_hidden_layers + 1
+        assert len(layer.self_attn._forward_hooks) >= 1          # the recorder stayed behind ...
+        assert layer._fused_ok(probe, None)                      # ... and is recognised as idle
+        assert torch.equal(m(input_ids=ids, use_cache=False).logits, plain)
+        h = layer.mlp.register_forward_hook(lambda *_: None)
+        assert not layer._fused_ok(probe, None)
+        h.remove()
+
+
 def test_gpt2_cpu_path_untouched():
     """BASELINE config 1: gpt2 eager forward on CPU through AutoModelForCausalLM must run unchanged with the
     package imported (and even after accelerate(): CPU tensors take the reference forward)."""

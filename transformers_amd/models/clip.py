@@ -10,7 +10,7 @@ from transformers.models.clip import modeling_clip as ref
 
 from .. import ops
 from ..fused_params import FusedWeights
-from .common import _gpu
+from .common import _gpu, _has_hooks
 
 
 class TamdCLIPAttention(ref.CLIPAttention):
@@ -68,7 +68,7 @@ class TamdCLIPEncoderLayer(ref.CLIPEncoderLayer):
                 and x.dtype in (torch.bfloat16, torch.float16) and attn.head_dim in (64, 128)
                 and attn.config._attn_implementation == "tamd" and not (self.training and attn.dropout > 0)
                 and isinstance(act, str) and ops.ACT_CODES.get(act, 0) != ops.ACT_NONE
-                and not (attn._forward_hooks or mlp._forward_hooks or kwargs.get("output_attentions", False))):
+                and not (_has_hooks(attn, mlp) or kwargs.get("output_attentions", False))):
             return super().forward(hidden_states, attention_mask, **kwargs)
         b, s, h = x.shape
         nh, d = attn.num_heads, attn.head_dim

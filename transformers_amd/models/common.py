@@ -44,3 +44,28 @@ class TamdLayerNorm(nn.LayerNorm):
 
 
 REPLACEMENTS = {nn.Linear: TamdLinear, nn.Embedding: TamdEmbedding, nn.LayerNorm: TamdLayerNorm}
+
+
+def _capture_hook_is_idle(fn) -> bool:
+    """The reference's output recorders (utils/output_capturing.py:100-119) stay installed on attention modules after
+    the first call that asked for hidden states / attentions, and do nothing unless the active collector wants their
+    key.  Such a hook must not disable the fused layer for every later call."""
+    if getattr(fn, "__name__", "") != "output_capturing_hook" or "output_capturing" not in getattr(fn, "__module__", ""):
+        return False
+    try:
+        from transformers.utils.output_capturing import _active_collector
+
+        wanted = _active_collector.get()
+        key = dict(zip(fn.__code__.co_freevars, (c.cell_contents for c in fn.__closure__))).get("key")
+    except Exception:  # reference internals moved: be conservative
+        return False
+    return wanted is None or key not in wanted.keys()
+
+
+def _has_hooks(*mods: nn.Module) -> bool:
+    for m in mods:
+        if m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+            return True
+        if any(not _capture_hook_is_idle(fn) for fn in m._forward_hooks.values()):
+            return True
+    return False

@@ -22,12 +22,11 @@ from ..fused_params import FusedWeights
 from ..ops import EPI_RESIDUAL
 
 
+from .common import _has_hooks  # noqa: E402
+
+
 def _on_gpu(t: torch.Tensor) -> bool:
     return t.is_cuda or ops.backend_is_emulated()
-
-
-def _has_hooks(*mods: nn.Module) -> bool:
-    return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks for m in mods)
 
 
 class TamdLlamaRMSNorm(ref.LlamaRMSNorm):
