@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 2
+#define TAMD_ABI_VERSION 3
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -247,6 +247,11 @@ struct tamd_attn_params {
    * and scaled by 1/(1-p); the same counter-based mask is regenerated in the backward.  0 disables. */
   float dropout_p;
   uint64_t dropout_seed;
+  /* packed sequences (several sequences in one batch row, position_ids restarting: masking_utils.py:728-757,
+   * packed_sequence_mask_function :182-188): q_start[b, q] = key index of the first token of query q's sequence;
+   * key k is visible to query q iff q_start[b,q] <= k <= q (+ seq_k - seq_q).  [batch, seq_q] int32 or NULL;
+   * requires causal = 1. */
+  const int32_t* q_start;
 };
 int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream);
 

@@ -278,6 +278,54 @@ def test_training_with_default_dropout_runs_on_kernels(env):
     assert all(torch.isfinite(g).all() for g in g1)
 
 
+def test_packed_sequences_match_reference_and_separate_runs(env):
+    """Padding-free batches (position_ids restarting inside a row, no attention_mask): the reference turns them into a
+    block-diagonal causal mask (masking_utils.py:728-757, 973-974); `tamd_mask` turns the same information into
+    q_start for the kernels.  Checked against the reference's fp32 eager run and against running each sequence alone;
+    other mask overlays are refused, not ignored."""
+    torch.manual_seed(14)
+    cfg = tiny_llama(env.big)
+    ref = LlamaForCausalLM(cfg).bfloat16().train()
+    ref32 = copy.deepcopy(ref).float()
+    fast = transformers_amd.accelerate(copy.deepcopy(ref).to(env.device))
+    lens = [300, 77, 135] if env.big else [40, 9, 31]
+    s = sum(lens)
+    ids = torch.randint(0, cfg.vocab_size, (1, s))
+    pos = torch.cat([torch.arange(n) for n in lens])[None]
+    labels = ids.clone()
+    dev = env.device
+    o32 = ref32(input_ids=ids, position_ids=pos, labels=labels, use_cache=False)
+    o32.loss.backward()
+    oref = ref(input_ids=ids, position_ids=pos, labels=labels, use_cache=False)
+    o = fast(input_ids=ids.to(dev), position_ids=pos.to(dev), labels=labels.to(dev), use_cache=False)
+    o.loss.backward()
+    e_fast, e_ref = rel_err(o.logits, o32.logits), rel_err(oref.logits, o32.logits)
+    assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
+    g32 = dict(ref32.named_parameters())
+    for n, p in fast.named_parameters():
+        if "layers.0.self_attn.k_proj" in n or "layers.1.mlp.down_proj" in n:
+            assert rel_err(p.grad, g32[n].grad) < 3e-2, n
+    # every sequence alone (its own forward, positions from 0) reproduces its slice of the packed logits
+    fast.eval()
+    st = 0
+    with torch.no_grad():
+        packed = fast(input_ids=ids.to(dev), position_ids=pos.to(dev), use_cache=False).logits
+        for n in lens:
+            alone = fast(input_ids=ids[:, st:st + n].to(dev), use_cache=False).logits
+            assert rel_err(packed[:, st:st + n], alone) < 1e-2
+            st += n
+        # without position_ids the same tokens are ONE sequence: different logits after the first boundary
+        single = fast(input_ids=ids.to(dev), use_cache=False).logits
+        assert rel_err(single[:, lens[0]:], packed[:, lens[0]:]) > 5e-2
+    # an overlay the kernels do not implement is refused loudly
+    from transformers.masking_utils import and_masks, causal_mask_function, sliding_window_overlay
+    from transformers_amd.attention import tamd_mask
+    from transformers_amd.ops import TamdError
+
+    with pytest.raises(TamdError):
+        tamd_mask(1, 8, 8, mask_function=and_masks(causal_mask_function, sliding_window_overlay(4)))
+
+
 def test_clip_vision_tower_hidden_states(env):
     """LLaVA's use of CLIP (models/llava/modeling_llava.py:154-166): output_hidden_states -> hidden_states[-2]."""
     from transformers import CLIPVisionConfig, CLIPVisionModel

@@ -14,7 +14,7 @@ TAMD_BF16, TAMD_F16, TAMD_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 GEMM_A_KM, GEMM_B_KN = 1, 2
 EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_BIAS_ACT, EPI_ACCUM = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 P = c_void_p
 I64 = c_int64
@@ -29,7 +29,7 @@ class AttnParams(Structure):
         ("v_stride_b", I64), ("v_stride_s", I64), ("v_stride_h", I64),
         ("o_stride_b", I64), ("o_stride_s", I64), ("o_stride_h", I64),
         ("scale", c_float), ("causal", c_int), ("dtype", c_int),
-        ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint64),
+        ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint64), ("q_start", P),
     ]
 
 

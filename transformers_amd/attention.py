@@ -21,16 +21,75 @@ from ._cabi import TamdError
 ATTN_KEY = "tamd"
 
 
+class TamdMask:
+    """What `tamd_mask` hands to the attention function when the mask is more than padding: the 2-D key-validity mask
+    (or None) plus, for packed sequences, `q_start` (int32 [B, S], first visible key of every query).  The decoder
+    layers pass it along untouched as `attention_mask`."""
+
+    __slots__ = ("key_valid", "q_start")
+
+    def __init__(self, key_valid, q_start):
+        self.key_valid, self.q_start = key_valid, q_start
+
+
+def _closure_vars(fn):
+    cells = getattr(fn, "__closure__", None) or ()
+    return dict(zip(fn.__code__.co_freevars, (c.cell_contents for c in cells))) if cells else {}
+
+
+def _decompose_mask_function(fn):
+    """Leaves of an `and_masks(...)` tree (masking_utils.py:48-59)."""
+    inner = _closure_vars(fn).get("mask_functions") if getattr(fn, "__name__", "") == "and_mask" else None
+    if inner is None:
+        return [fn]
+    out = []
+    for f in inner:
+        out.extend(_decompose_mask_function(f))
+    return out
+
+
 def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_function=None, attention_mask=None,
               **kwargs):
-    """Mask factory for AttentionMaskInterface: the kernel takes a [B, kv_len] key-validity mask (or None).
+    """Mask factory for AttentionMaskInterface: the kernels take a [B, kv_len] key-validity mask (or None) and, for
+    packed sequences, the first visible key of every query.
 
-    Same contract as `flash_attention_mask` (masking_utils.py:607-647) minus its host-side `.all()` sync:
-    causality is a kernel flag, padding is the 2-D mask itself.
-    """
+    Same contract as `flash_attention_mask` (masking_utils.py:607-647) minus its host-side `.all()` sync: causality
+    is a kernel flag, padding is the 2-D mask itself.  The reference describes everything else through
+    `mask_function`: plain causal / bidirectional are the kernel flag; `and_masks(causal, packed_sequence_mask)`
+    (masking_utils.py:973-974, position_ids restarting inside a row) becomes `q_start`; any other mask function
+    (sliding window, chunked, user overlays) is refused instead of being silently ignored."""
+    from transformers import masking_utils as mu
+
+    padding = None if attention_mask is None else attention_mask[:, -kv_length:]
+    plain = (None, mu.causal_mask_function, getattr(mu, "bidirectional_mask_function", None))
+    if mask_function in plain:
+        return padding
+    packed_ids = None
+    for leaf in _decompose_mask_function(mask_function):
+        if leaf in plain:
+            continue
+        ids = _closure_vars(leaf).get("packed_sequence_mask") if getattr(leaf, "__name__", "") == "inner_mask" else None
+        if torch.is_tensor(ids) and packed_ids is None:
+            packed_ids = ids
+            continue
+        raise TamdError("attn_implementation='tamd' supports causal / bidirectional masks, 2-D padding and packed "
+                        f"sequences; the mask function {getattr(leaf, '__qualname__', leaf)!r} is not one of them "
+                        "(sliding-window / chunked / custom overlays need attn_implementation='sdpa' or 'eager')")
+    if packed_ids is None:
+        return padding
+    if q_offset != 0 or kv_offset != 0 or q_length != kv_length:
+        raise TamdError("packed sequences with a KV cache are not supported by attn_implementation='tamd'")
+    return TamdMask(padding, ops.packed_q_start(packed_ids[:, -q_length:]))
+
+
+def split_mask(attention_mask, batch: int, kv_len: int):
+    """(key_valid [B, kv_len] bool or None, q_start int32 [B, S] or None) from whatever reached the attention layer."""
+    if isinstance(attention_mask, TamdMask):
+        kv = None if attention_mask.key_valid is None else _key_valid_from_mask(attention_mask.key_valid, batch, kv_len)
+        return kv, attention_mask.q_start
     if attention_mask is None:
-        return None
-    return attention_mask[:, -kv_length:]
+        return None, None
+    return _key_valid_from_mask(attention_mask, batch, kv_len), None
 
 
 def _key_valid_from_mask(attention_mask: torch.Tensor, batch: int, kv_len: int) -> Optional[torch.Tensor]:
@@ -70,9 +129,7 @@ def tamd_attention_forward(module, query, key, value, attention_mask, dropout: f
         scaling = d ** -0.5
     causal = is_causal if is_causal is not None else getattr(module, "is_causal", True)
     causal = bool(causal) and sq > 1
-    key_valid = None
-    if attention_mask is not None:
-        key_valid = _key_valid_from_mask(attention_mask, b, sk)
+    key_valid, q_start = split_mask(attention_mask, b, sk)
     # [B,H,S,D] -> [B,S,H,D] views (the projections produced [B,S,H,D]; this undoes the caller's transpose)
     q, k, v = query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2)
     if q.stride(3) != 1:
@@ -81,7 +138,7 @@ def tamd_attention_forward(module, query, key, value, attention_mask, dropout: f
         k = k.contiguous()
     if v.stride(3) != 1:
         v = v.contiguous()
-    out = ops.attention(q, k, v, float(scaling), causal, key_valid, dropout_p=drop_p)
+    out = ops.attention(q, k, v, float(scaling), causal, key_valid, dropout_p=drop_p, q_start=q_start)
     return out, None
 
 

@@ -70,6 +70,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   for (int ks = 0; ks < KS; ++ks)
     qf[ks] = (qrow < a.seq_q) ? ld16(Q + (int64_t)qrow * a.qss + ks * 16 + hi * 8) : u32x4{0, 0, 0, 0};
 
+  // packed sequences: this query's first visible key; wave-uniform bounds for tile skipping / mask-free tiles
+  const int klo = packed_klo(a, b, qrow);
+  const int klo_max = (int)wave_max((float)klo), klo_min = -(int)wave_max(-(float)klo);
+
   f32x16 oacc[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
     const unsigned k_off = (unsigned)cur * 2u * TILEB, v_off = k_off + TILEB;
     const int kt0 = t * kKB;
     // wave-uniform skip: every key of the tile is above the diagonal for all 32 rows of this wave
-    const bool wave_active = !CAUSAL || (kt0 <= qw0 + 31 + off);
+    // (packed: ... or below the first visible key of all 32 rows)
+    const bool wave_active = (!CAUSAL || (kt0 <= qw0 + 31 + off)) && (kt0 + kKB > klo_min);
     if (wave_active) {
       // ---- S^T tile [64 keys][32 q] = K . Q^T   (two 32-key sub-tiles)
       f32x16 s[2];
@@ -120,7 +125,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
           s[sub] = mfma32<T>(toff.read_row(smem, k_off, sub, ks), qf[ks], s[sub]);
       }
       // ---- mask (diagonal / ragged / padded tiles only: wave-uniform branch, the common tile has no mask code)
-      const bool need_mask = HAS_MASK || (kt0 + kKB > a.seq_k) || (CAUSAL && (kt0 + kKB - 1 > qw0 + off));
+      const bool need_mask = HAS_MASK || (kt0 + kKB > a.seq_k) || (CAUSAL && (kt0 + kKB - 1 > qw0 + off)) ||
+                             (kt0 < klo_max);
       if (need_mask) {
         unsigned long long vmask = ~0ull;
         if (HAS_MASK) {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
           for (int r = 0; r < 16; ++r) {
             const int kl = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // key index inside the tile
             const int kp = kt0 + kl;
-            bool vis = kp < a.seq_k;
+            bool vis = kp < a.seq_k && kp >= klo;
             if (CAUSAL) vis = vis && (kp <= qrow + off);
             if (HAS_MASK) vis = vis && ((vmask >> kl) & 1ull);
             s[sub][r] = vis ? s[sub][r] : -INFINITY;
@@ -263,6 +269,7 @@ int attn_check(const tamd_attn_params* p) {
   if (p->heads_q % p->heads_kv != 0) return TAMD_E_SHAPE;
   if (p->dtype != TAMD_BF16 && p->dtype != TAMD_F16) return TAMD_E_DTYPE;
   if (!(p->dropout_p >= 0.f && p->dropout_p < 1.f)) return TAMD_E_ARG;
+  if (p->q_start != nullptr && !p->causal) return TAMD_E_ARG;
   const int64_t strides[] = {p->q_stride_b, p->q_stride_s, p->q_stride_h, p->k_stride_b, p->k_stride_s, p->k_stride_h,
                              p->v_stride_b, p->v_stride_s, p->v_stride_h, p->o_stride_b, p->o_stride_s, p->o_stride_h};
   for (int64_t st : strides)
@@ -279,6 +286,7 @@ AttnArgs make_args(const tamd_attn_params* p) {
   a.o = p->o;
   a.lse = p->lse;
   a.key_valid = p->key_valid;
+  a.q_start = p->q_start;
   a.batch = (int)p->batch;
   a.heads_q = (int)p->heads_q;
   a.heads_kv = (int)p->heads_kv;

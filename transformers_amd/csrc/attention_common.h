@@ -21,6 +21,7 @@ struct AttnArgs {
   void* o;
   float* lse;
   const uint8_t* key_valid;
+  const int* q_start;  // packed sequences: first visible key of each query, or null
   int batch, heads_q, heads_kv, seq_q, seq_k;
   int64_t qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh;
   float scale_log2;  // scale * log2(e)
@@ -164,6 +165,11 @@ __device__ __forceinline__ void pack_c_to_b(const float* p, u32x4* out2) {
   for (int st = 0; st < 2; ++st)
     out2[st] = u32x4{pack2<T>(p[8 * st + 0], p[8 * st + 1]), pack2<T>(p[8 * st + 2], p[8 * st + 3]),
                      pack2<T>(p[8 * st + 4], p[8 * st + 5]), pack2<T>(p[8 * st + 6], p[8 * st + 7])};
+}
+
+// first visible key of query row `qrow` (0 when sequences are not packed) and its wave-wide max / min
+__device__ __forceinline__ int packed_klo(const AttnArgs& a, int b, int qrow) {
+  return (a.q_start != nullptr && qrow < a.seq_q) ? a.q_start[(int64_t)b * a.seq_q + qrow] : 0;
 }
 
 constexpr int kKVB = 128;  // keys per workgroup in the dK/dV kernel (32 per wave)

@@ -85,12 +85,10 @@ class TamdLlamaAttention(ref.LlamaAttention):
         q = qkv[..., : hq * d].view(b, s, hq, d)
         k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d)
-        key_valid = None
-        if attention_mask is not None:
-            from ..attention import _key_valid_from_mask
-            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        from ..attention import split_mask
+        key_valid, q_start = split_mask(attention_mask, b, s)
         o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid,
-                          dropout_p=self.attention_dropout if self.training else 0.0)
+                          dropout_p=self.attention_dropout if self.training else 0.0, q_start=q_start)
         out = ops.linear(o.view(b, s, hq * d), self.o_proj.weight)
         return out, None
 
@@ -107,7 +105,8 @@ class LlamaLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, h_in, cos, sin, key_valid, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, meta):
+    def forward(ctx, h_in, cos, sin, key_valid, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, meta,
+                q_start=None):
         eps, hq, hkv, d, scale, causal = meta
         b, s, hd = h_in.shape
         t = b * s
@@ -119,7 +118,7 @@ class LlamaLayerFn(torch.autograd.Function):
         k = qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
         v = qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
         need_grad = any(ctx.needs_input_grad)
-        o, lse = ops.raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need_grad)
+        o, lse = ops.raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need_grad, q_start=q_start)
         h_mid = ops.raw_gemm(o.view(t, hq * d), wo, residual=x, epilogue=EPI_RESIDUAL)
         xn2, _, rstd2 = ops.raw_rmsnorm_fwd(h_mid, w_ln2, eps)
         gu = ops.raw_gemm(xn2, wgu)
@@ -127,7 +126,7 @@ class LlamaLayerFn(torch.autograd.Function):
         h_out = ops.raw_gemm(act, wd, residual=h_mid, epilogue=EPI_RESIDUAL)
         if need_grad:
             ctx.save_for_backward(x, cos, sin, key_valid, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse,
-                                  h_mid, rstd2, xn2, gu)
+                                  h_mid, rstd2, xn2, gu, q_start)
             ctx.meta = meta
             ctx.shape = (b, s, hd)
         return h_out.view(b, s, hd)
@@ -135,7 +134,7 @@ class LlamaLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_hout):
         (x, cos, sin, key_valid, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse, h_mid, rstd2, xn2,
-         gu) = ctx.saved_tensors
+         gu, q_start) = ctx.saved_tensors
         eps, hq, hkv, d, scale, causal = ctx.meta
         b, s, hd = ctx.shape
         t = b * s
@@ -161,7 +160,8 @@ class LlamaLayerFn(torch.autograd.Function):
         dq = d_qkv[:, : hq * d].view(b, s, hq, d)
         dk = d_qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
         dv = d_qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
-        ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, hq, d), scale, causal, key_valid, dq=dq, dk=dk, dv=dv)
+        ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, hq, d), scale, causal, key_valid, dq=dq, dk=dk, dv=dv,
+                         q_start=q_start)
         del d_o
         ops.raw_rope_(d_qkv, cos, sin, s, hq + hkv, d, conj=True)
         d_xn = ops.raw_gemm(d_qkv, wqkv, b_kn=True)
@@ -170,7 +170,7 @@ class LlamaLayerFn(torch.autograd.Function):
         nq, nk = hq * d, hkv * d
         inter = wgu.shape[0] // 2
         return (d_hin.view(b, s, hd), None, None, None, dw_ln1, None, dwqkv[:nq], dwqkv[nq:nq + nk],
-                dwqkv[nq + nk:], dwo, dw_ln2, None, dwgu[:inter], dwgu[inter:], dwd, None)
+                dwqkv[nq + nk:], dwo, dw_ln2, None, dwgu[:inter], dwgu[inter:], dwd, None, None)
 
 
 class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
@@ -194,17 +194,15 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
         attn, mlp = self.self_attn, self.mlp
         b, s, _ = hidden_states.shape
         cos, sin = position_embeddings
-        key_valid = None
-        if attention_mask is not None:
-            from ..attention import _key_valid_from_mask
-            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        from ..attention import split_mask
+        key_valid, q_start = split_mask(attention_mask, b, s)
         qkv, gu = attn._fused(), mlp._fused()
         meta = (float(self.input_layernorm.variance_epsilon), attn.config.num_attention_heads,
                 attn.config.num_key_value_heads, attn.head_dim, float(attn.scaling), bool(attn.is_causal) and s > 1)
         return LlamaLayerFn.apply(hidden_states, cos, sin, key_valid, self.input_layernorm.weight, qkv.weight(),
                                   attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight, attn.o_proj.weight,
                                   self.post_attention_layernorm.weight, gu.weight(), mlp.gate_proj.weight,
-                                  mlp.up_proj.weight, mlp.down_proj.weight, meta)
+                                  mlp.up_proj.weight, mlp.down_proj.weight, meta, q_start)
 
 
 REPLACEMENTS = {

@@ -357,7 +357,7 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
     return out
 
 
-def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=0):
+def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=0, q_start=None):
     """q/k/v/o are [B, S, H, D] *views* (any batch/seq/head strides, D contiguous)."""
     p = _cabi.AttnParams()
     p.q, p.k, p.v, p.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
@@ -376,10 +376,23 @@ def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=
     p.dtype = _code(q)
     p.dropout_p = float(dropout_p)
     p.dropout_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    p.q_start = q_start.data_ptr() if q_start is not None else None
     return p
 
 
-def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None, dropout_p=0.0, seed=0):
+def _check_q_start(q_start, q, causal):
+    """packed sequences: int32 [B, Sq], first visible key of every query (include/tamd.h)."""
+    if q_start is None:
+        return None
+    if not causal:
+        raise TamdError("packed sequences (q_start) need causal attention")
+    if q_start.dtype != torch.int32 or tuple(q_start.shape) != (q.shape[0], q.shape[1]):
+        raise TamdError(f"q_start must be int32 [batch, seq_q], got {q_start.dtype} {tuple(q_start.shape)}")
+    return _c(q_start)
+
+
+def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None, dropout_p=0.0, seed=0,
+                 q_start=None):
     """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32."""
     be = _prep(q, k, v, key_valid, out)
     b, sq, hq, d = q.shape
@@ -387,13 +400,14 @@ def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None
     lse = torch.empty(b, hq, sq, dtype=torch.float32, device=q.device) if need_lse else None
     if key_valid is not None:
         key_valid = _c(key_valid.to(torch.uint8))
-    p = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed)
+    q_start = _check_q_start(q_start, q, causal)
+    p = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start)
     be.lib.check(be.lib.tamd_attn_fwd(ctypes.byref(p), be.stream(q)), "tamd_attn_fwd")
     return o, lse
 
 
 def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, dk=None, dv=None,
-                 dropout_p=0.0, seed=0):
+                 dropout_p=0.0, seed=0, q_start=None):
     """Gradients written into dq/dk/dv (views with the strides of q/k/v) or freshly allocated."""
     be = _prep(q, k, v, o, lse, dout, key_valid)
     if dout.stride() != o.stride():
@@ -409,7 +423,8 @@ def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, 
         key_valid = _c(key_valid.to(torch.uint8))
     delta = torch.empty((2,) + tuple(lse.shape), dtype=torch.float32, device=lse.device)  # delta | lse*log2(e)
     bp = _cabi.AttnBwdParams()
-    bp.fwd = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed)
+    q_start = _check_q_start(q_start, q, causal)
+    bp.fwd = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start)
     bp.dout, bp.dq, bp.dk, bp.dv, bp.delta = (dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                               delta.data_ptr())
     be.lib.check(be.lib.tamd_attn_bwd(ctypes.byref(bp), be.stream(q)), "tamd_attn_bwd")
@@ -582,20 +597,22 @@ class AttentionFn(torch.autograd.Function):
     models/llama/modeling_llama.py:191-213 and siblings."""
 
     @staticmethod
-    def forward(ctx, q, k, v, key_valid, scale, causal, dropout_p=0.0, seed=0):
+    def forward(ctx, q, k, v, key_valid, scale, causal, dropout_p=0.0, seed=0, q_start=None):
         need = any(ctx.needs_input_grad[:3])
-        o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need, dropout_p=dropout_p, seed=seed)
+        o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need, dropout_p=dropout_p, seed=seed,
+                              q_start=q_start)
         if need:
-            ctx.save_for_backward(q, k, v, o, lse, key_valid)
+            ctx.save_for_backward(q, k, v, o, lse, key_valid, q_start)
         ctx.meta = (scale, causal, dropout_p, seed)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse, key_valid = ctx.saved_tensors
+        q, k, v, o, lse, key_valid, q_start = ctx.saved_tensors
         scale, causal, dropout_p, seed = ctx.meta
-        dq, dk, dv = raw_attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid, dropout_p=dropout_p, seed=seed)
-        return dq, dk, dv, None, None, None, None, None
+        dq, dk, dv = raw_attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid, dropout_p=dropout_p, seed=seed,
+                                  q_start=q_start)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 def dropout_seed() -> int:
@@ -623,10 +640,20 @@ def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int,
     return torch.from_numpy((x >= thr).reshape(batch, heads, seq_q, seq_k))
 
 
-def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None):
+def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None, q_start=None):
     if dropout_p > 0.0 and seed is None:
         seed = dropout_seed()
-    return AttentionFn.apply(q, k, v, key_valid, scale, causal, float(dropout_p), int(seed or 0))
+    return AttentionFn.apply(q, k, v, key_valid, scale, causal, float(dropout_p), int(seed or 0), q_start)
+
+
+def packed_q_start(seq_ids: torch.Tensor) -> torch.Tensor:
+    """[B, S] sequence ids of a packed batch (equal ids = same sequence, masking_utils.py:728-757) -> int32 [B, S]
+    index of the first token of each token's sequence.  Device-side, no synchronisation."""
+    s = seq_ids.shape[-1]
+    pos = torch.arange(s, device=seq_ids.device).expand_as(seq_ids)
+    first = torch.ones_like(seq_ids, dtype=torch.bool)
+    first[..., 1:] = seq_ids[..., 1:] != seq_ids[..., :-1]
+    return torch.where(first, pos, torch.zeros_like(pos)).cummax(-1).values.to(torch.int32).contiguous()
 
 
 class SwiGLUFn(torch.autograd.Function):
