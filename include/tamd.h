@@ -248,9 +248,10 @@ struct tamd_attn_params {
   float dropout_p;
   uint64_t dropout_seed;
   /* packed sequences (several sequences in one batch row, position_ids restarting: masking_utils.py:728-757,
-   * packed_sequence_mask_function :182-188): q_start[b, q] = key index of the first token of query q's sequence;
-   * key k is visible to query q iff q_start[b,q] <= k <= q (+ seq_k - seq_q).  [batch, seq_q] int32 or NULL;
-   * requires causal = 1. */
+   * packed_sequence_mask_function :182-188).  int32 [2, batch, seq] or NULL; requires causal = 1 and seq_q == seq_k:
+   *   plane 0  q_start[b, q] = index of the first token of query q's sequence
+   *   plane 1  k_end[b, k]   = index of the last token of key k's sequence
+   * key k is visible to query q iff q_start[b,q] <= k <= q (equivalently k <= q <= k_end[b,k]). */
   const int32_t* q_start;
 };
 int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream);

@@ -448,7 +448,8 @@ def test_attention_packed_sequences(env):
             assert sum(ls) == s
             ids[i] = torch.repeat_interleave(torch.arange(len(ls)), torch.tensor(ls))
         q_start = ops.packed_q_start(ids.to(dev))
-        assert q_start.dtype == torch.int32 and q_start[0, lens[0][0]].item() == lens[0][0]
+        assert q_start.dtype == torch.int32 and q_start[0, 0, lens[0][0]].item() == lens[0][0]
+        assert q_start[1, 0, 0].item() == lens[0][0] - 1 and q_start[1, 0, s - 1].item() == s - 1
         q = torch.randn(b, s, hq, d).bfloat16().to(dev).requires_grad_(True)
         k = torch.randn(b, s, hkv, d).bfloat16().to(dev).requires_grad_(True)
         v = torch.randn(b, s, hkv, d).bfloat16().to(dev).requires_grad_(True)

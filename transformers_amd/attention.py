@@ -23,7 +23,7 @@ ATTN_KEY = "tamd"
 
 class TamdMask:
     """What `tamd_mask` hands to the attention function when the mask is more than padding: the 2-D key-validity mask
-    (or None) plus, for packed sequences, `q_start` (int32 [B, S], first visible key of every query).  The decoder
+    (or None) plus, for packed sequences, `q_start` (int32 [2, B, S]: first token of every query's sequence, last token of every key's sequence).  The decoder
     layers pass it along untouched as `attention_mask`."""
 
     __slots__ = ("key_valid", "q_start")
@@ -83,7 +83,7 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
 
 
 def split_mask(attention_mask, batch: int, kv_len: int):
-    """(key_valid [B, kv_len] bool or None, q_start int32 [B, S] or None) from whatever reached the attention layer."""
+    """(key_valid [B, kv_len] bool or None, q_start int32 [2, B, S] or None) from whatever reached the attention layer."""
     if isinstance(attention_mask, TamdMask):
         kv = None if attention_mask.key_valid is None else _key_valid_from_mask(attention_mask.key_valid, batch, kv_len)
         return kv, attention_mask.q_start

@@ -269,7 +269,7 @@ int attn_check(const tamd_attn_params* p) {
   if (p->heads_q % p->heads_kv != 0) return TAMD_E_SHAPE;
   if (p->dtype != TAMD_BF16 && p->dtype != TAMD_F16) return TAMD_E_DTYPE;
   if (!(p->dropout_p >= 0.f && p->dropout_p < 1.f)) return TAMD_E_ARG;
-  if (p->q_start != nullptr && !p->causal) return TAMD_E_ARG;
+  if (p->q_start != nullptr && (!p->causal || p->seq_q != p->seq_k)) return TAMD_E_ARG;
   const int64_t strides[] = {p->q_stride_b, p->q_stride_s, p->q_stride_h, p->k_stride_b, p->k_stride_s, p->k_stride_h,
                              p->v_stride_b, p->v_stride_s, p->v_stride_h, p->o_stride_b, p->o_stride_s, p->o_stride_h};
   for (int64_t st : strides)

@@ -63,8 +63,18 @@ __device__ __forceinline__ void after_wait(u32x4& x0, u32x4& x1) {
 #endif
 }
 
-// PACKED: a third statistics row per tile carries q_start (first visible key of each query, include/tamd.h); a key is
-// visible iff q_start[q] <= key as well.  A separate instantiation: the test costs 2 VALU per element.
+// PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
+// a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
+// the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
+// PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
+// a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
+// the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
+// PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
+// a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
+// the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
+// PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
+// a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
+// the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
 __device__ __forceinline__ void after_wait1(u32x4& x0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(x0)::"memory");
@@ -77,7 +87,7 @@ template <typename T, int D, bool CAUSAL, bool HAS_MASK, bool DROP, int DBG = 0,
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdArgs g, int nkvt) {
   const AttnArgs& a = g.f;
   constexpr int ROWB = D * 2, TILEB = kQT * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
-  constexpr int BUFB = 2 * TILEB + 3 * kQT * 4;  // Q tile + dO tile + lse2[64] + delta[64] + q_start[64]
+  constexpr int BUFB = 2 * TILEB + 2 * kQT * 4;  // Q tile + dO tile + lse2[64] + delta[64]
   constexpr int NGA = KS / 2;                    // MFMA groups of one S/dP sub-tile (2 k-steps x {S, dP} each)
   constexpr int NGC = DT;                        // MFMA groups of one half of dV/dK (2 d-tiles x {dV, dK} each)
   static_assert(KS % 2 == 0 && DT % 2 == 0, "head_dim must be a multiple of 64");
@@ -119,6 +129,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   if (HAS_MASK && a.key_valid != nullptr)
     key_ok = key_ok && a.key_valid[(int64_t)b * a.seq_k + (krow < a.seq_k ? krow : 0)] != 0;
   const DropCtx drop = {a.drop_thr, a.seed_lo, a.seed_hi, a.drop_scale};
+  // PACKED: last query that sees this lane's key, and (wave-uniform) the last one that sees any key of the block
+  const int* k_end = PACKED ? a.q_start + (int64_t)a.batch * a.seq_q + (int64_t)b * a.seq_k : nullptr;
+  const int kend = PACKED ? k_end[krow < a.seq_k ? krow : a.seq_k - 1] : 0x3fffffff;
+  const int kend_blk = PACKED ? k_end[k0 + kKVB - 1 < a.seq_k ? k0 + kKVB - 1 : a.seq_k - 1] : 0x3fffffff;
 
   TileOffsets<D> toff;
   toff.init(lane);
@@ -137,7 +151,12 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     const int qmin = k0 - off;  // first query row that sees key k0
     qt_first = qmin > 0 ? qmin / kQT : 0;
   }
-  const int nqt64 = (a.seq_q + kQT - 1) / kQT;
+  int nqt64 = (a.seq_q + kQT - 1) / kQT;
+  if (PACKED) {  // q-tiles after the last query that can see a key of this block are never visited
+    const int lastq = kend_blk - off;
+    const int hi_tiles = lastq >= 0 ? lastq / kQT + 1 : 0;
+    nqt64 = hi_tiles < nqt64 ? hi_tiles : nqt64;
+  }
   const int per_head = nqt64 > qt_first ? nqt64 - qt_first : 0;
   const int niter = per_head * group;
 
@@ -198,10 +217,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
                          ((int64_t)b * a.heads_q + h) * a.seq_q + qr;  // wave 0: lse*log2(e) (second half)
       const void* p = (qr < a.seq_q) ? (const void*)src : (wave ? (const void*)g_zero16a : (const void*)g_pinf32);
       glds4(p, smem, st_off + (unsigned)wave * (kQT * 4));
-    } else if (PACKED && wave == 2) {  // q_start of the tile's rows (rows past seq_q: 0, they are masked by lse = +inf)
-      const int qr = qt * kQT + lane;
-      const void* p = (qr < a.seq_q) ? (const void*)(a.q_start + (int64_t)b * a.seq_q + qr) : (const void*)g_zero16a;
-      glds4(p, smem, st_off + 2u * (kQT * 4));
     }
   };
 
@@ -283,6 +298,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     };
     // key visible to local query row r of this tile iff mask_lim <= r (padding / out-of-range keys: never)
     const int mask_lim = key_ok ? (CAUSAL ? krow - (qt0 + off) : -0x40000000) : 0x40000000;
+    const int mask_hi = kend - qt0;  // PACKED: last local query row of this tile that belongs to the key's sequence
     sched_fence();
 
     f32x16 s[2], dp[2];
@@ -290,14 +306,13 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     // softmax backward of 4 consecutive query rows (chunk qd) of sub-tile `sub`: C-layout registers qd*4 .. +3 of
     // P and dS, rounded and packed at once into B operand sub*2 + (qd>>1), dwords (qd&1)*2 .. +1
     // lse / delta of 4 consecutive query rows of chunk qd (16 bytes each; lane part of the address = 16*hi)
-    auto stat_reads = [&](int sub, int qd, u32x4& l4, u32x4& d4, u32x4& s4) {
+    auto stat_reads = [&](int sub, int qd, u32x4& l4, u32x4& d4) {
       if (DBG & 1) return;
       const int imm = (sub * 32 + 8 * qd) * 4;  // (st_off of the second buffer does not fit the 16-bit offset field)
       l4 = lds_read16_abs(stataddr[cur], imm);
       d4 = lds_read16_abs(stataddr[cur], imm + kQT * 4);
-      if (PACKED) s4 = lds_read16_abs(stataddr[cur], imm + 2 * kQT * 4);
     };
-    auto softmax_chunk = [&](int sub, int qd, const u32x4& l4, const u32x4& d4, const u32x4& s4) {
+    auto softmax_chunk = [&](int sub, int qd, const u32x4& l4, const u32x4& d4) {
       if (DBG & 1) {
         const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
         pf[op][w] = f32_as_u32(s[sub][qd * 4]);
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         // branch-free: a branch here would cut the MFMA / VALU interleave into pieces; the test costs 2 VALU per
         // element on every tile (mask_lim is -2^30 on tiles that need no mask)
         if (PACKED)
-          x = (mask_lim <= ql + e && (int)s4[e] <= krow) ? x : -INFINITY;
+          x = (mask_lim <= ql + e && ql + e <= mask_hi) ? x : -INFINITY;
         else
           x = (mask_lim <= ql + e) ? x : -INFINITY;
         const float pe = fast_exp2(__builtin_fmaf(x, a.scale_log2, -u32_as_f32(l4[e])));
@@ -361,12 +376,12 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         u32x4(&fc)[4] = (gidx & 1) ? fb : fa;
         u32x4(&fn)[4] = (gidx & 1) ? fa : fb;
         constexpr int NCH_A = 4 / NGA;  // softmax chunks carried by one A1 group
-        u32x4 l4[NCH_A], d4[NCH_A], s4[NCH_A];
+        u32x4 l4[NCH_A], d4[NCH_A];
         // every LDS read of the loop is untracked; issue order = completion order:
         //   statistics of this group's chunks | next group's fragments | (wait: all but the newest batch)
         if (sub == 1) {
 #pragma unroll
-          for (int c = 0; c < NCH_A; ++c) stat_reads(0, ga * NCH_A + c, l4[c], d4[c], s4[c]);
+          for (int c = 0; c < NCH_A; ++c) stat_reads(0, ga * NCH_A + c, l4[c], d4[c]);
         }
         if (ga + 1 < NGA)
           load_rows(fn, q_off, do_off, sub, ga + 1);
@@ -381,10 +396,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           wait_frags<4>(fc[0], fc[1], fc[2], fc[3]);
         if (sub == 1) {
 #pragma unroll
-          for (int c = 0; c < NCH_A; ++c) {
-            after_wait(l4[c], d4[c]);
-            if (PACKED) after_wait1(s4[c]);
-          }
+          for (int c = 0; c < NCH_A; ++c) after_wait(l4[c], d4[c]);
         }
         sched_fence();
         s[sub] = mm(fc[0], kf[2 * ga], s[sub]);
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         dp[sub] = mm(fc[3], vf[2 * ga + 1], dp[sub]);
         if (sub == 1) {  // softmax backward of sub-tile 0 in the shadow of these MFMAs (NGA = 2: two chunks)
 #pragma unroll
-          for (int c = 0; c < NCH_A; ++c) softmax_chunk(0, ga * NCH_A + c, l4[c], d4[c], s4[c]);
+          for (int c = 0; c < NCH_A; ++c) softmax_chunk(0, ga * NCH_A + c, l4[c], d4[c]);
           mfma_valu_interleave();
         }
         sched_fence();
@@ -411,10 +423,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         u32x4(&fn)[4] = (gidx & 1) ? fa : fb;
         const bool last = (half == 1 && gc == NGC - 1);
         constexpr int NCH_C = 4 / NGC;
-        u32x4 l4[NCH_C], d4[NCH_C], s4[NCH_C];
+        u32x4 l4[NCH_C], d4[NCH_C];
         if (half == 0) {
 #pragma unroll
-          for (int c = 0; c < NCH_C; ++c) stat_reads(1, gc * NCH_C + c, l4[c], d4[c], s4[c]);
+          for (int c = 0; c < NCH_C; ++c) stat_reads(1, gc * NCH_C + c, l4[c], d4[c]);
         }
         if (last) {
           hand_off();  // waits lgkmcnt(0): this group's fragments are in registers
@@ -429,10 +441,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         }
         if (half == 0) {
 #pragma unroll
-          for (int c = 0; c < NCH_C; ++c) {
-            after_wait(l4[c], d4[c]);
-            if (PACKED) after_wait1(s4[c]);
-          }
+          for (int c = 0; c < NCH_C; ++c) after_wait(l4[c], d4[c]);
         }
         sched_fence();
         dvacc[2 * dtp] = mm(fc[0], pf[j], dvacc[2 * dtp]);
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         dkacc[2 * dtp + 1] = mm(fc[3], dsf[j], dkacc[2 * dtp + 1]);
         if (half == 0) {  // softmax backward of sub-tile 1 in the shadow of these MFMAs
 #pragma unroll
-          for (int c = 0; c < NCH_C; ++c) softmax_chunk(1, gc * NCH_C + c, l4[c], d4[c], s4[c]);
+          for (int c = 0; c < NCH_C; ++c) softmax_chunk(1, gc * NCH_C + c, l4[c], d4[c]);
           mfma_valu_interleave();
         }
         sched_fence();
@@ -466,7 +475,7 @@ static int dkdv_launch(const AttnBwdArgs& g, bool causal, hipStream_t s) {
   const bool mask = a.key_valid != nullptr;
   const bool drop = a.drop_thr != 0;
   const int nkvt = (int)ceil_div(a.seq_k, kKVB);
-  const size_t smem = (size_t)2 * (2 * kQT * D * 2 + 3 * kQT * 4);
+  const size_t smem = (size_t)2 * (2 * kQT * D * 2 + 2 * kQT * 4);
   dim3 grid((unsigned)(nkvt * a.heads_kv * a.batch)), block(kAttnThreads);
 #define TAMD_KV(C_, M_, D_) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, C_, M_, D_>), grid, block, smem, s, g, nkvt)
   if (a.q_start != nullptr) {  // packed sequences (causal only, checked by the caller)

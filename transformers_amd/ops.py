@@ -381,13 +381,14 @@ def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=
 
 
 def _check_q_start(q_start, q, causal):
-    """packed sequences: int32 [B, Sq], first visible key of every query (include/tamd.h)."""
+    """packed sequences: int32 [2, B, S] = (first token of each query's sequence, last token of each key's sequence),
+    include/tamd.h; build it with `packed_q_start`."""
     if q_start is None:
         return None
     if not causal:
         raise TamdError("packed sequences (q_start) need causal attention")
-    if q_start.dtype != torch.int32 or tuple(q_start.shape) != (q.shape[0], q.shape[1]):
-        raise TamdError(f"q_start must be int32 [batch, seq_q], got {q_start.dtype} {tuple(q_start.shape)}")
+    if q_start.dtype != torch.int32 or tuple(q_start.shape) != (2, q.shape[0], q.shape[1]):
+        raise TamdError(f"q_start must be int32 [2, batch, seq], got {q_start.dtype} {tuple(q_start.shape)}")
     return _c(q_start)
 
 
@@ -647,13 +648,18 @@ def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None, 
 
 
 def packed_q_start(seq_ids: torch.Tensor) -> torch.Tensor:
-    """[B, S] sequence ids of a packed batch (equal ids = same sequence, masking_utils.py:728-757) -> int32 [B, S]
-    index of the first token of each token's sequence.  Device-side, no synchronisation."""
+    """[B, S] sequence ids of a packed batch (equal ids = same sequence, masking_utils.py:728-757) -> int32 [2, B, S]:
+    plane 0 the index of the first token of each token's sequence, plane 1 the index of its last token (the two
+    bounds the kernels take, include/tamd.h).  Device-side, no synchronisation."""
     s = seq_ids.shape[-1]
     pos = torch.arange(s, device=seq_ids.device).expand_as(seq_ids)
     first = torch.ones_like(seq_ids, dtype=torch.bool)
     first[..., 1:] = seq_ids[..., 1:] != seq_ids[..., :-1]
-    return torch.where(first, pos, torch.zeros_like(pos)).cummax(-1).values.to(torch.int32).contiguous()
+    last = torch.ones_like(first)
+    last[..., :-1] = first[..., 1:]
+    start = torch.where(first, pos, torch.zeros_like(pos)).cummax(-1).values
+    end = torch.where(last, pos, torch.full_like(pos, s - 1)).flip(-1).cummin(-1).values.flip(-1)
+    return torch.stack((start, end)).to(torch.int32).contiguous()
 
 
 class SwiGLUFn(torch.autograd.Function):
