@@ -279,6 +279,32 @@ def test_gemm_schedules_agree(env, sched):
     assert rel_err(c16, x.half().float() @ w.half().float().t()) < 2e-3
 
 
+def test_gemm_split_k(env):
+    """Tile grids too small for the GPU are cut along K (fp32 partials + reduction): the weight-gradient products of
+    narrow layers.  Same result as the unsplit kernel up to fp32 summation order; every layout, plain and accumulate."""
+    torch.manual_seed(23)
+    dev = env.device
+    lib = ops.backend().lib
+    shapes = [(768, 3072, 16384), (768, 768, 8192), (264, 520, 4096)] if env.big else [(256, 256, 2048), (264, 136, 2560)]
+    for (m, n, k) in shapes:
+        assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE) > 0
+        assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_BIAS) == 0      # only plain / accumulate split
+        x = torch.randn(m, k).bfloat16().to(dev)
+        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+        ref = x.float() @ w.float().t()
+        xt, wt = x.t().contiguous(), w.t().contiguous()
+        for kw, a, b in ((dict(), x, w), (dict(b_kn=True), x, wt), (dict(a_km=True, b_kn=True), xt, wt)):
+            c = ops.raw_gemm(a, b, **kw)                     # default dispatch: split-K
+            unsplit = ops.raw_gemm(a, b, sched="fl", **kw)   # a schedule hint turns it off
+            assert rel_err(c, ref) < 4e-3, (m, n, k, kw)
+            assert rel_err(c, unsplit) < 2e-3 and (c != unsplit).float().mean() < 0.2
+        res = torch.randn(m, n).bfloat16().to(dev)
+        out = res.clone()
+        ops.raw_gemm(xt, wt, a_km=True, b_kn=True, epilogue=ops.EPI_ACCUM, out=out)
+        assert rel_err(out, ref.bfloat16().float() + res.float()) < 4e-3
+    assert lib.tamd_gemm_workspace_bytes(32768, 4096, 4096, 0, ops.EPI_NONE) == 0  # enough tiles: no split
+
+
 def test_gemm_epilogues(env):
     torch.manual_seed(10)
     dev = env.device

@@ -64,6 +64,9 @@ SIGNATURES = {
     "tamd_cross_entropy_fwd": (c_int, [P, P, P, P, I64, I64, I64, I64, c_int, P]),
     "tamd_cross_entropy_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, c_int, P]),
     "tamd_gemm": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P]),
+    "tamd_gemm_workspace_bytes": (c_size_t, [I64, I64, I64, c_int, c_int]),
+    "tamd_gemm_ws": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P, c_size_t,
+                             P]),
     "tamd_gemm_trace": (c_int, [P, P, P, I64, I64, I64, P, P]),
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),

@@ -58,7 +58,12 @@ struct GemmArgs {
   int64_t M, N, K, lda, ldb, ldc, ldr;
   int tiles_m, tiles_n;
   unsigned long long* trace;  // diagnostic: per-phase shader-clock stamps of workgroup 0 (tamd_gemm_trace)
+  // split-K (gemm_fl_kernel with EPI = kEpiSplitK): workgroup id = tile * splits + split; split s reduces stages
+  // [s*stages_per_split, ...) and writes an fp32 partial tile to ws[s][M][N]; splitk_reduce_kernel sums and rounds
+  float* ws;
+  int splits, stages_per_split;
 };
+constexpr int kEpiSplitK = 100;
 
 template <int ACT>
 __device__ __forceinline__ float gemm_act(float x) {
@@ -338,7 +343,8 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
   int tile_m, tile_n;
-  gemm_tile_of_block(g, blockIdx.x, &tile_m, &tile_n);
+  const int split = (EPI == kEpiSplitK) ? (int)(blockIdx.x % (unsigned)g.splits) : 0;
+  gemm_tile_of_block(g, (EPI == kEpiSplitK) ? (int)(blockIdx.x / (unsigned)g.splits) : (int)blockIdx.x, &tile_m, &tile_n);
   const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
@@ -351,7 +357,9 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
 
-  const int nst = (int)(g.K / kXK);
+  const int nst_all = (int)(g.K / kXK);
+  const int st0 = (EPI == kEpiSplitK) ? split * g.stages_per_split : 0;  // first stage of this workgroup's K range
+  const int nst = (EPI == kEpiSplitK) ? (nst_all - st0 < g.stages_per_split ? nst_all - st0 : g.stages_per_split) : nst_all;
   // per-lane source pointers: this wave's 8 A pieces ([0..7]) and 8 B pieces ([8..15]) of an operand stage.
   //   row-major operand: piece i = rows (wave*8+i)*8 .. +7, lane -> (row = lane>>3, physical chunk = lane&7);
   //                      next stage = +128 B
@@ -364,8 +372,8 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   int64_t kinc_a = A_KM ? (int64_t)kXK * g.lda * 2 : kXK * 2;  // bytes per stage; 0 once parked
   int64_t kinc_b = B_KN ? (int64_t)kXK * g.ldb * 2 : kXK * 2;
   // FEED 1 operand bases (tile origin - 4096 B so that no lane offset goes negative after the immediate is taken out)
-  const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096;
-  const char* base_b = (const char*)(B_KN ? B + n0 : B + n0 * g.ldb) - 4096;
+  const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096 + (int64_t)st0 * kinc_a;
+  const char* base_b = (const char*)(B_KN ? B + n0 : B + n0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (wave * 8 + i) * 8 + (lane >> 3);
@@ -574,8 +582,53 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   wait_vmcnt<0>();
   wait_lgkmcnt0();
   raw_barrier();
-  gemm_epilogue<T, EPI, ACT, 4, 4>(g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128,
-                                   n0 + wn * 128, lane);
+  if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per register quad
+    float* ws = g.ws + (int64_t)split * g.M * g.N;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int64_t m = m0 + wm * 128 + mi * 32 + l31;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int64_t n = n0 + wn * 128 + ni * 32 + 8 * qd + 4 * hi;
+          if (m < g.M && n < g.N)
+            st16(ws + m * g.N + n, u32x4{f32_as_u32(acc[ni][mi][qd * 4 + 0]), f32_as_u32(acc[ni][mi][qd * 4 + 1]),
+                                         f32_as_u32(acc[ni][mi][qd * 4 + 2]), f32_as_u32(acc[ni][mi][qd * 4 + 3])});
+        }
+    }
+    return;
+  }
+  gemm_epilogue<T, (EPI == kEpiSplitK ? TAMD_EPI_NONE : EPI), ACT, 4, 4>(
+      g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, lane);
+}
+
+// out[m][n] = round(sum_s ws[s][m][n] (+ out[m][n] if ACCUM)): 4 columns per thread (16-byte reads, 8-byte stores)
+template <typename T, bool ACCUM>
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
+                                     int splits) {
+  const int64_t nvec = M * (N / 4);
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nvec; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = idx / (N / 4), n = (idx % (N / 4)) * 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int sidx = 0; sidx < splits; ++sidx) {
+      const u32x4 v = ld16(ws + ((int64_t)sidx * M + m) * N + n);
+      a0 += u32_as_f32(v[0]);
+      a1 += u32_as_f32(v[1]);
+      a2 += u32_as_f32(v[2]);
+      a3 += u32_as_f32(v[3]);
+    }
+    T* out = C + m * ldc + n;
+    if (ACCUM) {  // TAMD_EPI_ACCUM: round(acc) + C_old, as the unsplit epilogue does
+      const u32x2 o = ld8(out);
+      typedef typename elem<T>::raw raw;
+      a0 = round_through<T>(a0) + elem<T>::to_f32((raw)(o[0] & 0xffffu));
+      a1 = round_through<T>(a1) + elem<T>::to_f32((raw)(o[0] >> 16));
+      a2 = round_through<T>(a2) + elem<T>::to_f32((raw)(o[1] & 0xffffu));
+      a3 = round_through<T>(a3) + elem<T>::to_f32((raw)(o[1] >> 16));
+    }
+    st8(out, u32x2{pack2<T>(a0, a1), pack2<T>(a2, a3)});
+  }
 }
 
 // ============================================================================================ host dispatch
@@ -643,6 +696,32 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
 #undef TAMD_G
 }
 
+// split-K: partial tiles into the fp32 workspace, then the reduction (TAMD_EPI_NONE / TAMD_EPI_ACCUM only)
+template <typename T, bool A_KM, bool B_KN>
+static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, hipStream_t s) {
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(kFlThreads);
+  hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, kEpiSplitK, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem, s, g);
+  const int64_t nvec = g.M * (g.N / 4);
+  int64_t blocks = ceil_div(nvec, 256);
+  if (blocks > 4096) blocks = 4096;
+  if (epilogue == TAMD_EPI_ACCUM)
+    hipLaunchKernelGGL((splitk_reduce_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, g.ws, (T*)g.C, g.M, g.N,
+                       g.ldc, g.splits);
+  else
+    hipLaunchKernelGGL((splitk_reduce_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, g.ws, (T*)g.C, g.M,
+                       g.N, g.ldc, g.splits);
+  return launch_status();
+}
+
+template <typename T>
+static int gemm_fl_splitk_launch(const GemmArgs& g, int flags, int epilogue, hipStream_t s) {
+  const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
+  if (!akm && !bkn) return gemm_fl_splitk_launch2<T, false, false>(g, epilogue, s);
+  if (!akm && bkn) return gemm_fl_splitk_launch2<T, false, true>(g, epilogue, s);
+  if (akm && bkn) return gemm_fl_splitk_launch2<T, true, true>(g, epilogue, s);
+  return gemm_fl_splitk_launch2<T, true, false>(g, epilogue, s);
+}
+
 template <typename T>
 static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
   const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
@@ -673,6 +752,9 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->tiles_m = (int)ceil_div(M, kBM);
   g->tiles_n = (int)ceil_div(N, kBN);
   g->trace = nullptr;
+  g->ws = nullptr;
+  g->splits = 1;
+  g->stages_per_split = 0;
   return TAMD_OK;
 }
 
@@ -691,9 +773,40 @@ extern "C" int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M,
   return launch_status();
 }
 
+// Split-K policy: a 256x256 tile grid that cannot fill the 256 CUs (weight gradients of narrow layers: dW of a
+// 768x3072 BERT projection is 36 tiles over K = tokens) is cut along K so that tiles x splits ~ one workgroup per CU,
+// at least 8 stages (512 k) per split.
+static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int epilogue, int* stages_per_split) {
+  *stages_per_split = 0;
+  if (K % kXK != 0 || (N % 4) != 0 || (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM)) return 1;
+  const int64_t tiles = ceil_div(M, kBM) * ceil_div(N, kBN), nst = K / kXK;
+  if (tiles > 128 || nst < 32) return 1;
+  int64_t s = 256 / tiles;
+  if (s > nst / 8) s = nst / 8;
+  if (s > 16) s = 16;
+  if (s < 2) return 1;
+  const int64_t sps = ceil_div(nst, s);
+  *stages_per_split = (int)sps;
+  return (int)ceil_div(nst, sps);  // no empty split
+}
+
+extern "C" size_t tamd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags, int epilogue) {
+  (void)flags;
+  int sps;
+  const int splits = gemm_choose_splits(M, N, K, epilogue, &sps);
+  return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
 extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N,
                          int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue,
                          int act, int dtype, tamd_stream_t stream) {
+  return tamd_gemm_ws(A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr, flags, epilogue, act, dtype, nullptr, 0, stream);
+}
+
+extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M,
+                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags,
+                            int epilogue, int act, int dtype, void* workspace, size_t workspace_bytes,
+                            tamd_stream_t stream) {
   if (!A || !B || !C) return TAMD_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0) return TAMD_E_SHAPE;
   // 16-byte accesses run along the contiguous dimension of each operand: K for a row-major operand, M (A) / N (B)
@@ -716,6 +829,16 @@ extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias
   }();
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
+  if (sched != 1 && workspace != nullptr) {
+    int sps;
+    const int splits = gemm_choose_splits(M, N, K, epilogue, &sps);
+    if (splits > 1 && workspace_bytes >= (size_t)splits * (size_t)M * (size_t)N * sizeof(float) && aligned16(workspace)) {
+      g.ws = reinterpret_cast<float*>(workspace);
+      g.splits = splits;
+      g.stages_per_split = sps;
+      TAMD_DISPATCH_HALF(dtype, return (gemm_fl_splitk_launch<T>(g, flags, epilogue, TAMD_STREAM(stream))));
+    }
+  }
   if (K % kXK == 0 && sched != 1) {
     TAMD_DISPATCH_HALF(dtype, return (gemm_fl_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   } else {

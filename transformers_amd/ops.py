@@ -352,8 +352,17 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
         out = torch.empty(m, n, dtype=a.dtype, device=a.device)
     flags = (GEMM_A_KM if a_km else 0) | (GEMM_B_KN if b_kn else 0) | GEMM_SCHED[sched]
     ldr = residual.stride(0) if residual is not None else 0
-    be.lib.check(be.lib.tamd_gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), m, n, k_a, a.stride(0), b.stride(0),
-                                  out.stride(0), ldr, flags, epilogue, act, _code(a), be.stream(a)), "tamd_gemm")
+    # split-K for tile grids that cannot fill the GPU (weight gradients of narrow layers): needs an fp32 workspace
+    ws_bytes = be.lib.tamd_gemm_workspace_bytes(m, n, k_a, flags & 3, epilogue) if sched is None else 0
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+        be.lib.check(be.lib.tamd_gemm_ws(_p(a), _p(b), _p(out), _p(bias), _p(residual), m, n, k_a, a.stride(0),
+                                         b.stride(0), out.stride(0), ldr, flags, epilogue, act, _code(a), _p(ws),
+                                         ws_bytes, be.stream(a)), "tamd_gemm_ws")
+    else:
+        be.lib.check(be.lib.tamd_gemm(_p(a), _p(b), _p(out), _p(bias), _p(residual), m, n, k_a, a.stride(0),
+                                      b.stride(0), out.stride(0), ldr, flags, epilogue, act, _code(a), be.stream(a)),
+                     "tamd_gemm")
     return out
 
 
