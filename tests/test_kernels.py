@@ -250,10 +250,14 @@ def test_gemm_schedules_agree(env, sched):
         ref = x.float() @ w.float().t()
         c = ops.raw_gemm(x, w, sched=sched)
         assert rel_err(c, ref) < 4e-3, (sched, m, n, k)
+        if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
+            continue  # the default dispatch splits K for this grid: fp32 summation order differs (test_gemm_split_k)
         assert torch.equal(c, ops.raw_gemm(x, w, sched="pp")), (sched, m, n, k)  # same fp32 k-order per output
     if sched != "pp":  # k-major operands (the backward products)
         for (m, n, k) in ([(4096, 1024, 4096), (1000, 1032, 320), (264, 4104, 832)] if env.big else
                           [(256, 256, 64), (264, 248, 128), (136, 520, 192), (72, 264, 320), (304, 136, 384)]):
+            if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
+                continue
             x = torch.randn(m, k).bfloat16().to(dev)
             w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
             xt, wt = x.t().contiguous(), w.t().contiguous()

@@ -26,7 +26,7 @@ ids = torch.randint(1000, 30000, (b, s), device=dev)
 am = torch.ones(b, s, dtype=torch.long, device=dev); am[::4, 400:] = 0
 labels = ids.clone(); labels[:, ::2] = -100
 res = {"config": "bert-base-uncased MLM fwd+bwd, batch 32 x 512, bf16, dropout 0.1 (train mode)"}
-for impl in ("eager", "sdpa", "tamd"):
+for impl in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("eager", "sdpa", "tamd")):
     c = copy.deepcopy(cfg); c._attn_implementation = "eager" if impl == "tamd" else impl
     m = BertForMaskedLM(c).bfloat16().to(dev).train()
     if impl == "tamd": transformers_amd.accelerate(m)
@@ -38,6 +38,8 @@ for impl in ("eager", "sdpa", "tamd"):
     del m
 print(json.dumps(res), flush=True)
 
+if len(sys.argv) > 2 and sys.argv[2] == "bb":
+    sys.exit(0)
 # ---- LV
 torch.manual_seed(1)
 vc = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336, patch_size=14)
