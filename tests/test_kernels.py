@@ -307,6 +307,10 @@ def test_gemm_split_k(env):
         ops.raw_gemm(xt, wt, a_km=True, b_kn=True, epilogue=ops.EPI_ACCUM, out=out)
         assert rel_err(out, ref.bfloat16().float() + res.float()) < 4e-3
     assert lib.tamd_gemm_workspace_bytes(32768, 4096, 4096, 0, ops.EPI_NONE) == 0  # enough tiles: no split
+    for (m, n, k) in [(768, 3072, 16384), (768, 768, 512), (256, 256, 2048), (2304, 768, 16384), (4096, 4096, 32768),
+                      (30522, 768, 16384), (264, 136, 2560), (128, 4, 4096), (1000, 1000, 1000)]:
+        for epi in (ops.EPI_NONE, ops.EPI_ACCUM, ops.EPI_BIAS):  # the host-side mirror of the policy stays in step
+            assert ops.gemm_workspace_bytes(m, n, k, epi) == lib.tamd_gemm_workspace_bytes(m, n, k, 0, epi), (m, n, k, epi)
 
 
 def test_gemm_epilogues(env):

@@ -49,7 +49,9 @@ class HipBackend:
             raise TamdError(f"tamd op received a {t.device} tensor; the HIP kernels need GPU memory")
 
     def stream(self, t: torch.Tensor):
-        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        # raw handle of torch's current stream on the tensor's device (no Stream object: this runs once per kernel)
+        idx = t.device.index
+        return torch._C._cuda_getCurrentRawStream(idx if idx is not None else torch.cuda.current_device())
 
 
 _backend = None
@@ -85,7 +87,7 @@ def _code(t: torch.Tensor) -> int:
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()  # ctypes converts the int for `c_void_p` argtypes
 
 
 def _prep(*tensors):
@@ -336,6 +338,22 @@ def gemm_supported(m, n, k, dtype) -> bool:
     return dtype in (torch.bfloat16, torch.float16) and k % 8 == 0 and n % 8 == 0 and m > 0
 
 
+def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int) -> int:
+    """Host-side mirror of tamd_gemm_workspace_bytes (csrc/gemm.hip gemm_choose_splits): one ctypes round trip per
+    GEMM is ~10 us, which small-model steps (hundreds of 30-us kernels) cannot hide.  tests/test_kernels.py keeps the
+    two in step."""
+    if k % 64 or n % 4 or epilogue not in (EPI_NONE, EPI_ACCUM):
+        return 0
+    tiles, nst = -(-m // 256) * -(-n // 256), k // 64
+    if tiles > 128 or nst < 32:
+        return 0
+    s = min(256 // tiles, nst // 8, 16)
+    if s < 2:
+        return 0
+    sps = -(-nst // s)
+    return -(-nst // sps) * m * n * 4
+
+
 GEMM_SCHED = {None: 0, "pp": 1 << 8, "fl": 3 << 8}  # diagnostic schedule hints (include/tamd.h)
 
 
@@ -353,7 +371,7 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
     flags = (GEMM_A_KM if a_km else 0) | (GEMM_B_KN if b_kn else 0) | GEMM_SCHED[sched]
     ldr = residual.stride(0) if residual is not None else 0
     # split-K for tile grids that cannot fill the GPU (weight gradients of narrow layers): needs an fp32 workspace
-    ws_bytes = be.lib.tamd_gemm_workspace_bytes(m, n, k_a, flags & 3, epilogue) if sched is None else 0
+    ws_bytes = gemm_workspace_bytes(m, n, k_a, epilogue) if sched is None else 0
     if ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         be.lib.check(be.lib.tamd_gemm_ws(_p(a), _p(b), _p(out), _p(bias), _p(residual), m, n, k_a, a.stride(0),
