@@ -51,9 +51,12 @@ class HipBackend:
     def stream(self, t: torch.Tensor):
         # raw handle of torch's current stream on the tensor's device (no Stream object: this runs once per kernel)
         idx = t.device.index
-        return torch._C._cuda_getCurrentRawStream(idx if idx is not None else torch.cuda.current_device())
+        if _RAW_STREAM is not None:
+            return _RAW_STREAM(idx if idx is not None else torch.cuda.current_device())
+        return torch.cuda.current_stream(t.device).cuda_stream
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _backend = None
 _backend_lock = threading.Lock()
 
