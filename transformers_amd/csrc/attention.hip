@@ -101,11 +101,14 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
     issue_kv_tile<T, D>(K, a.kss, t * kKB, a.seq_k, smem, k_off, wave, lane);
     issue_kv_tile<T, D>(V, a.vss, t * kKB, a.seq_k, smem, v_off, wave, lane);
   };
-  if (nkt > 0) issue(0, 0);
+  // packed sequences: q_start is non-decreasing along a row, so no row of this block sees a key before the first
+  // visible key of its first row: whole K/V tiles below it are neither loaded nor visited (buffers alternate from t0)
+  const int t0 = (q0 < a.seq_q ? packed_klo(a, b, q0) : 0) / kKB;
+  if (nkt > t0) issue(t0, t0 & 1);
   wait_vmcnt0();
   block_sync();
 
-  for (int t = 0; t < nkt; ++t) {
+  for (int t = t0; t < nkt; ++t) {
     const int cur = t & 1;
     if (t + 1 < nkt) issue(t + 1, cur ^ 1);
     const unsigned k_off = (unsigned)cur * 2u * TILEB, v_off = k_off + TILEB;

@@ -313,15 +313,13 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
 // LDS: 5 half-slots of 32 KiB = all 160 KiB.  Operand-stage A_j lives in slot (2j) % 5, B_j in (2j+1) % 5; row r of
 // an operand stage is 128 B at r*128, logical 16-byte chunk c at slot c ^ ((r>>1)&7) (applied on the source
 // address, undone on the fragment read; 16 consecutive rows x one chunk cover all 64 banks once).
-// Schedule of stage s (4 k-steps of 16; fragments double-buffered one k-step ahead):
-//     k-step 0,1 : 16 MFMA | 8 fragment reads | 4 pieces each of A_{s+2}   (into the slot B_{s-1} vacated)
-//     k-step 2   : 16 MFMA | 8 fragment reads (the last reads of stage s)
-//     hand-off   : vmcnt(8) retires this wave's B_{s+1} (A_{s+1} is older), lgkmcnt(0), barrier
-//     k-step 3   : 16 MFMA | 8 fragment reads of stage s+1 | 8 pieces of B_{s+2} (into the slot A_s vacated)
+// Schedule of stage s (4 k-steps of 16; fragments double-buffered one k-step ahead; 4 LDS-DMA pieces per k-step):
+//     k-step 0 : 16 MFMA | 8 fragment reads | B_{s+1}[4:8]   (second half of the slot A_{s-1} vacated)
+//     k-step 1 : 16 MFMA | 8 fragment reads | A_{s+2}[0:4]   (into the slot B_{s-1} vacated)
+//     k-step 2 : 16 MFMA | 8 fragment reads (the last reads of stage s) | A_{s+2}[4:8]
+//     hand-off : vmcnt(8) retires this wave's B_{s+1} (A_{s+1} is older), lgkmcnt(0), barrier
+//     k-step 3 : 16 MFMA | 8 fragment reads of stage s+1 | B_{s+2}[0:4]   (into the slot A_s vacated)
 // so 8-16 pieces per wave (32-64 KiB per CU) are in flight across every barrier, one barrier per 64 k.
-// (That was the first version; the shipped schedule spreads the pieces 4 per k-step -- B_{s+1}[4:8] | A_{s+2}[0:4] |
-// A_{s+2}[4:8] | B_{s+2}[0:4] -- and feeds through buffer_load ... lds: wave-uniform operand base stepped per
-// stage, loop-invariant 32-bit lane offsets, one M0 per 4 pieces via the shared immediate.)
 // Rows past M / N are clamped to the last valid row (their products land in rows / columns the epilogue never
 // stores); requires K % 64 == 0 (host dispatch).
 constexpr int kFlThreads = 256;
@@ -332,11 +330,8 @@ constexpr int kXSmem = kXSlots * (int)kXHalf;  // 163840 = the whole LDS of a CU
 
 // DBG (diagnostic instantiations, TAMD_GEMM_DBG=n, wrong results): 1 no LDS-DMA after the prologue, 2 no LDS
 // fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier
-// FEED 0: global_load_lds with per-lane 64-bit pointers; FEED 1: buffer_load ... lds (tamd_device.h glds16_buf): wave-
-// uniform operand base stepped per stage, loop-invariant 32-bit lane offsets, one M0 per 4 pieces.
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
-  constexpr int SCHED = 1, FEED = 1;  // the measured winners (profiles/r01_gemm_variants.md); 0/0 = first version
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
@@ -367,11 +362,12 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   //                      ping-pong kernel); piece i = k-rows (wave*8+i)*2 .. +1, lane -> (k = lane>>5, physical
   //                      chunk = lane&31); next stage = +64 rows
   // Rows / column chunks outside the matrix are clamped to the last valid one.
-  const char* srcp[FEED == 0 ? 16 : 1];
-  unsigned voff[FEED == 1 ? 16 : 1];  // FEED 1: byte offset from the operand base + 4096 - 1024*(piece & 3)
+  // Feed: buffer_load ... lds (tamd_device.h glds16_buf).  Wave-uniform operand base stepped per stage, loop-invariant
+  // 32-bit lane offsets, one M0 per 4 pieces through the shared immediate.
+  unsigned voff[16];  // byte offset from the operand base + 4096 - 1024*(piece & 3)
   int64_t kinc_a = A_KM ? (int64_t)kXK * g.lda * 2 : kXK * 2;  // bytes per stage; 0 once parked
   int64_t kinc_b = B_KN ? (int64_t)kXK * g.ldb * 2 : kXK * 2;
-  // FEED 1 operand bases (tile origin - 4096 B so that no lane offset goes negative after the immediate is taken out)
+  // operand bases (tile origin - 4096 B so that no lane offset goes negative after the immediate is taken out)
   const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096 + (int64_t)st0 * kinc_a;
   const char* base_b = (const char*)(B_KN ? B + n0 : B + n0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
 #pragma unroll
@@ -384,58 +380,32 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     const int64_t ra = (m0 + row < g.M) ? m0 + row : g.M - 1;
     const int64_t gcb = (n0 + col < g.N) ? n0 + col : g.N - 8;
     const int64_t rb = (n0 + row < g.N) ? n0 + row : g.N - 1;
-    if (FEED == 0) {
-      srcp[i] = A_KM ? (const char*)(A + (int64_t)kr * g.lda + gca) : (const char*)(A + ra * g.lda + c * 8);
-      srcp[8 + i] = B_KN ? (const char*)(B + (int64_t)kr * g.ldb + gcb) : (const char*)(B + rb * g.ldb + c * 8);
-    } else {
-      const int64_t oa = A_KM ? (int64_t)kr * g.lda + (gca - m0) : (ra - m0) * g.lda + c * 8;
-      const int64_t ob = B_KN ? (int64_t)kr * g.ldb + (gcb - n0) : (rb - n0) * g.ldb + c * 8;
-      voff[i] = (unsigned)(oa * 2 + 4096 - (i & 3) * 1024);
-      voff[8 + i] = (unsigned)(ob * 2 + 4096 - (i & 3) * 1024);
-    }
+    const int64_t oa = A_KM ? (int64_t)kr * g.lda + (gca - m0) : (ra - m0) * g.lda + c * 8;
+    const int64_t ob = B_KN ? (int64_t)kr * g.ldb + (gcb - n0) : (rb - n0) * g.ldb + c * 8;
+    voff[i] = (unsigned)(oa * 2 + 4096 - (i & 3) * 1024);
+    voff[8 + i] = (unsigned)(ob * 2 + 4096 - (i & 3) * 1024);
   }
-  // past the last stage: keep the load counts uniform but read the zero page (FEED 1: re-read the last stage)
-  auto park_a = [&]() {
-    if (FEED == 0) {
-#pragma unroll
-      for (int p = 0; p < 8; ++p) srcp[p] = (const char*)g_zero16;
-    } else {
-      base_a -= kinc_a;
-    }
-    kinc_a = 0;
-  };
-  auto park_b = [&]() {
-    if (FEED == 0) {
-#pragma unroll
-      for (int p = 8; p < 16; ++p) srcp[p] = (const char*)g_zero16;
-    } else {
-      base_b -= kinc_b;
-    }
-    kinc_b = 0;
-  };
+  // past the last stage: keep the load counts uniform and re-read the last valid stage
   auto park = [&]() {
-    park_a();
-    park_b();
+    base_a -= kinc_a;
+    base_b -= kinc_b;
+    kinc_a = 0;
+    kinc_b = 0;
   };
   const unsigned piece0 = (unsigned)wave * 8192u;  // this wave's first piece inside an operand stage
   bool dma_on = true;
-  auto issue = [&](int p, int slot) {              // piece p (0..15) of this wave into half-slot `slot`
+  auto issue = [&](int p, int slot) {  // piece p (0..15) of this wave into half-slot `slot`
     if ((DBG & 1) && !dma_on) return;
-    if (FEED == 0) {
-      glds16(srcp[p], smem, (unsigned)slot * kXHalf + piece0 + (unsigned)(p & 7) * 1024u);
-      srcp[p] += (p < 8) ? kinc_a : kinc_b;
-    } else {
-      const unsigned dst = (unsigned)slot * kXHalf + piece0 + (unsigned)((p & 7) >> 2) * 4096u;  // + immediate
-      const char* base = (p < 8) ? base_a : base_b;
-      switch (p & 3) {
-        case 0: glds16_buf<0>(base, voff[p], smem, dst); break;
-        case 1: glds16_buf<1024>(base, voff[p], smem, dst); break;
-        case 2: glds16_buf<2048>(base, voff[p], smem, dst); break;
-        default: glds16_buf<3072>(base, voff[p], smem, dst); break;
-      }
-      if (p == 7) base_a += kinc_a;   // every piece of the operand stage is out: step to the next stage
-      if (p == 15) base_b += kinc_b;
+    const unsigned dst = (unsigned)slot * kXHalf + piece0 + (unsigned)((p & 7) >> 2) * 4096u;  // + immediate
+    const char* base = (p < 8) ? base_a : base_b;
+    switch (p & 3) {
+      case 0: glds16_buf<0>(base, voff[p], smem, dst); break;
+      case 1: glds16_buf<1024>(base, voff[p], smem, dst); break;
+      case 2: glds16_buf<2048>(base, voff[p], smem, dst); break;
+      default: glds16_buf<3072>(base, voff[p], smem, dst); break;
     }
+    if (p == 7) base_a += kinc_a;  // every piece of the operand stage is out: step to the next stage
+    if (p == 15) base_b += kinc_b;
   };
   // fragment offsets inside a half-slot.  row-major: one per k-step (row (wm|wn)*128 + t*32 + l31: t is the
   // immediate t*4096); k-major: one per 32-column block t (k-step ks is the immediate ks*8192)
@@ -491,7 +461,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   for (int j = 0; j < 2; ++j) {
     if (j == nst) park();
 #pragma unroll
-    for (int p = 0; p < (SCHED == 1 && j == 1 ? 12 : 16); ++p) issue(p, 2 * j + (p >> 3));
+    for (int p = 0; p < (j == 1 ? 12 : 16); ++p) issue(p, 2 * j + (p >> 3));  // B_1[4:8] goes out in stage 0
   }
   wait_vmcnt<0>();
   raw_barrier();
@@ -508,10 +478,8 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
         const int sa2 = (2 * u + 4) % kXSlots;                                         // A_{s+2} (= slot of B_{s-1})
         const int sb2 = sa;                                                            // B_{s+2} (= slot of A_s)
         // The 8 fragment reads of a k-step go into its first six gaps (2 2 1 1 1 1) so the last one has more than
-        // an LDS latency to land before the next k-step's first MFMA; LDS-DMA pieces fill gaps 2..5.
-        // SCHED 0: k-steps 0,1 carry A_{s+2} (4 pieces each), k-step 3 all 8 pieces of B_{s+2}.
-        // SCHED 1: 4 pieces in every k-step: B_{s+1}[4:8] | A_{s+2}[0:4] | A_{s+2}[4:8] | B_{s+2}[0:4].
-        if (SCHED == 0 && s + 2 == nst) park();
+        // an LDS latency to land before the next k-step's first MFMA; four LDS-DMA pieces fill gaps 2..5 of every
+        // k-step: B_{s+1}[4:8] | A_{s+2}[0:4] | A_{s+2}[4:8] | B_{s+2}[0:4].
         // k-step 0 | fragments of k-step 1
         sched_fence();
         kstep_open();
@@ -520,16 +488,10 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
           mfma_pair(0, p);
           sched_fence();
           if (p < 2) rd1(sa, sb, 1, 1, 2 * p), rd1(sa, sb, 1, 1, 2 * p + 1);
-          if (p >= 2 && p < 6) {
-            rd1(sa, sb, 1, 1, p + 2);
-            if (SCHED == 0)
-              issue(p - 2, sa2);
-            else
-              issue(12 + p - 2, sb1);
-          }
+          if (p >= 2 && p < 6) rd1(sa, sb, 1, 1, p + 2), issue(12 + p - 2, sb1);
           sched_fence();
         }
-        if (SCHED == 1 && s + 2 == nst) park();
+        if (s + 2 == nst) park();
         // k-step 1 | fragments of k-step 2
         kstep_open();
 #pragma unroll
@@ -537,13 +499,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
           mfma_pair(1, p);
           sched_fence();
           if (p < 2) rd1(sa, sb, 2, 0, 2 * p), rd1(sa, sb, 2, 0, 2 * p + 1);
-          if (p >= 2 && p < 6) {
-            rd1(sa, sb, 2, 0, p + 2);
-            if (SCHED == 0)
-              issue(4 + p - 2, sa2);
-            else
-              issue(p - 2, sa2);
-          }
+          if (p >= 2 && p < 6) rd1(sa, sb, 2, 0, p + 2), issue(p - 2, sa2);
           sched_fence();
         }
         // k-step 2 | fragments of k-step 3: the last reads of stage s
@@ -553,10 +509,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
           mfma_pair(0, p);
           sched_fence();
           if (p < 2) rd1(sa, sb, 3, 1, 2 * p), rd1(sa, sb, 3, 1, 2 * p + 1);
-          if (p >= 2 && p < 6) {
-            rd1(sa, sb, 3, 1, p + 2);
-            if (SCHED == 1) issue(4 + p - 2, sa2);
-          }
+          if (p >= 2 && p < 6) rd1(sa, sb, 3, 1, p + 2), issue(4 + p - 2, sa2);
           sched_fence();
         }
         // hand-off: stage s+1 has landed for everybody; everybody's reads of stage s are in registers
@@ -564,16 +517,14 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
         wait_lgkmcnt0();
         if (!(DBG & 8)) raw_barrier();
         sched_fence();
-        // k-step 3 | fragments of k-step 0 of stage s+1, B_{s+2} pieces into the slot A_s vacated
+        // k-step 3 | fragments of k-step 0 of stage s+1, B_{s+2}[0:4] into the slot A_s vacated
         kstep_open();
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
           mfma_pair(1, p);
           sched_fence();
           if (p < 2) rd1(sa1, sb1, 0, 0, 2 * p), rd1(sa1, sb1, 0, 0, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa1, sb1, 0, 0, p + 2);
-          if (SCHED == 0) issue(8 + p, sb2);
-          if (SCHED == 1 && p >= 2 && p < 6) issue(8 + p - 2, sb2);
+          if (p >= 2 && p < 6) rd1(sa1, sb1, 0, 0, p + 2), issue(8 + p - 2, sb2);
           sched_fence();
         }
       }
