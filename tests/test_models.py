@@ -326,6 +326,49 @@ def test_packed_sequences_match_reference_and_separate_runs(env):
         tamd_mask(1, 8, 8, mask_function=and_masks(causal_mask_function, sliding_window_overlay(4)))
 
 
+def test_bert_post_ln_block_with_hidden_dropout_matches_reference(env):
+    """Train mode, hidden_dropout_prob = 0.1 (the shipped value): dense -> dropout -> +residual -> LayerNorm
+    (modeling_bert.py:289-293, :347-351) through GEMM+bias, torch's dropout and the fused add+LayerNorm kernel gives
+    the reference block's output and gradients for the same RNG state (the dropout call is the same call)."""
+    from transformers import BertConfig
+    from transformers.models.bert import modeling_bert as mb
+
+    from transformers_amd.models.bert import TamdBertOutput, TamdBertSelfOutput
+
+    torch.manual_seed(15)
+    cfg = BertConfig(hidden_size=128, intermediate_size=256, num_attention_heads=2)
+    dev = env.device
+    for ref_cls, fast_cls, width in ((mb.BertSelfOutput, TamdBertSelfOutput, 128), (mb.BertOutput, TamdBertOutput, 256)):
+        ref = ref_cls(cfg).bfloat16().train()
+        fast = copy.deepcopy(ref).to(dev)
+        fast.__class__ = fast_cls
+        from transformers_amd.models.common import REPLACEMENTS
+        for m in fast.modules():
+            if type(m) in REPLACEMENTS:
+                m.__class__ = REPLACEMENTS[type(m)]
+        h = torch.randn(2, 24, width).bfloat16()
+        res = torch.randn(2, 24, 128).bfloat16()
+        hr, rr = h.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        hf, rf = h.clone().to(dev).requires_grad_(True), res.clone().to(dev).requires_grad_(True)
+        torch.manual_seed(99)
+        yr = ref(hr, rr)
+        if dev.type == "cuda":
+            torch.cuda.manual_seed(99)
+        torch.manual_seed(99)
+        yf = fast(hf, rf)
+        if dev.type == "cpu":  # same generator, same call: identical mask
+            assert rel_err(yf, yr) < 1e-2
+            g = torch.randn_like(yr)
+            yr.backward(g)
+            yf.backward(g.to(dev))
+            assert rel_err(hf.grad, hr.grad) < 2e-2 and rel_err(rf.grad, rr.grad) < 2e-2
+            assert rel_err(fast.dense.weight.grad, ref.dense.weight.grad) < 2e-2
+        else:          # different generators on CPU and GPU: statistics only
+            assert abs(yf.float().mean().item()) < 0.1 and 0.8 < yf.float().std().item() < 1.2
+        fast.eval(), ref.eval()
+        assert rel_err(fast(hf, rf), ref(hr, rr)) < 1e-2
+
+
 def test_clip_vision_tower_hidden_states(env):
     """LLaVA's use of CLIP (models/llava/modeling_llava.py:154-166): output_hidden_states -> hidden_states[-2]."""
     from transformers import CLIPVisionConfig, CLIPVisionModel

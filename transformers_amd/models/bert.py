@@ -1,8 +1,8 @@
 """MI355X execution path for the BERT encoder blocks (src/transformers/models/bert/modeling_bert.py).
 
-Post-LN blocks with biases: `LayerNorm(dropout(dense(x)) + residual)`.  The fused forms below are used when
-dropout is inactive (eval mode or p = 0); otherwise the reference forward runs over the swapped leaf modules
-(TamdLinear / TamdLayerNorm) with torch's dropout in between.
+Post-LN blocks with biases: `LayerNorm(dropout(dense(x)) + residual)`.  With dropout inactive (eval mode or p = 0)
+the residual add rides in the GEMM epilogue; in train mode with hidden dropout the GEMM keeps the bias, torch's dropout
+runs on its output, and the residual add joins the LayerNorm kernel.
 """
 from __future__ import annotations
 
@@ -54,12 +54,19 @@ class _DenseResidualLN:
     """dense -> (+bias, +residual in the GEMM epilogue) -> LayerNorm: BertSelfOutput / BertOutput."""
 
     def _fast(self, hidden_states, input_tensor):
-        y = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
-        return ops.layernorm(y, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        if _no_dropout(self):
+            y = ops.linear(hidden_states, self.dense.weight, self.dense.bias, residual=input_tensor)
+            return ops.layernorm(y, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+        # train mode with hidden dropout (the shipped configs): LayerNorm(dropout(dense(x)) + residual) -- the dropout
+        # sits between the bias and the residual add, so the residual leaves the GEMM epilogue and joins the LayerNorm
+        # kernel instead (3 launches: GEMM+bias, dropout, add+LN; the reference path takes 5)
+        y = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
+        y = torch.nn.functional.dropout(y, self.dropout.p, True)  # (not in place: y is a custom-Function output view)
+        return ops.layernorm(y, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
+                             residual=input_tensor)[0]  # (y, x + residual)
 
     def _ok(self, x):
-        return (_gpu(x) and _no_dropout(self) and x.dtype in (torch.bfloat16, torch.float16)
-                and self.dense.bias is not None)
+        return _gpu(x) and x.dtype in (torch.bfloat16, torch.float16) and self.dense.bias is not None
 
 
 class TamdBertSelfOutput(_DenseResidualLN, ref.BertSelfOutput):
@@ -125,7 +132,7 @@ class TamdBertEmbeddings(ref.BertEmbeddings):
     def forward(self, input_ids=None, token_type_ids=None, position_ids=None, inputs_embeds=None,
                 past_key_values_length=0):
         w = self.word_embeddings.weight
-        if not (input_ids is not None and inputs_embeds is None and _gpu(w) and _no_dropout(self)
+        if not (input_ids is not None and inputs_embeds is None and _gpu(w)
                 and w.shape[1] % 8 == 0 and w.shape[1] <= 4096
                 and w.dtype in (torch.bfloat16, torch.float16, torch.float32)):
             return super().forward(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
@@ -137,9 +144,10 @@ class TamdBertEmbeddings(ref.BertEmbeddings):
             token_type_ids = torch.zeros_like(input_ids)
         position_ids = position_ids.expand(b, s)
         token_type_ids = token_type_ids.expand(b, s)
-        return BertEmbeddingsFn.apply(input_ids, token_type_ids, position_ids, w, self.token_type_embeddings.weight,
-                                      self.position_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
-                                      float(self.LayerNorm.eps), self.word_embeddings.padding_idx)
+        out = BertEmbeddingsFn.apply(input_ids, token_type_ids, position_ids, w, self.token_type_embeddings.weight,
+                                     self.position_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
+                                     float(self.LayerNorm.eps), self.word_embeddings.padding_idx)
+        return out if _no_dropout(self) else torch.nn.functional.dropout(out, self.dropout.p, True)
 
 
 REPLACEMENTS = {
