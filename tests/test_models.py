@@ -369,6 +369,60 @@ def test_bert_post_ln_block_with_hidden_dropout_matches_reference(env):
         assert rel_err(fast(hf, rf), ref(hr, rr)) < 1e-2
 
 
+def test_full_size_layer_properties(env):
+    """At BASELINE.json's full size (Llama-3-8B decoder layer, batch 8 x seq 4096 on the GPU; a miniature on the CPU
+    model) no fp32 reference fits the test budget, so parity is checked through size-independent properties:
+    batch rows are independent (bit-exact), the layer is causal (bit-exact), and the backward is linear in dY (a
+    power-of-two scale is exact in bf16)."""
+    from transformers.models.llama.modeling_llama import LlamaDecoderLayer, LlamaRotaryEmbedding
+
+    from transformers_amd.patch import _tables
+
+    big = env.big
+    cfg = (LlamaConfig(vocab_size=128, hidden_size=4096, intermediate_size=14336, num_hidden_layers=1,
+                       num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, max_position_embeddings=8192,
+                       rope_parameters={"rope_type": "default", "rope_theta": 500000.0}, attn_implementation="eager")
+           if big else tiny_llama(False))
+    b, s = (8, 4096) if big else (3, 160)
+    dev = env.device
+    torch.manual_seed(17)
+    with torch.device(dev):
+        layer = LlamaDecoderLayer(cfg, 0).bfloat16()
+        rot = LlamaRotaryEmbedding(cfg)
+    transformers_amd.attention.register()
+    cfg._attn_implementation = "tamd"
+    for m in layer.modules():
+        r = _tables().get(type(m))
+        if r is not None:
+            m.__class__ = r
+    assert type(layer).__name__ == "TamdLlamaDecoderLayer"
+    x = torch.randn(b, s, cfg.hidden_size, device=dev).bfloat16()
+    pe = rot(x, torch.arange(s, device=dev)[None])
+    with torch.no_grad():
+        y = layer(x, position_embeddings=pe)
+        assert torch.isfinite(y.float()).all()
+        # (1) batch independence: a row alone gives the same bits (GEMM rows, attention heads and norms are per row)
+        y1 = layer(x[1:2], position_embeddings=pe)
+        assert torch.equal(y1[0], y[1])
+        # (2) causality: changing the second half of the sequence leaves the first half untouched
+        x2 = x.clone()
+        x2[:, s // 2:] = torch.randn_like(x2[:, s // 2:])
+        y2 = layer(x2, position_embeddings=pe)
+        assert torch.equal(y2[:, : s // 2], y[:, : s // 2]) and not torch.equal(y2[:, s // 2:], y[:, s // 2:])
+    # (3) the backward is linear in dY: scaling by 4 scales every gradient by exactly 4
+    xg = x.clone().requires_grad_(True)
+    dy = (torch.randn_like(x) * 0.25)
+    layer(xg, position_embeddings=pe).backward(dy)
+    g1 = [xg.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    xg.grad = None
+    layer.zero_grad(set_to_none=True)
+    layer(xg, position_embeddings=pe).backward(dy * 4)
+    g4 = [xg.grad] + [p.grad for p in layer.parameters()]
+    for a, c in zip(g1, g4):
+        # exact unless an intermediate leaves the normal range of bf16/fp32 (flush-to-zero is not scale-invariant)
+        assert ((a * 4) == c).float().mean().item() > 0.9999 and rel_err(a * 4, c) < 1e-4
+
+
 def test_clip_vision_tower_hidden_states(env):
     """LLaVA's use of CLIP (models/llava/modeling_llava.py:154-166): output_hidden_states -> hidden_states[-2]."""
     from transformers import CLIPVisionConfig, CLIPVisionModel
