@@ -184,6 +184,16 @@ def main():
     merged = emb.masked_scatter(mask, feats)  # models/llava/modeling_llava.py:244-248
     save("llava_merge", ids=ids.numpy(), embeds=f32(emb), feats=f32(feats), merged=f32(merged))
 
+    # ---- 11b. packed sequences: the reference's own index finder + mask functions on restarting position ids
+    from transformers import masking_utils as mu
+
+    pos = torch.tensor([[0, 1, 2, 3, 0, 1, 0, 1, 2, 3, 4, 5], [0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3]])
+    pids = mu.find_packed_sequence_indices(pos)
+    fn = mu.and_masks(mu.causal_mask_function, mu.packed_sequence_mask_function(pids))
+    bi, qi, ki = torch.meshgrid(torch.arange(2), torch.arange(12), torch.arange(12), indexing="ij")
+    dense = fn(bi, torch.zeros_like(bi), qi, ki)
+    save("packed_mask", position_ids=pos.numpy(), seq_ids=pids.numpy(), mask=dense.numpy())
+
     # ---- 12. torch.optim.AdamW (what Trainer builds by default, trainer.py:1783-1799): 3 steps, fp32, single-tensor
     torch.manual_seed(12)
     p0 = torch.randn(64, 48)

@@ -229,3 +229,45 @@ def test_kernel_adamw_golden(env):
     st = opt.state[w]
     assert nrel(st["exp_avg"].cpu().numpy(), g["exp_avg"]) < 5e-7
     assert nrel(st["exp_avg_sq"].cpu().numpy(), g["exp_avg_sq"]) < 5e-7
+
+
+def test_oracle_packed_mask_golden():
+    """The reference's packed-sequence index finder and its and_masks(causal, packed) mask on restarting position ids,
+    against the oracle's restatement; and the two bound arrays the kernels take describe exactly that mask."""
+    g = load("packed_mask")
+    ids = orc.packed_sequence_ids(g["position_ids"])
+    assert np.array_equal(ids, g["seq_ids"])
+    mask = orc.packed_attention_mask_bool(ids)
+    assert np.array_equal(mask[:, 0], g["mask"])
+    lo, hi = orc.packed_bounds(ids)
+    s = ids.shape[1]
+    qi, ki = np.meshgrid(np.arange(s), np.arange(s), indexing="ij")
+    for b in range(ids.shape[0]):
+        from_q = (lo[b][:, None] <= ki) & (ki <= qi)              # q_start[q] <= k <= q
+        from_k = (ki <= qi) & (qi <= hi[b][None, :])              # k <= q <= k_end[k]
+        assert np.array_equal(from_q, g["mask"][b]) and np.array_equal(from_k, g["mask"][b])
+    # the device-side construction used by the product path gives the same arrays
+    assert np.array_equal(ops.packed_q_start(torch.from_numpy(ids)).numpy(), np.stack((lo, hi)))
+
+
+def test_kernel_packed_and_dropout_attention_vs_oracle(env):
+    """Flash kernels with q_start (packed rows) and with in-kernel dropout against the oracle's exact restatements."""
+    rng = np.random.default_rng(5)
+    b, s, hq, hkv, d = (2, 320, 4, 2, 64) if env.big else (2, 96, 2, 1, 64)
+    pos = np.stack([np.concatenate([np.arange(n) for n in lens]) for lens in
+                    (([200, 120], [64, 1, 255]) if env.big else ([60, 36], [32, 1, 63]))])
+    ids = orc.packed_sequence_ids(pos)
+    q, k, v = (torch.from_numpy(rng.standard_normal((b, s, h, d)).astype(np.float32)).bfloat16() for h in (hq, hkv, hkv))
+    scale = d ** -0.5
+    dev = env.device
+    qs = ops.packed_q_start(torch.from_numpy(ids).to(dev))
+    o, _ = ops.raw_attn_fwd(q.to(dev), k.to(dev), v.to(dev), scale, True, q_start=qs)
+    tr = lambda t: t.float().numpy().transpose(0, 2, 1, 3)  # [B,S,H,D] -> [B,H,S,D]
+    want = orc.exact_attention(tr(q), tr(k), tr(v), scale, orc.packed_attention_mask_bool(ids))
+    assert nrel(o.float().cpu().numpy(), want) < 5e-3
+    # dropout: the keep mask is the exported hash; the oracle applies it after the softmax
+    p, seed = 0.25, 0x5EED1234ABCD
+    keep = ops.dropout_keep_mask(seed, b, hq, s, s, p).numpy()
+    o, _ = ops.raw_attn_fwd(q.to(dev), k.to(dev), v.to(dev), scale, True, dropout_p=p, seed=seed)
+    want = orc.dropout_attention_exact(tr(q), tr(k), tr(v), scale, orc.attention_mask_bool(b, s, s, True), keep, p)
+    assert nrel(o.float().cpu().numpy(), want) < 6e-3
