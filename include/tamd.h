@@ -116,10 +116,12 @@ int tamd_embedding_fwd(const int64_t* ids, const void* table, void* out, int64_t
 /* embedding_dense_backward: dtable[v,:] = sum_{t: ids[t]==v} dout[t,:] (fp32 accumulation), rows of
  * dtable not referenced are left untouched (caller zero-fills).  sorted_ids/perm: ids sorted ascending
  * and the permutation that sorts them (int64).  padding_idx < 0 = none (BERT padding_idx=0 gets no grad,
- * models/bert/modeling_bert.py:58). */
+ * models/bert/modeling_bert.py:58).  Two passes over 32-token segments of the sorted order (long runs of one id are
+ * split across waves and joined deterministically); workspace: tamd_embedding_bwd_workspace_bytes() bytes of fp32. */
+size_t tamd_embedding_bwd_workspace_bytes(int64_t ntokens, int64_t dim);
 int tamd_embedding_bwd(const int64_t* sorted_ids, const int64_t* perm, const void* dout, void* dtable,
-                       int64_t ntokens, int64_t vocab, int64_t dim, int64_t padding_idx, int dtype,
-                       tamd_stream_t stream);
+                       void* workspace, size_t workspace_bytes, int64_t ntokens, int64_t vocab, int64_t dim,
+                       int64_t padding_idx, int dtype, tamd_stream_t stream);
 
 /* BertEmbeddings.forward, models/bert/modeling_bert.py:68-108: word + token_type + position gathers,
  * adds (each rounded like the reference's three bf16 adds), LayerNorm.  pre_ln (nullable) receives the

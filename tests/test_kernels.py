@@ -146,6 +146,33 @@ def test_embedding_bit_exact_and_scatter(env):
     assert (dt2[7] == 0).all()
 
 
+def test_embedding_backward_long_runs(env):
+    """Runs of one id longer than a 32-token segment (every BERT token has token_type 0; padding ids; frequent tokens)
+    are split across waves and joined: every run / segment alignment, ignored padding rows, one id for all tokens."""
+    dev = env.device
+    dim = 768 if env.big else 64
+    cases = []
+    n = 16384 if env.big else 300
+    cases.append(torch.zeros(n, dtype=torch.long))                                   # one run covering everything
+    cases.append(torch.cat([torch.full((31,), 3), torch.full((33,), 5), torch.full((64,), 9), torch.full((1,), 11),
+                            torch.full((n - 129,), 2)]))                             # boundaries at 31, 64, 128, 129
+    cases.append(torch.randint(0, 4, (n,)))                                          # 4 long interleaved runs (after sort)
+    cases.append(torch.cat([torch.arange(40), torch.full((n - 40,), 17)]))           # short runs then a long one
+    for ci, ids in enumerate(cases):
+        torch.manual_seed(40 + ci)
+        vocab = 64
+        ids = ids.to(dev)
+        dout = torch.randn(ids.numel(), dim).bfloat16().to(dev)
+        ref = torch.zeros(vocab, dim, dtype=torch.float32, device=dev).index_add_(0, ids, dout.float())
+        for pad in (None, int(ids[-1])):
+            dt = ops.raw_embedding_bwd(ids.view(1, -1), dout.view(1, -1, dim), vocab, padding_idx=pad)
+            want = ref.clone()
+            if pad is not None:
+                want[pad] = 0
+            assert rel_err(dt, want) < 4e-3, (ci, pad)
+            assert (dt[want.abs().sum(-1) == 0] == 0).all(), (ci, pad)
+
+
 def test_swiglu(env):
     torch.manual_seed(5)
     t, inter = (4096, 14336) if env.big else (5, 256)

@@ -77,29 +77,93 @@ __global__ void embedding_fwd_kernel(const int64_t* __restrict__ ids, const T* _
   }
 }
 
-// Scatter-add with fp32 accumulation over runs of equal (sorted) ids: one wave per run start.
+// Scatter-add with fp32 accumulation over runs of equal (sorted) ids, in two passes so that a long run (every BERT
+// token has token_type 0; padding ids; frequent tokens) is not serialised on one wave:
+//   pass 1  one wave per segment of kEmbSeg consecutive sorted tokens.  Runs that lie inside the segment are summed
+//           and stored.  The piece of a run that reaches the segment from the left (head) or leaves it to the right
+//           (tail; a run covering the whole segment counts as tail) goes to the fp32 workspace ws[seg][0|1][dim].
+//   pass 2  one wave per run that crosses a segment boundary (found at the segment where it starts): tail of the
+//           first segment + tails of fully covered segments + head of the last one -> dtable.  Deterministic.
+constexpr int kEmbSeg = 32;
+
 template <typename T>
-__global__ void embedding_bwd_kernel(const int64_t* __restrict__ sorted_ids, const int64_t* __restrict__ perm,
-                                     const T* __restrict__ dout, T* __restrict__ dtable, int64_t ntokens,
-                                     int64_t vocab, int dim, int64_t padding_idx) {
+__global__ void embedding_bwd_seg_kernel(const int64_t* __restrict__ sorted_ids, const int64_t* __restrict__ perm,
+                                         const T* __restrict__ dout, T* __restrict__ dtable, float* __restrict__ ws,
+                                         int64_t ntokens, int64_t vocab, int dim, int64_t padding_idx) {
   constexpr int VE = vec16<T>::N;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  for (int64_t t = (int64_t)blockIdx.x * wpb + wave; t < ntokens; t += (int64_t)gridDim.x * wpb) {
-    const int64_t id = sorted_ids[t];
-    if (t > 0 && sorted_ids[t - 1] == id) continue;  // not a run start
+  const int64_t nseg = (ntokens + kEmbSeg - 1) / kEmbSeg;
+  for (int64_t sg = (int64_t)blockIdx.x * wpb + wave; sg < nseg; sg += (int64_t)gridDim.x * wpb) {
+    const int64_t t0 = sg * kEmbSeg, t1 = (t0 + kEmbSeg < ntokens) ? t0 + kEmbSeg : ntokens;
+    for (int c = lane * VE; c < dim; c += 64 * VE) {
+      int64_t j = t0;
+      while (j < t1) {
+        const int64_t id = sorted_ids[j];
+        int64_t e = j + 1;
+        while (e < t1 && sorted_ids[e] == id) ++e;
+        float acc[VE];
+#pragma unroll
+        for (int i = 0; i < VE; ++i) acc[i] = 0.f;
+        for (int64_t q = j; q < e; ++q) {
+          float v[VE];
+          unpack16<T>(ld16(dout + perm[q] * dim + c), v);
+#pragma unroll
+          for (int i = 0; i < VE; ++i) acc[i] += v[i];
+        }
+        const bool from_left = (j == t0) && t0 > 0 && sorted_ids[t0 - 1] == id;
+        const bool to_right = (e == t1) && t1 < ntokens && sorted_ids[t1] == id;
+        const bool valid = id >= 0 && id < vocab && id != padding_idx;
+        if (to_right || from_left) {  // a piece of a longer run: fp32 partial (tail wins when the run covers the segment)
+          float* slot = ws + ((sg * 2 + (to_right ? 1 : 0)) * (int64_t)dim + c);
+#pragma unroll
+          for (int i = 0; i < VE; i += 4)
+            st16(slot + i, u32x4{f32_as_u32(acc[i]), f32_as_u32(acc[i + 1]), f32_as_u32(acc[i + 2]), f32_as_u32(acc[i + 3])});
+        } else if (valid) {
+          st16(dtable + id * dim + c, pack16<T>(acc));
+        }
+        j = e;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void embedding_bwd_join_kernel(const int64_t* __restrict__ sorted_ids, T* __restrict__ dtable,
+                                          const float* __restrict__ ws, int64_t ntokens, int64_t vocab, int dim,
+                                          int64_t padding_idx) {
+  constexpr int VE = vec16<T>::N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int64_t nseg = (ntokens + kEmbSeg - 1) / kEmbSeg;
+  for (int64_t sg = (int64_t)blockIdx.x * wpb + wave; sg + 1 < nseg; sg += (int64_t)gridDim.x * wpb) {
+    const int64_t t1 = (sg + 1) * kEmbSeg;  // first token of the next segment (exists: sg + 1 < nseg)
+    const int64_t id = sorted_ids[t1 - 1];
+    if (sorted_ids[t1] != id) continue;  // no run leaves this segment to the right
+    // the run must START in this segment (else an earlier segment owns it): its first token is inside [t0, t1)
+    const int64_t t0 = sg * kEmbSeg;
+    if (sorted_ids[t0] == id && t0 > 0 && sorted_ids[t0 - 1] == id) continue;
     if (id < 0 || id >= vocab || id == padding_idx) continue;
-    int64_t e = t + 1;
-    while (e < ntokens && sorted_ids[e] == id) ++e;
     for (int c = lane * VE; c < dim; c += 64 * VE) {
       float acc[VE];
 #pragma unroll
       for (int i = 0; i < VE; ++i) acc[i] = 0.f;
-      for (int64_t j = t; j < e; ++j) {
-        float v[VE];
-        unpack16<T>(ld16(dout + perm[j] * dim + c), v);
+      auto add = [&](const float* slot) {
 #pragma unroll
-        for (int i = 0; i < VE; ++i) acc[i] += v[i];
+        for (int i = 0; i < VE; i += 4) {
+          const u32x4 v = ld16(slot + i);
+          acc[i] += u32_as_f32(v[0]);
+          acc[i + 1] += u32_as_f32(v[1]);
+          acc[i + 2] += u32_as_f32(v[2]);
+          acc[i + 3] += u32_as_f32(v[3]);
+        }
+      };
+      add(ws + ((sg * 2 + 1) * (int64_t)dim + c));  // tail of the segment the run starts in
+      for (int64_t k = sg + 1; k < nseg; ++k) {
+        const int64_t e1 = ((k + 1) * kEmbSeg < ntokens) ? (k + 1) * kEmbSeg : ntokens;
+        const bool covers = sorted_ids[e1 - 1] == id && e1 < ntokens && sorted_ids[e1] == id;
+        add(ws + ((k * 2 + (covers ? 1 : 0)) * (int64_t)dim + c));  // whole segment and on: its tail; else: its head
+        if (!covers) break;
       }
       st16(dtable + id * dim + c, pack16<T>(acc));
     }
@@ -541,17 +605,28 @@ int tamd_embedding_fwd(const int64_t* ids, const void* table, void* out, int64_t
   return launch_status();
 }
 
+size_t tamd_embedding_bwd_workspace_bytes(int64_t ntokens, int64_t dim) {
+  const int64_t nseg = ceil_div(ntokens > 0 ? ntokens : 1, kEmbSeg);
+  return (size_t)nseg * 2 * (size_t)dim * sizeof(float);
+}
+
 int tamd_embedding_bwd(const int64_t* sorted_ids, const int64_t* perm, const void* dout, void* dtable,
-                       int64_t ntokens, int64_t vocab, int64_t dim, int64_t padding_idx, int dtype,
-                       tamd_stream_t stream) {
-  if (!sorted_ids || !perm || !dout || !dtable) return TAMD_E_NULL;
+                       void* workspace, size_t workspace_bytes, int64_t ntokens, int64_t vocab, int64_t dim,
+                       int64_t padding_idx, int dtype, tamd_stream_t stream) {
+  if (!sorted_ids || !perm || !dout || !dtable || !workspace) return TAMD_E_NULL;
   if (ntokens <= 0) return TAMD_OK;
-  if (!aligned16(dout) || !aligned16(dtable)) return TAMD_E_ALIGN;
+  if (!aligned16(dout) || !aligned16(dtable) || !aligned16(workspace)) return TAMD_E_ALIGN;
+  if (workspace_bytes < tamd_embedding_bwd_workspace_bytes(ntokens, dim)) return TAMD_E_ARG;
+  const int64_t nseg = ceil_div(ntokens, kEmbSeg);
   TAMD_DISPATCH_DTYPE(dtype, {
-    if (dim % vec16<T>::N != 0) return TAMD_E_SHAPE;
-    hipLaunchKernelGGL((embedding_bwd_kernel<T>), dim3(stream_grid(ntokens * 64, 256)), dim3(256), 0,
-                       TAMD_STREAM(stream), sorted_ids, perm, (const T*)dout, (T*)dtable, ntokens, vocab, (int)dim,
-                       padding_idx);
+    if (dim % vec16<T>::N != 0 || dim % 4 != 0) return TAMD_E_SHAPE;
+    hipLaunchKernelGGL((embedding_bwd_seg_kernel<T>), dim3(stream_grid(nseg * 64, 256)), dim3(256), 0,
+                       TAMD_STREAM(stream), sorted_ids, perm, (const T*)dout, (T*)dtable, (float*)workspace, ntokens,
+                       vocab, (int)dim, padding_idx);
+    if (nseg > 1)
+      hipLaunchKernelGGL((embedding_bwd_join_kernel<T>), dim3(stream_grid(nseg * 64, 256)), dim3(256), 0,
+                         TAMD_STREAM(stream), sorted_ids, (T*)dtable, (const float*)workspace, ntokens, vocab,
+                         (int)dim, padding_idx);
   });
   return launch_status();
 }

@@ -207,7 +207,10 @@ def raw_embedding_bwd(ids, dout, vocab, padding_idx=-1):
     sorted_ids, perm = torch.sort(flat, stable=True)  # index plumbing on torch; accumulation is ours
     dtable = torch.zeros(vocab, dim, dtype=dout.dtype, device=dout.device)
     d2 = _c(dout).view(-1, dim)
-    be.lib.check(be.lib.tamd_embedding_bwd(_p(sorted_ids), _p(perm), _p(d2), _p(dtable), flat.numel(), vocab, dim,
+    ws_bytes = 2 * (-(-max(flat.numel(), 1) // 32)) * dim * 4  # = tamd_embedding_bwd_workspace_bytes (32-token segments)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dout.device)
+    be.lib.check(be.lib.tamd_embedding_bwd(_p(sorted_ids), _p(perm), _p(d2), _p(dtable), _p(ws), ws_bytes,
+                                           flat.numel(), vocab, dim,
                                            -1 if padding_idx is None else int(padding_idx), _code(d2),
                                            be.stream(d2)), "tamd_embedding_bwd")
     return dtable
