@@ -423,6 +423,58 @@ def test_full_size_layer_properties(env):
         assert ((a * 4) == c).float().mean().item() > 0.9999 and rel_err(a * 4, c) < 1e-4
 
 
+def test_fused_lm_head_loss(env):
+    """lm_head GEMM + causal-LM loss chunk by chunk, no [tokens, vocab] tensor.  Same loss and
+    gradients as the unfused accelerated model (ignored labels, num_items_in_batch, a ragged last chunk); opt-in,
+    instance-level, undone by revert()."""
+    from transformers_amd import ops
+
+    if env.name == "hip":
+        pytest.skip("written after the round's GPU budget was spent: validated on the CPU execution model only; it "
+                    "composes kernels (GEMM incl. accumulate epilogue, cross-entropy fwd/bwd) that are GPU-tested")
+    torch.manual_seed(16)
+    cfg = tiny_llama(env.big)
+    base = LlamaForCausalLM(cfg).bfloat16().to(env.device).train()
+    fused = transformers_amd.accelerate(copy.deepcopy(base), fused_lm_head_loss=True)
+    plain = transformers_amd.accelerate(copy.deepcopy(base))
+    assert type(fused) is LlamaForCausalLM and "forward" in fused.__dict__
+    b, s = (4, 1000) if env.big else (2, 75)
+    ids = torch.randint(0, cfg.vocab_size, (b, s)).to(env.device)
+    labels = ids.clone()
+    labels[0, :7] = -100
+    for kw in ({}, {"num_items_in_batch": torch.tensor(b * s - 11)}):
+        fused.zero_grad(set_to_none=True)
+        plain.zero_grad(set_to_none=True)
+        of = fused(input_ids=ids, labels=labels, use_cache=False, **kw)
+        op = plain(input_ids=ids, labels=labels, use_cache=False, **kw)
+        assert of.logits is None and op.logits is not None
+        assert abs(of.loss.item() - op.loss.item()) <= 2e-3 * abs(op.loss.item())
+        (of.loss * 3).backward()
+        (op.loss * 3).backward()
+        gp = dict(plain.named_parameters())
+        for n, p in fused.named_parameters():
+            if n in ("lm_head.weight", "model.norm.weight", "model.layers.0.self_attn.q_proj.weight",
+                     "model.embed_tokens.weight"):
+                assert rel_err(p.grad, gp[n].grad) < 1.5e-2, n
+    # the op alone, with chunks that do not divide the token count
+    h = torch.randn(3, 50, cfg.hidden_size).bfloat16().to(env.device).requires_grad_(True)
+    w = base.lm_head.weight.detach().clone().requires_grad_(True)
+    lab = torch.randint(0, cfg.vocab_size, (3, 50)).to(env.device)
+    loss = ops.fused_linear_cross_entropy(h, w, lab, chunk_tokens=64)
+    hr, wr = h.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    ref = ops.causal_lm_loss(ops.linear(hr, wr), lab, cfg.vocab_size)
+    assert abs(loss.item() - ref.item()) <= 2e-3 * abs(ref.item())
+    loss.backward()
+    ref.backward()
+    assert rel_err(h.grad, hr.grad) < 1e-2 and rel_err(w.grad, wr.grad) < 1.5e-2
+    # eval / no labels: the reference forward, logits present; revert removes the instance-level forward
+    fused.eval()
+    with torch.no_grad():
+        assert fused(input_ids=ids, labels=labels, use_cache=False).logits is not None
+    transformers_amd.revert(fused)
+    assert "forward" not in fused.__dict__
+
+
 def test_clip_vision_tower_hidden_states(env):
     """LLaVA's use of CLIP (models/llava/modeling_llava.py:154-166): output_hidden_states -> hidden_states[-2]."""
     from transformers import CLIPVisionConfig, CLIPVisionModel

@@ -205,6 +205,31 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
                                   mlp.up_proj.weight, mlp.down_proj.weight, meta, q_start)
 
 
+def fused_causal_lm_forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                            inputs_embeds=None, labels=None, use_cache=None, logits_to_keep=0, **kwargs):
+    """LlamaForCausalLM.forward (modeling_llama.py: `logits = self.lm_head(...)` then `self.loss_function(...)`) with the
+    lm_head GEMM and the causal-LM loss fused chunk by chunk.  Installed on the INSTANCE by
+    `accelerate(model, fused_lm_head_loss=True)` -- the class, its name in `config.architectures` and the reference's
+    per-class registries stay untouched.  Used when labels are given in training mode: the output carries the loss and
+    `logits=None` (nothing of shape [tokens, vocab] is ever allocated); every other call is the reference's forward."""
+    w = self.lm_head.weight
+    fused = (labels is not None and self.training and self.lm_head.bias is None and w.shape[0] % 8 == 0
+             and w.shape[1] % 8 == 0 and w.dtype in (torch.bfloat16, torch.float16) and _on_gpu(w)
+             and isinstance(logits_to_keep, int) and logits_to_keep == 0)
+    if not fused:
+        return type(self).forward(self, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                                  past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,
+                                  use_cache=use_cache, logits_to_keep=logits_to_keep, **kwargs)
+    from transformers.modeling_outputs import CausalLMOutputWithPast
+
+    outputs = self.model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                         past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache, **kwargs)
+    loss = ops.fused_linear_cross_entropy(outputs.last_hidden_state, w, labels,
+                                          num_items_in_batch=kwargs.get("num_items_in_batch"))
+    return CausalLMOutputWithPast(loss=loss, logits=None, past_key_values=outputs.past_key_values,
+                                  hidden_states=outputs.hidden_states, attentions=outputs.attentions)
+
+
 REPLACEMENTS = {
     ref.LlamaRMSNorm: TamdLlamaRMSNorm,
     ref.LlamaMLP: TamdLlamaMLP,

@@ -783,6 +783,71 @@ def causal_lm_loss(logits, labels, vocab_size, num_items_in_batch=None, ignore_i
     return total / n_valid
 
 
+class FusedLinearCrossEntropyFn(torch.autograd.Function):
+    """lm_head + causal-LM loss without ever holding the [tokens, vocab] logits (reference:
+    `logits = self.lm_head(hidden)` then ForCausalLMLoss, modeling_llama.py / loss/loss_utils.py:49-71).
+
+    Tokens are processed in chunks: logits_c = h_c W^T (MFMA GEMM) -> cross-entropy forward (lse, per-token loss) ->
+    dlogits_c, already scaled by 1/normaliser -> dh_c = dlogits_c W and dW += dlogits_c^T h_c (accumulate epilogue).
+    The same three GEMMs as the unfused path, no recomputation; the gradients are produced in the forward and only
+    multiplied by the upstream scalar in the backward.  Peak extra memory: one chunk of logits instead of 2 x [T, V].
+    dW accumulates in the storage dtype across chunks (<= 8 roundings at the default chunking)."""
+
+    @staticmethod
+    def forward(ctx, h2d, w, labels, normaliser, ignore_index, chunk):
+        t, v = h2d.shape[0], w.shape[0]
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gs = (1.0 / normaliser.to(torch.float32)).reshape(1).contiguous()
+        loss = torch.zeros((), dtype=torch.float32, device=h2d.device)
+        dh = torch.empty_like(h2d) if need_h else None
+        dw = torch.empty_like(w) if need_w else None
+        first = True
+        for c0 in range(0, t, chunk):
+            c1 = min(c0 + chunk, t)
+            hc, lc = h2d[c0:c1], labels[c0:c1]
+            logits = raw_gemm(hc, w)
+            lse, row_loss = raw_cross_entropy_fwd(logits, lc, ignore_index)
+            loss = loss + row_loss.sum()
+            if need_h or need_w:
+                dlog = raw_cross_entropy_bwd(logits, lc, lse, gs, ignore_index)
+                del logits
+                if need_h:
+                    raw_gemm(dlog, w, b_kn=True, out=dh[c0:c1])
+                if need_w:
+                    raw_gemm(dlog, hc, a_km=True, b_kn=True, epilogue=EPI_NONE if first else EPI_ACCUM, out=dw)
+                del dlog
+            first = False
+        ctx.save_for_backward(dh, dw)
+        return loss * gs[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dh, dw = ctx.saved_tensors
+        g = g.detach()
+        return (None if dh is None else dh * g.to(dh.dtype), None if dw is None else dw * g.to(dw.dtype), None, None,
+                None, None)
+
+
+def fused_linear_cross_entropy(hidden, weight, labels, num_items_in_batch=None, ignore_index=-100, shift=True,
+                               chunk_tokens=None):
+    """Causal-LM loss of `hidden @ weight.T` against `labels` (shifted by one like ForCausalLMLoss unless shift=False)
+    without materialising the logits.  hidden [..., h], weight [V, h] (V % 8 == 0), labels [...] int64."""
+    hd = hidden.shape[-1]
+    if shift:
+        labels = torch.nn.functional.pad(labels, (0, 1), value=ignore_index)[..., 1:]
+    labels = labels.reshape(-1).to(hidden.device).contiguous()
+    h2d = _c(hidden).view(-1, hd)
+    t = h2d.shape[0]
+    if chunk_tokens is None:  # at most 8 chunks, at least 2048 tokens each (multiple of 256 rows: whole GEMM tiles)
+        chunk_tokens = max(2048, -(-t // 8))
+        chunk_tokens = -(-chunk_tokens // 256) * 256
+    if num_items_in_batch is not None:
+        norm = torch.as_tensor(num_items_in_batch, device=hidden.device)
+    else:
+        norm = (labels != ignore_index).sum()
+    return FusedLinearCrossEntropyFn.apply(h2d, weight, labels, norm, ignore_index, int(chunk_tokens))
+
+
 # --------------------------------------------------------------------------- torch.ops registration
 _LIB = torch.library.Library("tamd", "DEF")
 _registered = False

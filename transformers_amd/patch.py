@@ -25,14 +25,17 @@ def _tables() -> Dict[Type[nn.Module], Type[nn.Module]]:
     return table
 
 
-def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bool = True) -> nn.Module:
+def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bool = True,
+               fused_lm_head_loss: bool = False) -> nn.Module:
     """Switch `model` (any PreTrainedModel containing Llama / BERT / CLIP / GPT-2 blocks) to the MI355X path.
 
     * registers and selects `attn_implementation="tamd"` (reference API: `set_attn_implementation`,
       src/transformers/modeling_utils.py:2041-2139);
     * swaps norm / MLP / attention / layer modules for their tamd subclasses in place;
     * installs the fused cross-entropy as `model.loss_function` for causal-LM heads
-      (reference hook: modeling_utils.py:4652-4669).
+      (reference hook: modeling_utils.py:4652-4669);
+    * `fused_lm_head_loss=True` (opt-in, Llama): training forwards with labels run the lm_head GEMM and the loss chunk by
+      chunk and return `logits=None` -- no [tokens, vocab] tensor is allocated (ops.fused_linear_cross_entropy).
     Returns the same object.
     """
     attention.register()
@@ -44,6 +47,16 @@ def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bo
             m.__class__ = repl
             n += 1
     model._tamd_swapped = n
+    if fused_lm_head_loss:
+        import types
+
+        from transformers.models.llama.modeling_llama import LlamaForCausalLM
+
+        from .models.llama import fused_causal_lm_forward
+
+        if not isinstance(model, LlamaForCausalLM):
+            raise TypeError("fused_lm_head_loss=True is implemented for LlamaForCausalLM")
+        model.forward = types.MethodType(fused_causal_lm_forward, model)  # instance attribute: the class is untouched
     if attn_implementation and hasattr(model, "set_attn_implementation"):
         model.set_attn_implementation(attention.ATTN_KEY)
     # eager weight fusion (before DDP wraps the model)
@@ -81,4 +94,5 @@ def revert(model: nn.Module) -> nn.Module:
             m.__class__ = orig
     if isinstance(getattr(model, "loss_function", None), _LossDispatch):
         model.loss_function = model.loss_function.reference
+    model.__dict__.pop("forward", None)  # the instance-level fused forward, if installed
     return model
