@@ -1,4 +1,5 @@
 #!/bin/bash
+exec < /dev/null  # nothing here may wait on stdin (an empty $(find ...) once turned `head` into a 15-minute hang)
 # What the driver runs at round end, in one visit: GPU parity tests, smoke(), the default bench line.
 out=$PWD/gpurun_out
 mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+exec < /dev/null  # nothing here may wait on stdin (an empty $(find ...) once turned `head` into a 15-minute hang)
 # Round-end GPU visit: parity tests, rocprofv3 kernel stats + HBM counters of the bench command, the bench line.
 tag=${1:-r01}
 out=$PWD/gpurun_out

@@ -1,4 +1,5 @@
 #!/bin/bash
+exec < /dev/null  # nothing here may wait on stdin (an empty $(find ...) once turned `head` into a 15-minute hang)
 tag=${1:-pa}
 out=$PWD/gpurun_out/${tag}
 mkdir -p $out
