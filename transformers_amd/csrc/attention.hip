@@ -1,4 +1,6 @@
-// attention.hip -- flash-style scaled-dot-product attention (forward + backward) for gfx950.
+// attention.hip -- flash-style scaled-dot-product attention for gfx950: forward kernel, C-ABI entry points; the
+// backward's delta / dQ kernels come from attention_bwd.inc, the dK/dV kernel is attention_bwd_dkdv.hip, shared
+// device code (tile loads, swizzles, dropout hash, packed-sequence bounds) is attention_common.h.
 //
 // Replaces, behind AttentionInterface (src/transformers/modeling_utils.py:5092-5130):
 //   eager_attention_forward + repeat_kv   models/llama/modeling_llama.py:179-213 (fp32 softmax, GQA)

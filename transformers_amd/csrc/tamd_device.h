@@ -120,7 +120,7 @@ __device__ __forceinline__ u32x2 lds_read8_tr16(const char* smem, unsigned off) 
 }
 // The same instruction issued behind the compiler's back.  Why: with LDS-DMA loads in flight, LLVM's waitcnt
 // insertion puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 it knows about whenever it cannot
-// rule out that the read touches an LDS-DMA destination (seen in gemm_w4x_kernel: 43-73 drains inside the loop,
+// rule out that the read touches an LDS-DMA destination (seen in gemm_fl_kernel with k-major operands: 43-73 drains inside the loop,
 // i.e. no load pipelining at all).  The caller orders reads against landed data itself (counted vmcnt + barrier),
 // and must place wait_lgkmcnt0() before the first use of the result: the compiler does not know the register
 // is filled asynchronously.
