@@ -496,6 +496,29 @@ def test_dropout_hash_export_matches_host_mirror(env):
     assert len({lib.tamd_dropout_hash(seed, i) for i in idx}) == len(idx)
 
 
+def test_attention_fp16(env):
+    """The f16 instantiations of the three attention kernels (CLIP / fp16 checkpoints): forward and backward against
+    the fp32 restatement on the same rounded inputs; fp16 probabilities carry 3 more mantissa bits than bf16."""
+    dev = env.device
+    for (b, sq, hq, hkv, d, causal) in ([(2, 1024, 8, 2, 128, True), (2, 577, 4, 4, 64, False)] if env.big
+                                        else [(1, 150, 2, 1, 128, True), (1, 100, 2, 2, 64, False)]):
+        torch.manual_seed(33)
+        q = torch.randn(b, sq, hq, d).half().to(dev).requires_grad_(True)
+        k = torch.randn(b, sq, hkv, d).half().to(dev).requires_grad_(True)
+        v = torch.randn(b, sq, hkv, d).half().to(dev).requires_grad_(True)
+        scale = 1 / math.sqrt(d)
+        o = ops.attention(q, k, v, scale, causal, None)
+        assert o.dtype == torch.float16
+        qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        ref = ref_attention(qr, kr, vr, scale, causal, None)
+        assert rel_err(o, ref) < 1e-3, (b, sq, d)
+        do = torch.randn_like(o)
+        o.backward(do)
+        ref.backward(do.float())
+        for name, a, r in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+            assert rel_err(a, r) < 2e-3, (name, b, sq, d)
+
+
 def test_attention_packed_sequences(env):
     """Packed batches (several sequences per row; block-diagonal causal mask of masking_utils.py:182-188, 728-757):
     forward and backward against eager attention with the explicit mask, and against running every sequence alone."""
