@@ -92,7 +92,14 @@ def split_mask(attention_mask, batch: int, kv_len: int):
     return _key_valid_from_mask(attention_mask, batch, kv_len), None
 
 
-def _key_valid_from_mask(attention_mask: torch.Tensor, batch: int, kv_len: int) -> Optional[torch.Tensor]:
+def _key_valid_from_mask(attention_mask, batch: int, kv_len: int) -> Optional[torch.Tensor]:
+    if isinstance(attention_mask, TamdMask):  # a fused module path that only knows padding masks
+        if attention_mask.q_start is not None:
+            raise TamdError("packed sequences reached a fused block that does not implement them (supported: the "
+                            "Llama path and every model that goes through the registered attention function)")
+        attention_mask = attention_mask.key_valid
+        if attention_mask is None:
+            return None
     if attention_mask.dim() == 2:
         kv = attention_mask
     elif attention_mask.dim() == 4 and attention_mask.shape[1] == 1 and attention_mask.shape[2] == 1:
