@@ -216,12 +216,6 @@ int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const 
                  int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act, int dtype,
                  void* workspace, size_t workspace_bytes, tamd_stream_t stream);
 
-/* Diagnostic twin of tamd_gemm (bf16, row-major A[M,K], B[N,K], no epilogue): workgroup 0 additionally writes
- * 8 shader-clock stamps per K sub-tile and wave into trace[8 waves][32 sub-tiles][8] (uint64).  Not a product
- * path; tools/gemm_phase_trace.py turns the stamps into a per-phase cycle breakdown. */
-int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, void* trace,
-                    tamd_stream_t stream);
-
 /* ------------------------------------------------------------------ attention (MFMA, flash-style) */
 
 /* Scaled-dot-product attention replacing eager_attention_forward / repeat_kv
@@ -291,18 +285,6 @@ int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream);
 int tamd_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, double lr, double beta1, double beta2,
                     double eps, double weight_decay, int64_t step, double grad_scale, int dtype, int state_dtype,
                     tamd_stream_t stream);
-
-/* ------------------------------------------------------------------ diagnostics */
-
-/* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
- * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
- * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */
-int tamd_probe(const void* in, const void* in2, void* out, int which, int dtype, tamd_stream_t stream);
-
-/* Diagnostic: global -> LDS streaming rate of `blocks` 512-thread workgroups with a GEMM-tile address pattern
- * (`seg` contiguous bytes per row, rows `row_stride` bytes apart); mode 0 = LDS-DMA, 1 = register staged. */
-int tamd_bw_probe(const void* buf, size_t bytes, int seg, size_t row_stride, int iters, int mode, int blocks,
-                  void* sink, tamd_stream_t stream);
 
 #ifdef __cplusplus
 }

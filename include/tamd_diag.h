@@ -1,0 +1,31 @@
+/* tamd_diag.h -- diagnostic entry points of libtamd_diag.so (the kernel sources built with -DTAMD_DIAG plus
+ * csrc/probe.hip).  NOT part of the product ABI: libtamd.so does not export these, the package never loads this
+ * library; tools/ (ablation timing, phase traces, bandwidth probes) and tests/test_gpu_probe.py (instruction semantics
+ * of the CPU execution model against the silicon) do. */
+#ifndef TAMD_DIAG_H_
+#define TAMD_DIAG_H_
+#include "tamd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostic twin of tamd_gemm (bf16, row-major A[M,K], B[N,K], no epilogue): workgroup 0 additionally writes
+ * 8 shader-clock stamps per K sub-tile and wave into trace[8 waves][32 sub-tiles][8] (uint64).  Not a product
+ * path; tools/gemm_phase_trace.py turns the stamps into a per-phase cycle breakdown. */
+int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, void* trace,
+                    tamd_stream_t stream);
+
+/* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
+ * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
+ * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */
+int tamd_probe(const void* in, const void* in2, void* out, int which, int dtype, tamd_stream_t stream);
+
+/* Diagnostic: global -> LDS streaming rate of `blocks` 512-thread workgroups with a GEMM-tile address pattern
+ * (`seg` contiguous bytes per row, rows `row_stride` bytes apart); mode 0 = LDS-DMA, 1 = register staged. */
+int tamd_bw_probe(const void* buf, size_t bytes, int seg, size_t row_stride, int iters, int mode, int blocks,
+                  void* sink, tamd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAMD_DIAG_H_ */

@@ -73,3 +73,24 @@ def rel_err(a, b):
 
 def max_err(a, b):
     return (a.detach().float().cpu() - b.detach().float().cpu()).abs().max().item()
+
+
+# ---- measured errors ("dump measured rel-errors of every gpu test to profiles/r02_parity.json") -------------
+_PARITY = {}
+
+
+def record(group, name, err, ref=None):
+    """Remember a measured error (and, for noise-floor gates, the reference's own bf16 error) for the parity report."""
+    _PARITY.setdefault(group, {})[name] = {"err": float(err)} if ref is None else {"err": float(err), "ref": float(ref)}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY:
+        return
+    import json
+
+    backend = "hip" if torch.cuda.is_available() else "emu"
+    out = ROOT / "gpurun_out" if backend == "hip" else ROOT / ".pytest_cache"
+    out.mkdir(exist_ok=True)
+    with open(out / f"parity_{backend}.json", "w") as f:
+        json.dump(_PARITY, f, indent=1, sort_keys=True)

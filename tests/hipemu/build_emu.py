@@ -14,14 +14,14 @@ OUT = HERE / "_build"
 LIB = OUT / "libtamd_emu.so"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip", "probe.hip"]
-FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-pthread", "-Wno-unused-value",
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DTAMD_DIAG", "-ffp-contract=off", "-pthread", "-Wno-unused-value",
          "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-pass-failed",
          "-I", str(HERE), "-I", str(CSRC), "-I", str(ROOT / "include")]
 
 
 def build(force: bool = False) -> Path:
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()] + [HERE / "emu_api.cpp"]
-    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(HERE.glob("*.h")) + [HERE / "hip" / "hip_runtime.h"]
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + sorted(HERE.glob("*.h")) + [HERE / "hip" / "hip_runtime.h"]
     h = hashlib.sha256()
     for p in deps:
         h.update(p.name.encode() + p.read_bytes())

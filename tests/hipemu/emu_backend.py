@@ -25,7 +25,7 @@ class EmuBackend:
     name = "emu"
 
     def __init__(self):
-        self.lib = _cabi.TamdLib(build_emu.build())
+        self.lib = _cabi.TamdLib(build_emu.build(), diag=True)
 
     def check_tensor(self, t):
         if t.device.type != "cpu":

@@ -39,6 +39,34 @@ def test_library_exports_every_symbol():
     assert lib.tamd_error_string(0) == b"ok"
 
 
+def test_diagnostics_are_not_in_the_product_library():
+    """ablation instantiations (wrong results by design), phase traces and probes are built only into
+    libtamd_diag.so (include/tamd_diag.h, -DTAMD_DIAG); libtamd.so neither exports nor contains them."""
+    dll = ctypes.CDLL(str(build.build()))
+    for name in _cabi.DIAG_SIGNATURES:
+        assert not hasattr(dll, name), name
+        assert name not in HEADER
+    diag_header = (ROOT / "include" / "tamd_diag.h").read_text()
+    diag = _cabi.TamdLib(build.build_diag(), diag=True)
+    for name in _cabi.DIAG_SIGNATURES:
+        assert name in diag_header and hasattr(diag, name)
+    blob = Path(build.build()).read_bytes()
+    assert b"TAMD_GEMM_DBG" not in blob and b"TAMD_DKDV_DBG" not in blob
+    assert b"TAMD_GEMM_DBG" in Path(build.build_diag()).read_bytes()
+
+
+def test_build_digest_covers_included_kernel_bodies(tmp_path, monkeypatch):
+    """attention_bwd.inc is part of libtamd.so; an edit there must invalidate the build stamp."""
+    srcs = [build.CSRC / s for s in build.SOURCES]
+    deps = srcs + sorted(build.CSRC.glob("*.h")) + sorted(build.CSRC.glob("*.inc")) + sorted(build.INCLUDE.glob("*.h"))
+    assert any(p.name == "attention_bwd.inc" for p in deps)
+    d0 = build._digest(deps)
+    inc = tmp_path / "attention_bwd.inc"
+    inc.write_bytes((build.CSRC / "attention_bwd.inc").read_bytes() + b"\n// edit\n")
+    d1 = build._digest([p if p.name != "attention_bwd.inc" else inc for p in deps])
+    assert d0 != d1
+
+
 def test_argument_errors_do_not_launch():
     lib = _cabi.TamdLib(build.build())
     # NULL pointers / bad shapes are rejected before any launch (safe without a GPU)

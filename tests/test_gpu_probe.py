@@ -46,7 +46,7 @@ def _inputs(which, rng):
 def test_hardware_matches_cpu_model(which):
     from emu_backend import get_emu
 
-    hip = _cabi.TamdLib(build.build())
+    hip = _cabi.TamdLib(build.build_diag(), diag=True)  # diagnostics library (include/tamd_diag.h)
     emu = get_emu().lib
     rng = np.random.default_rng(which)
     for trial in range(4):
@@ -62,7 +62,7 @@ def test_hardware_matches_cpu_model(which):
 def test_probe_f16_mfma():
     from emu_backend import get_emu
 
-    hip = _cabi.TamdLib(build.build())
+    hip = _cabi.TamdLib(build.build_diag(), diag=True)  # diagnostics library (include/tamd_diag.h)
     emu = get_emu().lib
     rng = np.random.default_rng(99)
     vals = rng.integers(-4, 5, size=8192).astype(np.float16)

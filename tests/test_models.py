@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import transformers_amd
-from conftest import rel_err
+from conftest import record, rel_err
 from transformers import LlamaConfig, LlamaForCausalLM
 
 
@@ -24,7 +24,7 @@ def tiny_llama(big):
                        rms_norm_eps=1e-5, attn_implementation="eager")
 
 
-@pytest.mark.parametrize("padding", [False, True, "ragged"])
+@pytest.mark.parametrize("padding", [False, True, "left", "ragged"])
 def test_llama_forward_backward_parity(env, padding):
     torch.manual_seed(0)
     cfg = tiny_llama(env.big)
@@ -38,7 +38,18 @@ def test_llama_forward_backward_parity(env, padding):
     labels = ids.clone()
     labels[0, :10] = -100
     am = None
-    if padding:
+    if padding == "left":
+        # the reference's backend-parity test pads on both sides (tests/test_modeling_common.py:158, 361-365): with
+        # left padding the padded query rows see no key at all (eager gives them uniform attention, the kernel 0);
+        # like the reference test (:498-503) only the valid rows are compared -- and no gradient may be poisoned
+        am = torch.ones(b, s, dtype=torch.long)
+        am[1, :16] = 0
+        am[b - 1, :2] = 0
+        labels[am == 0] = -100
+        # (the last padded position predicts the first real token: keep that garbage-in term out of the loss too)
+        labels[1, 16] = -100
+        labels[b - 1, 2] = -100
+    elif padding:
         am = torch.ones(b, s, dtype=torch.long)
         am[1, s - 16:] = 0
         labels[1, s - 16:] = -100
@@ -61,8 +72,11 @@ def test_llama_forward_backward_parity(env, padding):
     g32 = dict(ref32.named_parameters())
     gref = dict(ref.named_parameters())
     for n, p in fast.named_parameters():
+        assert torch.isfinite(p.grad).all(), n
         ef, er = rel_err(p.grad, g32[n].grad), rel_err(gref[n].grad, g32[n].grad)
         assert ef <= 1.25 * er + 2e-3, (n, ef, er)
+        record("llama_model", f"{padding}:{n}", ef, er)
+    record("llama_model", f"{padding}:logits", e_fast, e_ref)
 
 
 def test_llama_module_level_path_matches_fused_layer(env):
@@ -97,6 +111,88 @@ def test_generate_with_cache_uses_reference_modules(env):
         got = fast(input_ids=ids.to(env.device), use_cache=True)
     assert rel_err(got.logits, want.logits) < 2e-2
     assert got.past_key_values is not None
+
+
+@pytest.mark.parametrize("padding_side", [None, "left"])
+def test_static_cache_prefill_and_decode_match_sdpa(env, padding_side):
+    """with a pre-allocated KV cache (`cache_implementation="static"`) K/V are [B,H,max_cache_len,D]
+    while the 2-D mask is [B, tokens so far]: `tamd_mask` must pad the mask to the cache length and the attention
+    function must only look at the slots in use.  Prefill and two teacher-forced decode steps against the reference's
+    sdpa backend with the same StaticCache class, an independent config object per model; then `generate`."""
+    from transformers import StaticCache
+
+    torch.manual_seed(21)
+    cfg = tiny_llama(False)
+    ref = LlamaForCausalLM(cfg).bfloat16().eval()
+    ref.set_attn_implementation("sdpa")
+    fast = LlamaForCausalLM(copy.deepcopy(cfg)).bfloat16().eval()
+    fast.load_state_dict(ref.state_dict())
+    fast = transformers_amd.accelerate(fast.to(env.device))
+    assert fast.config is not ref.config and ref.config._attn_implementation == "sdpa"
+    dev = env.device
+    b, p, steps, max_len = 2, 11, 2, 32
+    ids = torch.randint(1, cfg.vocab_size, (b, p + steps))
+    am = torch.ones(b, p + steps, dtype=torch.long)
+    if padding_side == "left":
+        am[1, :4] = 0
+    valid = am.bool()
+
+    def run(model, device):
+        cache = StaticCache(config=model.config, max_cache_len=max_len)
+        outs = []
+        with torch.no_grad():
+            o = model(input_ids=ids[:, :p].to(device), attention_mask=am[:, :p].to(device), past_key_values=cache,
+                      use_cache=True)
+            outs.append(o.logits.float().cpu())
+            for t in range(steps):
+                o = model(input_ids=ids[:, p + t: p + t + 1].to(device), attention_mask=am[:, : p + t + 1].to(device),
+                          past_key_values=cache, use_cache=True)
+                outs.append(o.logits.float().cpu())
+        return torch.cat(outs, dim=1)
+
+    want, got = run(ref, "cpu"), run(fast, dev)
+    assert got.shape == want.shape == (b, p + steps, cfg.vocab_size)
+    assert rel_err(got[valid], want[valid]) < 2e-2
+    # the static path agrees with the dynamic-cache path of the same model (same kernels, sliced K/V)
+    with torch.no_grad():
+        dyn = fast(input_ids=ids.to(dev), attention_mask=am.to(dev), use_cache=False).logits.float().cpu()
+    assert rel_err(got[valid], dyn[valid]) < 1e-2
+    gen_kw = dict(max_new_tokens=4, do_sample=False, cache_implementation="static", pad_token_id=0)
+    g_ref = ref.generate(ids[:, :p], attention_mask=am[:, :p], **gen_kw)
+    g_fast = fast.generate(ids[:, :p].to(dev), attention_mask=am[:, :p].to(dev), **gen_kw)
+    assert g_fast.shape == g_ref.shape
+    # random-init logits are nearly flat: bf16 rounding may flip an argmax, after which the continuations differ
+    assert (g_fast.cpu()[:, : p + 1] == g_ref[:, : p + 1]).float().mean() > 0.9
+
+
+def test_autocast_with_fp32_master_weights(env):
+    """Trainer(bf16=True) keeps fp32 parameters and runs under autocast; q/k arrive in fp32 after the
+    rotary (cos/sin are fp32).  The registered attention function casts to the autocast dtype instead of raising;
+    accelerate() on an fp32 model leaves the attention backend alone and says so."""
+    import warnings
+
+    torch.manual_seed(22)
+    cfg = tiny_llama(False)
+    m32 = LlamaForCausalLM(cfg).to(env.device)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        transformers_amd.accelerate(m32)
+    assert any("fp32 model" in str(x.message) for x in w)
+    assert m32.config._attn_implementation == "eager"
+    from transformers_amd.attention import tamd_attention_forward
+
+    q = torch.randn(1, 4, 24, 64, device=env.device)
+    k = torch.randn(1, 2, 24, 64, device=env.device)
+    mod = m32.model.layers[0].self_attn
+    with pytest.raises(transformers_amd.ops.TamdError):
+        tamd_attention_forward(mod, q, k, k, None)
+    if env.name == "hip":
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            o, _ = tamd_attention_forward(mod, q, k, k, None, scaling=0.125)
+        assert o.dtype == torch.bfloat16 and o.shape == (1, 24, 4, 64)
+        want = torch.nn.functional.scaled_dot_product_attention(q, k.repeat_interleave(2, 1), k.repeat_interleave(2, 1),
+                                                                is_causal=True, scale=0.125).transpose(1, 2)
+        assert rel_err(o, want) < 1e-2
 
 
 def test_state_dict_keys_and_fused_views_roundtrip(env):
@@ -201,8 +297,10 @@ def _grad_parity(fast, ref, ref32, skip=()):
         assert ef <= 1.6 * er + 3e-3, (n, ef, er)
 
 
-def test_bert_masked_lm_parity(env):
-    """BASELINE config 2 architecture (encoder LayerNorm/GeLU path) at test scale, dropout 0 (parity mode)."""
+@pytest.mark.parametrize("padding_side", ["right", "left"])
+def test_bert_masked_lm_parity(env, padding_side):
+    """BASELINE config 2 architecture (encoder LayerNorm/GeLU path) at test scale, dropout 0 (parity mode); padding on
+    either side as in the reference's backend-parity test (tests/test_modeling_common.py:158, 361-365)."""
     from transformers import BertConfig, BertForMaskedLM
 
     torch.manual_seed(3)
@@ -217,9 +315,14 @@ def test_bert_masked_lm_parity(env):
     b, s = (8, 512) if big else (2, 40)
     ids = torch.randint(1, cfg.vocab_size, (b, s))
     am = torch.ones(b, s, dtype=torch.long)
-    am[0, s - 7:] = 0
+    if padding_side == "right":
+        am[0, s - 7:] = 0
+    else:
+        am[0, :7] = 0
+        am[b - 1, :2] = 0
     labels = ids.clone()
     labels[:, ::3] = -100
+    labels[am == 0] = -100
     o_ref = ref(input_ids=ids, attention_mask=am, labels=labels)
     o_ref.loss.backward()
     o32 = ref32(input_ids=ids, attention_mask=am, labels=labels)
@@ -232,6 +335,7 @@ def test_bert_masked_lm_parity(env):
     v = am.bool()
     e_fast, e_ref = rel_err(o.logits[v.to(dev)], o32.logits[v]), rel_err(o_ref.logits[v], o32.logits[v])
     assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
+    record("bert_model", f"{padding_side}:logits", e_fast, e_ref)
     # key.bias has an exactly-zero gradient (softmax shift invariance): relative error is meaningless there
     _grad_parity(fast, ref, ref32, skip=("key.bias",))
 

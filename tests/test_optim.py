@@ -1,5 +1,6 @@
 """Fused AdamW against torch.optim.AdamW -- the optimizer `Trainer` builds by default
 (src/transformers/trainer.py:1783-1799) -- and against the oracle's restatement with explicit storage roundings."""
+import copy
 import sys
 from pathlib import Path
 
@@ -76,16 +77,61 @@ def test_adamw_bf16_matches_oracle_roundings(env, fp32_moments):
         _bf16_ulp_close(st["exp_avg_sq"], torch.from_numpy(v).bfloat16())
 
 
-def test_adamw_rejects_bad_inputs(env):
-    w = torch.nn.Parameter(torch.randn(16, 6).to(env.device))  # 96 elements: fine; a 6-element tensor is not
-    opt = transformers_amd.TamdAdamW([w], **HYP)
-    w.grad = torch.randn_like(w)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adamw_small_and_ragged_parameters(env, dtype):
+    """Parameters whose element count is not a multiple of the 16-byte vector (CLIP's scalar `logit_scale`, a 2- or
+    3-label classifier bias, odd hidden sizes): the vector body plus a one-element-per-thread tail, same update."""
+    torch.manual_seed(3)
+    shapes = [(), (3,), (6,), (37,), (5, 13)]
+    ref_p = [torch.nn.Parameter(torch.randn(s).to(dtype).float()) for s in shapes]
+    our_p = [torch.nn.Parameter(p.detach().clone().to(dtype).to(env.device)) for p in ref_p]
+    ref = torch.optim.AdamW(ref_p, foreach=False, **HYP)
+    our = transformers_amd.TamdAdamW(our_p, fp32_moments=True, **HYP)
+    for _ in range(3):
+        for rp, op in zip(ref_p, our_p):
+            g = torch.randn(rp.shape).to(dtype)
+            rp.grad, op.grad = g.float(), g.clone().to(env.device)
+        ref.step()
+        our.step()
+        if dtype != torch.float32:  # the reference run keeps fp32 parameters: round them where ours are stored
+            with torch.no_grad():
+                for rp in ref_p:
+                    rp.copy_(rp.to(dtype).float())
+    for rp, op in zip(ref_p, our_p):
+        if dtype == torch.float32:
+            assert torch.allclose(op.detach().cpu(), rp.detach(), rtol=3e-6, atol=1e-7)
+        else:
+            _bf16_ulp_close(op.detach(), rp.detach().to(dtype), frac=1.0)
+        assert torch.allclose(our.state[op]["exp_avg"].cpu(), ref.state[rp]["exp_avg"], rtol=1e-5, atol=1e-8)
+
+
+def test_adamw_resume_keeps_fp32_moments(env):
+    """Optimizer.load_state_dict casts state to the parameter dtype; fp32 moments must survive a resume."""
+    torch.manual_seed(4)
+    w = torch.nn.Parameter(torch.randn(64).bfloat16().to(env.device))
+    opt = transformers_amd.TamdAdamW([w], fp32_moments=True, **HYP)
+    w.grad = torch.randn(64).bfloat16().to(env.device)
     opt.step()
-    bad = torch.nn.Parameter(torch.randn(6).to(env.device))
-    opt2 = transformers_amd.TamdAdamW([bad], **HYP)
-    bad.grad = torch.randn_like(bad)
-    with pytest.raises(ops.TamdError):
-        opt2.step()  # n % 4 != 0: the C-ABI refuses instead of running a scalar tail silently
+    sd = copy.deepcopy(opt.state_dict())  # (a checkpoint: load_state_dict shares same-dtype tensors such as `step`)
+    w2 = torch.nn.Parameter(w.detach().clone())
+    opt2 = transformers_amd.TamdAdamW([w2], fp32_moments=True, **HYP)
+    opt2.load_state_dict(sd)
+    st = opt2.state[w2]
+    assert st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].dtype == torch.float32
+    assert torch.equal(st["exp_avg"], opt.state[w]["exp_avg"]) and torch.equal(st["exp_avg_sq"], opt.state[w]["exp_avg_sq"])
+    g = torch.randn(64).bfloat16().to(env.device)
+    w.grad, w2.grad = g, g.clone()
+    opt.step()
+    opt2.step()
+    assert torch.equal(w.detach(), w2.detach())
+    # bf16 moments stay bf16
+    opt3 = transformers_amd.TamdAdamW([torch.nn.Parameter(w.detach().clone())], **HYP)
+    p3 = opt3.param_groups[0]["params"][0]
+    p3.grad = g.clone()
+    opt3.step()
+    opt4 = transformers_amd.TamdAdamW([torch.nn.Parameter(w.detach().clone())], **HYP)
+    opt4.load_state_dict(copy.deepcopy(opt3.state_dict()))
+    assert opt4.state[opt4.param_groups[0]["params"][0]]["exp_avg"].dtype == torch.bfloat16
 
 
 @pytest.mark.gpu

@@ -5,6 +5,9 @@ code = r'''
 import sys, torch, json, os, math
 sys.path.insert(0, ".")
 from transformers_amd import ops
+sys.path.insert(0, "tools")
+import _diag
+_diag.use_diag()
 dev = torch.device("cuda:0")
 b, s, hq, hkv, d = 8, 4096, 32, 8, 128
 torch.manual_seed(0)

@@ -1,7 +1,8 @@
 import ctypes, sys, torch, json
 sys.path.insert(0, ".")
-from transformers_amd import ops
-lib = ops.backend().lib
+sys.path.insert(0, "tools")
+import _diag
+lib = _diag.use_diag()
 dev = torch.device("cuda:0")
 sink = torch.zeros(4, dtype=torch.int32, device=dev)
 P = lambda t: ctypes.c_void_p(t.data_ptr())

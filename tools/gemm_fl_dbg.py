@@ -5,6 +5,9 @@ code = r'''
 import sys, torch, json, os
 sys.path.insert(0, ".")
 from transformers_amd import ops
+sys.path.insert(0, "tools")
+import _diag
+_diag.use_diag()
 dev = torch.device("cuda:0")
 out = {"dbg": os.environ.get("TAMD_GEMM_DBG", "0")}
 for name, m, n, k in [("o_proj", 32768, 4096, 4096), ("gate_up", 32768, 28672, 4096), ("down", 32768, 4096, 14336)]:

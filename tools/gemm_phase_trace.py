@@ -6,7 +6,11 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import _diag  # noqa: E402
 from transformers_amd import ops  # noqa: E402
+
+_diag.use_diag()
 
 m, n, k = 32768, 4096, 4096
 dev = torch.device("cuda:0")

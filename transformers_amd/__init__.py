@@ -9,6 +9,7 @@ See DESIGN.md for the kernel inventory and INTEGRATION.md for the boundary.
 __version__ = "0.1.0"
 
 from . import attention as _attention
+from . import layer_ops as _layer_ops  # noqa: F401  (registers torch.ops.tamd.llama_layer)
 from .optim import TamdAdamW  # noqa: F401
 from .patch import accelerate, revert  # noqa: F401
 

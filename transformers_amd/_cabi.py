@@ -68,10 +68,14 @@ SIGNATURES = {
     "tamd_gemm_workspace_bytes": (c_size_t, [I64, I64, I64, c_int, c_int]),
     "tamd_gemm_ws": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P, c_size_t,
                              P]),
-    "tamd_gemm_trace": (c_int, [P, P, P, I64, I64, I64, P, P]),
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),
     "tamd_attn_bwd": (c_int, [POINTER(AttnBwdParams), P]),
+}
+
+# include/tamd_diag.h -- exported by libtamd_diag.so only (tools/, tests/test_gpu_probe.py), never by the product library
+DIAG_SIGNATURES = {
+    "tamd_gemm_trace": (c_int, [P, P, P, I64, I64, I64, P, P]),
     "tamd_probe": (c_int, [P, P, P, c_int, c_int, P]),
     "tamd_bw_probe": (c_int, [P, c_size_t, c_int, c_size_t, c_int, c_int, c_int, P, P]),
 }
@@ -84,11 +88,12 @@ class TamdError(RuntimeError):
 class TamdLib:
     """A loaded C-ABI library with typed entry points (`lib.tamd_gemm(...)`)."""
 
-    def __init__(self, path):
+    def __init__(self, path, diag: bool = False):
         self.path = str(path)
         self._dll = ctypes.CDLL(self.path)
         missing = []
-        for name, (res, args) in SIGNATURES.items():
+        table = dict(SIGNATURES, **DIAG_SIGNATURES) if diag else SIGNATURES
+        for name, (res, args) in table.items():
             try:
                 fn = getattr(self._dll, name)
             except AttributeError:

@@ -22,14 +22,23 @@ ATTN_KEY = "tamd"
 
 
 class TamdMask:
-    """What `tamd_mask` hands to the attention function when the mask is more than padding: the 2-D key-validity mask
-    (or None) plus, for packed sequences, `q_start` (int32 [2, B, S]: first token of every query's sequence, last token of every key's sequence).  The decoder
-    layers pass it along untouched as `attention_mask`."""
+    """What `tamd_mask` hands to the attention function for packed sequences: the 2-D key-validity mask (or None) plus
+    `q_start` (int32 [2, B, S]: first token of every query's sequence, last token of every key's sequence).  The
+    decoder layers pass it along untouched as `attention_mask`."""
 
     __slots__ = ("key_valid", "q_start")
 
     def __init__(self, key_valid, q_start):
         self.key_valid, self.q_start = key_valid, q_start
+
+
+def _with_kv_len(key_valid: torch.Tensor, kv_len: int) -> torch.Tensor:
+    """Prefill into a pre-allocated (static) KV cache: the 2-D key-validity mask over the `kv_len` cache slots in use,
+    tagged with that length.  The attention function slices K/V to it, so the kernels' bottom-right causal alignment is
+    the reference's `kv_idx <= q_idx + q_offset`.  (A plain tensor, not a wrapper class: `generate` builds masks ahead
+    of the forward and feeds them back through `create_causal_mask`, masking_utils.py:812-823.)"""
+    key_valid._tamd_kv_len = kv_len
+    return key_valid
 
 
 def _closure_vars(fn):
@@ -60,10 +69,38 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
     (sliding window, chunked, user overlays) is refused instead of being silently ignored."""
     from transformers import masking_utils as mu
 
-    padding = None if attention_mask is None else attention_mask[:, -kv_length:]
+    # 2-D padding mask over the kv window [kv_offset, kv_offset + kv_length), padded with zeros on the right when it
+    # is shorter than the window (pre-allocated caches), as prepare_padding_mask does (masking_utils.py:205-215)
+    padding = attention_mask
+    if padding is not None:
+        if padding.dim() != 2:
+            raise TamdError(f"attn_implementation='tamd' takes a 2-D attention_mask, got {tuple(padding.shape)}")
+        if (short := kv_length + kv_offset - padding.shape[-1]) > 0:
+            padding = torch.nn.functional.pad(padding, (0, short))
+        padding = padding[:, kv_offset: kv_offset + kv_length] if padding.shape[-1] != kv_length else padding
+    kv_len = None
+    dynamic = not torch.is_tensor(q_offset) and kv_offset == 0 and kv_length == q_offset + q_length
+    if not dynamic:
+        # a cache whose key/value tensors are longer than what has been written (StaticCache: kv_length =
+        # max_cache_len, q_offset = tokens already cached, cache_utils.py:489-497).  Visible keys are
+        # kv_idx <= q_idx + q_offset (masking_utils.py:76-81 with the offsets of :193-202).
+        if kv_offset != 0:
+            raise TamdError("attn_implementation='tamd' does not implement sliding-window KV caches (kv_offset != 0); "
+                            "use attn_implementation='sdpa' or 'eager'")
+        if q_length == 1:  # decode: one query sees keys 0 .. q_offset; stays on the device (q_offset may be a tensor)
+            dev = padding.device if padding is not None else kwargs.get("device")
+            used = torch.arange(kv_length, device=dev)[None] <= torch.as_tensor(q_offset, device=dev)
+            padding = used.expand(batch_size, -1) if padding is None else (padding.to(torch.bool) & used)
+        else:              # prefill into the cache: slice K/V to the slots in use (host integer: one sync per forward)
+            kv_len = int(q_offset) + q_length
+            if kv_len > kv_length:
+                raise TamdError(f"KV cache overflow: {kv_len} positions, cache holds {kv_length}")
+            dev = padding.device if padding is not None else kwargs.get("device")
+            padding = (torch.ones(batch_size, kv_len, dtype=torch.bool, device=dev) if padding is None
+                       else padding[:, :kv_len].to(torch.bool))
     plain = (None, mu.causal_mask_function, getattr(mu, "bidirectional_mask_function", None))
     if mask_function in plain:
-        return padding
+        return padding if kv_len is None else _with_kv_len(padding, kv_len)
     packed_ids = None
     for leaf in _decompose_mask_function(mask_function):
         if leaf in plain:
@@ -76,8 +113,8 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
                         f"sequences; the mask function {getattr(leaf, '__qualname__', leaf)!r} is not one of them "
                         "(sliding-window / chunked / custom overlays need attn_implementation='sdpa' or 'eager')")
     if packed_ids is None:
-        return padding
-    if q_offset != 0 or kv_offset != 0 or q_length != kv_length:
+        return padding if kv_len is None else _with_kv_len(padding, kv_len)
+    if not dynamic or q_offset != 0 or q_length != kv_length:
         raise TamdError("packed sequences with a KV cache are not supported by attn_implementation='tamd'")
     return TamdMask(padding, ops.packed_q_start(packed_ids[:, -q_length:]))
 
@@ -130,15 +167,27 @@ def tamd_attention_forward(module, query, key, value, attention_mask, dropout: f
     sk = key.shape[2]
     if d not in (64, 128):
         raise TamdError(f"attn_implementation='tamd' supports head_dim 64 and 128, got {d}")
+    if query.dtype == torch.float32 and torch.is_autocast_enabled():
+        # mixed precision with fp32 master weights (Trainer(bf16=True)): the projections ran in the autocast dtype but
+        # cos/sin are fp32, so q/k arrive in fp32 after the rotary -- autocast would cast them for torch's own attention
+        adt = torch.get_autocast_dtype("cuda")
+        query, key, value = query.to(adt), key.to(adt), value.to(adt)
     if query.dtype not in (torch.bfloat16, torch.float16):
-        raise TamdError(f"attn_implementation='tamd' supports bf16/fp16, got {query.dtype}")
+        raise TamdError(f"attn_implementation='tamd' supports bf16/fp16 (or fp32 under autocast), got {query.dtype}: "
+                        "load the model with dtype=torch.bfloat16 or select attn_implementation='sdpa'")
+    if key.dtype != query.dtype or value.dtype != query.dtype:
+        key, value = key.to(query.dtype), value.to(query.dtype)
     if scaling is None:
         scaling = d ** -0.5
     causal = is_causal if is_causal is not None else getattr(module, "is_causal", True)
     causal = bool(causal) and sq > 1
-    key_valid, q_start = split_mask(attention_mask, b, sk)
     # [B,H,S,D] -> [B,S,H,D] views (the projections produced [B,S,H,D]; this undoes the caller's transpose)
     q, k, v = query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2)
+    used = getattr(attention_mask, "_tamd_kv_len", None)
+    if used is not None and used != sk:
+        sk = used  # pre-allocated cache: only the first kv_len key slots are in use (strided views of the cache)
+        k, v = k[:, :sk], v[:, :sk]
+    key_valid, q_start = split_mask(attention_mask, b, sk)
     if q.stride(3) != 1:
         q = q.contiguous()
     if k.stride(3) != 1:

@@ -18,8 +18,10 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 INCLUDE = HERE.parent / "include"
 LIB = HERE / "libtamd.so"
+DIAG_LIB = HERE / "libtamd_diag.so"  # diagnostics only (include/tamd_diag.h): tools/ and tests/test_gpu_probe.py
 OBJ_DIR = HERE / "_build"
-SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip", "probe.hip"]
+SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip"]
+DIAG_SOURCES = SOURCES + ["probe.hip"]  # + every source recompiled with -DTAMD_DIAG (ablation instantiations, traces)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wno-unused-result", "-I", str(CSRC), "-I", str(INCLUDE)] + os.environ.get("TAMD_EXTRA_HIPCC_FLAGS", "").split()
@@ -49,10 +51,10 @@ PER_SOURCE_FLAGS: dict = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"
                           "attention_bwd_dkdv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 
-def _compile(hipcc: str, src: Path, obj: Path, verbose: bool) -> None:
+def _compile(hipcc: str, src: Path, obj: Path, verbose: bool, defines=()) -> None:
     extra = os.environ.get(f"TAMD_FLAGS_{src.stem}", None)
     extra = extra.split() if extra is not None else PER_SOURCE_FLAGS.get(src.name, [])
-    cmd = [hipcc, *FLAGS, *extra, "-c", str(src), "-o", str(obj)]
+    cmd = [hipcc, *FLAGS, *defines, *extra, "-c", str(src), "-o", str(obj)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -60,27 +62,39 @@ def _compile(hipcc: str, src: Path, obj: Path, verbose: bool) -> None:
         raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stdout}\n{r.stderr}")
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source for gfx950 and link libtamd.so.  Returns the library path."""
-    srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
-    deps = srcs + sorted(CSRC.glob("*.h")) + [INCLUDE / "tamd.h"]
-    stamp = OBJ_DIR / "stamp"
-    digest = _digest(deps)
-    if not force and LIB.exists() and stamp.exists() and stamp.read_text() == digest:
-        return LIB
+def _build(lib: Path, sources, obj_dir: Path, defines, force: bool, verbose: bool) -> Path:
+    srcs = [CSRC / s for s in sources if (CSRC / s).exists()]
+    # everything a translation unit can include: headers AND the .inc kernel bodies (attention_bwd.inc)
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.inc")) + sorted(INCLUDE.glob("*.h"))
+    stamp = obj_dir / "stamp"
+    digest = _digest(deps) + " ".join(defines)
+    if not force and lib.exists() and stamp.exists() and stamp.read_text() == digest:
+        return lib
     hipcc = _hipcc()
-    OBJ_DIR.mkdir(exist_ok=True)
-    objs = [OBJ_DIR / (s.stem + ".o") for s in srcs]
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    objs = [obj_dir / (s.stem + ".o") for s in srcs]
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        list(ex.map(lambda so: _compile(hipcc, so[0], so[1], verbose), zip(srcs, objs)))
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+        list(ex.map(lambda so: _compile(hipcc, so[0], so[1], verbose, defines), zip(srcs, objs)))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(lib), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     stamp.write_text(digest)
-    return LIB
+    return lib
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 and link libtamd.so (the product library).  Returns the library path."""
+    return _build(LIB, SOURCES, OBJ_DIR, (), force, verbose)
+
+
+def build_diag(force: bool = False, verbose: bool = False) -> Path:
+    """libtamd_diag.so: the same sources with -DTAMD_DIAG (ablation instantiations, phase traces) + probe.hip."""
+    return _build(DIAG_LIB, DIAG_SOURCES, OBJ_DIR / "diag", ("-DTAMD_DIAG",), force, verbose)
 
 
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose=True)
     print(path)
+    if "--diag" in sys.argv:
+        print(build_diag(force="--force" in sys.argv, verbose=True))

@@ -51,7 +51,7 @@ __device__ __forceinline__ void wait_frags(u32x4& f0, u32x4& f1, u32x4& f2, u32x
 #endif
 }
 
-// DBG (diagnostic builds, TAMD_DKDV_DBG=n, wrong results): 1 no softmax arithmetic, 2 no LDS fragment reads,
+// DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_DKDV_DBG=n, wrong results): 1 no softmax arithmetic, 2 no LDS fragment reads,
 // 4 no MFMA, 8 no tile loads after the prologue, 16 no barrier
 // order-only dependency: the registers are "produced" here, after every earlier volatile asm (the waits)
 __device__ __forceinline__ void after_wait(u32x4& x0, u32x4& x1) {
@@ -491,33 +491,24 @@ static int dkdv_launch(const AttnBwdArgs& g, bool causal, hipStream_t s) {
     else
       TAMD_KV(false, true, true);
   } else if (causal) {
+    if (mask) {
+      TAMD_KV(true, true, false);
+      return launch_status();
+    }
+#ifdef TAMD_DIAG  // ablation instantiations (wrong results by design): libtamd_diag.so only
     static const int dbg = [] {
       const char* e = getenv("TAMD_DKDV_DBG");
       return e ? atoi(e) : 0;
     }();
-#define TAMD_KVD(N_) \
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, false, false, N_>), grid, block, smem, s, g, nkvt)
-    if (mask)
-      TAMD_KV(true, true, false);
-    else if (dbg == 1)
-      TAMD_KVD(1);
-    else if (dbg == 2)
-      TAMD_KVD(2);
-    else if (dbg == 4)
-      TAMD_KVD(4);
-    else if (dbg == 8)
-      TAMD_KVD(8);
-    else if (dbg == 16)
-      TAMD_KVD(16);
-    else if (dbg == 3)
-      TAMD_KVD(3);
-    else if (dbg == 7)
-      TAMD_KVD(7);
-    else if (dbg == 6)
-      TAMD_KVD(6);
-    else
-      TAMD_KV(true, false, false);
+#define TAMD_KVD(N_)                                                                                          \
+  if (dbg == N_) {                                                                                            \
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, false, false, N_>), grid, block, smem, s, g, nkvt);  \
+    return launch_status();                                                                                   \
+  }
+    TAMD_KVD(1) TAMD_KVD(2) TAMD_KVD(4) TAMD_KVD(8) TAMD_KVD(16) TAMD_KVD(3) TAMD_KVD(7) TAMD_KVD(6)
 #undef TAMD_KVD
+#endif
+    TAMD_KV(true, false, false);
   } else {
     if (mask)
       TAMD_KV(false, true, false);

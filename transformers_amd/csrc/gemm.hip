@@ -328,7 +328,7 @@ constexpr unsigned kXHalf = 256u * kXK * 2u;  // one operand of one stage: 32 Ki
 constexpr int kXSlots = 5;
 constexpr int kXSmem = kXSlots * (int)kXHalf;  // 163840 = the whole LDS of a CU
 
-// DBG (diagnostic instantiations, TAMD_GEMM_DBG=n, wrong results): 1 no LDS-DMA after the prologue, 2 no LDS
+// DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_GEMM_DBG=n, wrong results): 1 no LDS-DMA after the prologue, 2 no LDS
 // fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
@@ -622,6 +622,7 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
 template <typename T, bool A_KM, bool B_KN>
 static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
+#ifdef TAMD_DIAG  // ablation instantiations (wrong results by design): libtamd_diag.so only, never the product library
   static const int dbg = [] {
     const char* e = getenv("TAMD_GEMM_DBG");
     return e ? atoi(e) : 0;
@@ -640,6 +641,7 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
     }
 #undef TAMD_GD
   }
+#endif
 #define TAMD_G(E_, A_)                                                                              \
   hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, E_, A_>), grid, block, (size_t)kXSmem, s, g); \
   return launch_status();
@@ -709,6 +711,7 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   return TAMD_OK;
 }
 
+#ifdef TAMD_DIAG
 // Diagnostic: C = A.B^T (bf16 row-major operands, no epilogue) on the ping-pong kernel while workgroup 0 writes
 // 8 shader-clock stamps per sub-tile and wave into `trace` (8 waves x 32 sub-tiles x 8 u64): tools/gemm_phase_trace.py
 extern "C" int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, void* trace,
@@ -723,6 +726,7 @@ extern "C" int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M,
                      TAMD_STREAM(stream), g);
   return launch_status();
 }
+#endif  // TAMD_DIAG
 
 // Split-K policy: a 256x256 tile grid that cannot fill the 256 CUs (weight gradients of narrow layers: dW of a
 // 768x3072 BERT projection is 36 tiles over K = tokens) is cut along K so that tiles x splits ~ one workgroup per CU,

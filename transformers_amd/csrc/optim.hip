@@ -70,16 +70,51 @@ __global__ void adamw_kernel(T* __restrict__ p, const T* __restrict__ g, S* __re
   }
 }
 
+__device__ __forceinline__ float load1(const bf16_t* q) { return bf16_bits_to_f32(q->bits); }
+__device__ __forceinline__ float load1(const f16_t* q) { return f16_bits_to_f32(q->bits); }
+__device__ __forceinline__ float load1(const float* q) { return *q; }
+__device__ __forceinline__ void store1(bf16_t* q, float f) { q->bits = f32_to_bf16_bits(f); }
+__device__ __forceinline__ void store1(f16_t* q, float f) { q->bits = f32_to_f16_bits(f); }
+__device__ __forceinline__ void store1(float* q, float f) { *q = f; }
+
+// elements [start, n) one per thread: the ragged tail (n % VE) of a tensor, or a whole tensor whose storage is not
+// 16-byte aligned (scalar parameters such as CLIP's logit_scale, a 2- or 3-label classifier bias)
+template <typename T, typename S>
+__global__ void adamw_scalar_kernel(T* __restrict__ p, const T* __restrict__ g, S* __restrict__ m, S* __restrict__ v,
+                                    int64_t start, int64_t n, float decay, float b1, float b2, float step_size,
+                                    float inv_bc2_sqrt, float eps, float grad_scale) {
+  for (int64_t idx = start + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = load1(g + idx) * grad_scale;
+    const float pd = load1(p + idx) * decay;
+    const float m0 = load1(m + idx), v0 = load1(v + idx);
+    const float mn = m0 + (1.f - b1) * (gi - m0);
+    const float vn = b2 * v0 + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vn) * inv_bc2_sqrt + eps;
+    store1(p + idx, pd - step_size * (mn / denom));
+    store1(m + idx, mn);
+    store1(v + idx, vn);
+  }
+}
+
 template <typename T, typename S>
 static int adamw_launch(void* p, const void* g, void* m, void* v, int64_t n, float decay, float b1, float b2,
                         float step_size, float inv_bc2_sqrt, float eps, float grad_scale, hipStream_t s) {
   constexpr int VE = vec16<T>::N < vec16<S>::N ? vec16<T>::N : vec16<S>::N;
-  if (n % VE != 0) return TAMD_E_SHAPE;
-  const int64_t threads = n / VE;
-  int64_t blocks = ceil_div(threads, 256);
-  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
-  hipLaunchKernelGGL((adamw_kernel<T, S>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)p, (const T*)g, (S*)m, (S*)v, n,
-                     decay, b1, b2, step_size, inv_bc2_sqrt, eps, grad_scale);
+  const bool vec_ok = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
+  const int64_t n_vec = vec_ok ? n - n % VE : 0;  // streamed 16 bytes per lane; the rest one element per thread
+  if (n_vec > 0) {
+    int64_t blocks = ceil_div(n_vec / VE, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 workgroups per CU
+    hipLaunchKernelGGL((adamw_kernel<T, S>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)p, (const T*)g, (S*)m, (S*)v,
+                       n_vec, decay, b1, b2, step_size, inv_bc2_sqrt, eps, grad_scale);
+  }
+  if (n_vec < n) {
+    int64_t blocks = ceil_div(n - n_vec, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL((adamw_scalar_kernel<T, S>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)p, (const T*)g, (S*)m,
+                       (S*)v, n_vec, n, decay, b1, b2, step_size, inv_bc2_sqrt, eps, grad_scale);
+  }
   return launch_status();
 }
 
@@ -93,7 +128,6 @@ extern "C" int tamd_adamw_step(void* p, const void* g, void* m, void* v, int64_t
   if (!p || !g || !m || !v) return TAMD_E_NULL;
   if (n <= 0) return TAMD_OK;
   if (step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return TAMD_E_ARG;
-  if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return TAMD_E_ALIGN;
   // bias corrections in double on the host, as torch does (torch/optim/adam.py: python floats)
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));

@@ -17,34 +17,6 @@ from torch import nn
 from . import ops
 
 
-class FusedLinearFn(torch.autograd.Function):
-    """y = x . Wf^T (+ bf), Wf = concat of the member weights.  Gradients go to the member parameters."""
-
-    @staticmethod
-    def forward(ctx, x, wf, bf, n_members, *members):
-        k = x.shape[-1]
-        x2 = ops._c(x).view(-1, k)
-        y = ops.raw_gemm(x2, wf, bias=bf, epilogue=ops.EPI_BIAS if bf is not None else ops.EPI_NONE)
-        ctx.save_for_backward(x2, wf)
-        ctx.splits = [m.shape[0] for m in members[:n_members]]
-        ctx.n_members = n_members
-        ctx.has_bias = bf is not None
-        ctx.x_shape = x.shape
-        return y.view(*x.shape[:-1], wf.shape[0])
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, wf = ctx.saved_tensors
-        dy2 = ops._c(dy).view(-1, wf.shape[0])
-        dx = ops.raw_gemm(dy2, wf, b_kn=True).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
-        dwf = ops.raw_gemm(dy2, x2, a_km=True, b_kn=True)
-        dws = list(torch.split(dwf, ctx.splits, dim=0))
-        dbs = []
-        if ctx.has_bias:
-            dbs = list(torch.split(ops.raw_colsum(dy2), ctx.splits, dim=0))
-        return (dx, None, None, None, *dws, *dbs)
-
-
 class FusedWeights:
     """Row-concatenation of several nn.Linear weights (and biases) kept coherent with the parameters."""
 
@@ -107,4 +79,4 @@ class FusedWeights:
         members = [lin.weight for lin in self.linears]
         if self.has_bias:
             members += [lin.bias for lin in self.linears]
-        return FusedLinearFn.apply(x, wf, self.bias(), len(self.linears), *members)
+        return ops.fused_linear(x, wf, self.bias(), members)

@@ -1,0 +1,150 @@
+"""Layer-level dispatcher ops: a whole reference block as ONE `torch.ops.tamd.*` call (one autograd node).
+
+    tamd::llama_layer / tamd::llama_layer_bwd    LlamaDecoderLayer.forward, models/llama/modeling_llama.py:295-324
+
+The implementations below are the op kernels: sequences of C-ABI launches (ops.raw_*) on the caller's stream.  The
+model classes in `transformers_amd/models/` only call `torch.ops.tamd.llama_layer(...)`.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import EPI_RESIDUAL, define_op
+
+T = torch.ops.tamd
+
+
+def _split_qkv(qkv, b, s, hq, hkv, d):
+    q = qkv[:, : hq * d].view(b, s, hq, d)
+    k = qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
+    v = qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
+    return q, k, v
+
+
+# forward : rmsnorm -> QKV GEMM -> rope(in place) -> attention -> o_proj GEMM(+residual)
+#           -> rmsnorm -> gate|up GEMM -> SwiGLU -> down GEMM(+residual)
+def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, eps,
+                      hq, hkv, d, scale, causal, train):
+    b, s, hd = h_in.shape
+    t = b * s
+    x = ops._c(h_in).view(t, hd)
+    xn, _, rstd1 = ops.raw_rmsnorm_fwd(x, w_ln1, eps)
+    qkv = ops.raw_gemm(xn, wqkv)
+    ops.raw_rope_(qkv, cos, sin, s, hq + hkv, d)
+    q, k, v = _split_qkv(qkv, b, s, hq, hkv, d)
+    o, lse = ops.raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=train, q_start=q_start)
+    h_mid = ops.raw_gemm(o.view(t, hq * d), wo, residual=x, epilogue=EPI_RESIDUAL)
+    xn2, _, rstd2 = ops.raw_rmsnorm_fwd(h_mid, w_ln2, eps)
+    gu = ops.raw_gemm(xn2, wgu)
+    act = ops.raw_swiglu_fwd(gu)
+    h_out = ops.raw_gemm(act, wd, residual=h_mid, epilogue=EPI_RESIDUAL).view(b, s, hd)
+    if not train:
+        e = h_out.new_empty(0)
+        return h_out, e, e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone()
+    return h_out, xn, qkv, o, lse, h_mid, xn2, gu, rstd1, rstd2
+
+
+def _llama_layer_fake(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, eps, hq,
+                      hkv, d, scale, causal, train):
+    b, s, hd = h_in.shape
+    t = b * s
+    h_out = h_in.new_empty(b, s, hd)
+    if not train:
+        return (h_out,) + tuple(h_in.new_empty(0) for _ in range(9))
+    f32 = dict(dtype=torch.float32)
+    return (h_out, h_in.new_empty(t, hd), h_in.new_empty(t, wqkv.shape[0]), h_in.new_empty(b, s, hq, d),
+            h_in.new_empty(b, hq, s, **f32), h_in.new_empty(t, hd), h_in.new_empty(t, hd),
+            h_in.new_empty(t, wgu.shape[0]), h_in.new_empty(t, **f32), h_in.new_empty(t, **f32))
+
+
+# backward: the derivatives of SURVEY.md section 8a in reverse; every weight gradient is a k-major GEMM on the saved
+# activations, the SiLU*up product is re-materialised instead of stored, and the residual-stream gradient is folded
+# into the RMSNorm backward kernels (`dres`).  Nothing saved by the forward is written (a retained graph can be
+# differentiated twice).
+def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o,
+                          lse, h_mid, rstd2, xn2, gu, hq, hkv, d, scale, causal):
+    b, s, hd = h_in.shape
+    t = b * s
+    x = ops._c(h_in).view(t, hd)
+    dh = ops._c(d_hout).view(t, hd)
+    # ---- MLP
+    d_act = ops.raw_gemm(dh, wd, b_kn=True)                                  # [T, I]
+    d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
+    del d_act
+    dwd = ops.raw_gemm(dh, act, a_km=True, b_kn=True)                        # [hd, I]
+    del act
+    d_xn2 = ops.raw_gemm(d_gu, wgu, b_kn=True)                               # [T, hd]
+    dwgu = ops.raw_gemm(d_gu, xn2, a_km=True, b_kn=True)                     # [2I, hd]
+    del d_gu
+    d_hmid, dw_ln2 = ops.raw_rmsnorm_bwd(d_xn2, h_mid, w_ln2, rstd2, dres=dh)
+    del d_xn2
+    # ---- attention
+    d_o = ops.raw_gemm(d_hmid, wo, b_kn=True)                                # [T, Hq*D]
+    dwo = ops.raw_gemm(d_hmid, o.view(t, hq * d), a_km=True, b_kn=True)
+    d_qkv = torch.empty_like(qkv)
+    q, k, v = _split_qkv(qkv, b, s, hq, hkv, d)
+    dq, dk, dv = _split_qkv(d_qkv, b, s, hq, hkv, d)
+    ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, hq, d), scale, causal, key_valid, dq=dq, dk=dk, dv=dv,
+                     q_start=q_start)
+    del d_o
+    ops.raw_rope_(d_qkv, cos, sin, s, hq + hkv, d, conj=True)
+    d_xn = ops.raw_gemm(d_qkv, wqkv, b_kn=True)
+    dwqkv = ops.raw_gemm(d_qkv, xn, a_km=True, b_kn=True)                    # [(Hq+2Hkv)D, hd]
+    d_hin, dw_ln1 = ops.raw_rmsnorm_bwd(d_xn, x, w_ln1, rstd1, dres=d_hmid)
+    return d_hin.view(b, s, hd), dw_ln1, dwqkv, dwo, dw_ln2, dwgu, dwd
+
+
+def _llama_layer_bwd_fake(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv,
+                          o, lse, h_mid, rstd2, xn2, gu, hq, hkv, d, scale, causal):
+    return (torch.empty_like(h_in, memory_format=torch.contiguous_format), torch.empty_like(w_ln1),
+            torch.empty_like(wqkv), torch.empty_like(wo), torch.empty_like(w_ln2), torch.empty_like(wgu),
+            torch.empty_like(wd))
+
+
+def _llama_layer_setup(ctx, inputs, output):
+    (h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, _wq, _wk, _wv, wo, w_ln2, wgu, _wg, _wu, wd, _eps, hq, hkv, d,
+     scale, causal, train) = inputs
+    _h_out, xn, qkv, o, lse, h_mid, xn2, gu, rstd1, rstd2 = output
+    ctx.save_for_backward(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse,
+                          h_mid, rstd2, xn2, gu)
+    ctx.meta = (hq, hkv, d, scale, causal, train)
+    ctx.set_materialize_grads(False)
+
+
+def _llama_layer_backward(ctx, d_hout, *_aux):
+    none = (None,) * 23
+    if d_hout is None:
+        return none
+    hq, hkv, d, scale, causal, train = ctx.meta
+    if not train:
+        raise ops.TamdError("llama_layer was run with train=False but is being differentiated")
+    d_hin, dw_ln1, dwqkv, dwo, dw_ln2, dwgu, dwd = T.llama_layer_bwd(d_hout, *ctx.saved_tensors, hq, hkv, d, scale,
+                                                                      causal)
+    nq, nk = hq * d, hkv * d
+    inter = dwgu.shape[0] // 2
+    #       h_in   cos   sin   kv    qs    w_ln1   wqkv  wq          wk                 wv               wo
+    return (d_hin, None, None, None, None, dw_ln1, None, dwqkv[:nq], dwqkv[nq:nq + nk], dwqkv[nq + nk:], dwo,
+            dw_ln2, None, dwgu[:inter], dwgu[inter:], dwd) + none[16:]
+
+
+define_op("llama_layer(Tensor h_in, Tensor cos, Tensor sin, Tensor? key_valid, Tensor? q_start, Tensor w_ln1, "
+          "Tensor wqkv, Tensor wq, Tensor wk, Tensor wv, Tensor wo, Tensor w_ln2, Tensor wgu, Tensor wg, Tensor wu, "
+          "Tensor wd, float eps, int hq, int hkv, int d, float scale, bool causal, bool train) -> "
+          "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+          _llama_layer_impl, _llama_layer_fake, _llama_layer_backward, _llama_layer_setup)
+define_op("llama_layer_bwd(Tensor d_hout, Tensor h_in, Tensor cos, Tensor sin, Tensor? key_valid, Tensor? q_start, "
+          "Tensor w_ln1, Tensor wqkv, Tensor wo, Tensor w_ln2, Tensor wgu, Tensor wd, Tensor rstd1, Tensor xn, "
+          "Tensor qkv, Tensor o, Tensor lse, Tensor h_mid, Tensor rstd2, Tensor xn2, Tensor gu, int hq, int hkv, int d, "
+          "float scale, bool causal) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+          _llama_layer_bwd_impl, _llama_layer_bwd_fake)
+
+
+def llama_layer(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, *, eps, hq,
+                hkv, d, scale, causal):
+    """LlamaDecoderLayer.forward as one op.  `wqkv` / `wgu` are the fused buffers the member parameters `wq, wk, wv` /
+    `wg, wu` are row-slice views of (fused_params.py): the kernels read the fused buffers, the gradients go to the
+    members."""
+    train = ops._wants_grad(h_in, w_ln1, wq, wk, wv, wo, w_ln2, wg, wu, wd)
+    return T.llama_layer(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd,
+                         float(eps), int(hq), int(hkv), int(d), float(scale), bool(causal), train)[0]

@@ -104,30 +104,6 @@ class TamdBertIntermediate(ref.BertIntermediate):
         return ops.linear(hidden_states, self.dense.weight, self.dense.bias, act=ops.ACT_CODES[act])
 
 
-class BertEmbeddingsFn(torch.autograd.Function):
-    """BertEmbeddings.forward (modeling_bert.py:68-108) as one kernel: 3 gathers + 2 adds + LayerNorm."""
-
-    @staticmethod
-    def forward(ctx, input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, padding_idx):
-        need = any(ctx.needs_input_grad)
-        out, pre, mean, rstd = ops.raw_bert_embeddings_fwd(input_ids, token_type_ids, position_ids, word, typ, pos,
-                                                           ln_w, ln_b, eps, keep_pre_ln=need)
-        if need:
-            ctx.save_for_backward(input_ids, token_type_ids, position_ids, pre, ln_w, mean, rstd)
-            ctx.meta = (word.shape[0], typ.shape[0], pos.shape[0], padding_idx)
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        input_ids, token_type_ids, position_ids, pre, ln_w, mean, rstd = ctx.saved_tensors
-        vocab, tvocab, npos, padding_idx = ctx.meta
-        d_pre, dw, db = ops.raw_layernorm_bwd(dy, pre, ln_w, mean, rstd)
-        d_word = ops.raw_embedding_bwd(input_ids, d_pre, vocab, padding_idx)
-        d_typ = ops.raw_embedding_bwd(token_type_ids, d_pre, tvocab, None)
-        d_pos = ops.raw_embedding_bwd(position_ids, d_pre, npos, None)
-        return None, None, None, d_word, d_typ, d_pos, dw, db, None, None
-
-
 class TamdBertEmbeddings(ref.BertEmbeddings):
     def forward(self, input_ids=None, token_type_ids=None, position_ids=None, inputs_embeds=None,
                 past_key_values_length=0):
@@ -144,9 +120,9 @@ class TamdBertEmbeddings(ref.BertEmbeddings):
             token_type_ids = torch.zeros_like(input_ids)
         position_ids = position_ids.expand(b, s)
         token_type_ids = token_type_ids.expand(b, s)
-        out = BertEmbeddingsFn.apply(input_ids, token_type_ids, position_ids, w, self.token_type_embeddings.weight,
-                                     self.position_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
-                                     float(self.LayerNorm.eps), self.word_embeddings.padding_idx)
+        out = ops.bert_embeddings(input_ids, token_type_ids, position_ids, w, self.token_type_embeddings.weight,
+                                  self.position_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias,
+                                  self.LayerNorm.eps, self.word_embeddings.padding_idx)
         return out if _no_dropout(self) else torch.nn.functional.dropout(out, self.dropout.p, True)
 
 

@@ -6,7 +6,7 @@ names / shapes / state_dict keys are untouched) and are swapped in post-construc
 `transformers_amd.accelerate` (`module.__class__ = ...`).
 
 Fusion levels, outermost first -- each falls back to the next when its preconditions fail:
-  TamdLlamaDecoderLayer   whole layer as ONE autograd node (LlamaLayerFn): 4 GEMMs, attention, 2 norms,
+  TamdLlamaDecoderLayer   whole layer as ONE op / autograd node (torch.ops.tamd.llama_layer): 4 GEMMs, attention, 2 norms,
                           rope and SwiGLU launches forward; residual adds live in GEMM epilogues.
   TamdLlamaAttention / TamdLlamaMLP / TamdLlamaRMSNorm   module-level replacements (fused QKV, fused gate|up).
 CPU tensors always take the reference's own forward (config 1, GPT-2 on CPU, must run unchanged).
@@ -17,9 +17,8 @@ import torch
 from torch import nn
 from transformers.models.llama import modeling_llama as ref
 
-from .. import ops
+from .. import layer_ops, ops
 from ..fused_params import FusedWeights
-from ..ops import EPI_RESIDUAL
 
 
 from .common import _has_hooks  # noqa: E402
@@ -49,10 +48,13 @@ class TamdLlamaMLP(ref.LlamaMLP):
         return fw
 
     def forward(self, x):
-        if not _on_gpu(x) or self.config.hidden_act not in ("silu", "swish") or self.gate_proj.bias is not None:
+        w = self.gate_proj.weight
+        if (not _on_gpu(x) or self.config.hidden_act not in ("silu", "swish") or self.gate_proj.bias is not None
+                or self.down_proj.bias is not None or x.dtype not in (torch.bfloat16, torch.float16)
+                or w.dtype != x.dtype or w.shape[0] % 8 or w.shape[1] % 8):
             return super().forward(x)
         gu = self._fused().linear(x)
-        act = ops.SwiGLUFn.apply(gu)
+        act = ops.swiglu(gu)
         return ops.linear(act, self.down_proj.weight)
 
 
@@ -81,7 +83,7 @@ class TamdLlamaAttention(ref.LlamaAttention):
         d = self.head_dim
         cos, sin = position_embeddings
         qkv = self._fused().linear(hidden_states)                       # [B, S, (Hq+2Hkv)*D]
-        qkv = ops.RopeFn.apply(qkv, cos, sin, hq + hkv, d)
+        qkv = ops.rope(qkv, cos, sin, hq + hkv, d)
         q = qkv[..., : hq * d].view(b, s, hq, d)
         k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d)
@@ -91,86 +93,6 @@ class TamdLlamaAttention(ref.LlamaAttention):
                           dropout_p=self.attention_dropout if self.training else 0.0, q_start=q_start)
         out = ops.linear(o.view(b, s, hq * d), self.o_proj.weight)
         return out, None
-
-
-class LlamaLayerFn(torch.autograd.Function):
-    """LlamaDecoderLayer.forward (modeling_llama.py:295-324) as one autograd node.
-
-    forward : rmsnorm -> QKV GEMM -> rope(in place) -> attention -> o_proj GEMM(+residual)
-              -> rmsnorm -> gate|up GEMM -> SwiGLU -> down GEMM(+residual)
-    backward: the derivatives of SURVEY.md §8a in reverse; every weight gradient is a k-major GEMM on the
-              saved activations, the SiLU*up product is re-materialised instead of stored, d(gate|up)
-              overwrites the saved gate|up buffer, and the residual-stream gradient is folded into the
-              RMSNorm backward kernels (`dres`).
-    """
-
-    @staticmethod
-    def forward(ctx, h_in, cos, sin, key_valid, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, meta,
-                q_start=None):
-        eps, hq, hkv, d, scale, causal = meta
-        b, s, hd = h_in.shape
-        t = b * s
-        x = h_in.contiguous().view(t, hd)
-        xn, _, rstd1 = ops.raw_rmsnorm_fwd(x, w_ln1, eps)
-        qkv = ops.raw_gemm(xn, wqkv)
-        ops.raw_rope_(qkv, cos, sin, s, hq + hkv, d)
-        q = qkv[:, : hq * d].view(b, s, hq, d)
-        k = qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
-        v = qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
-        need_grad = any(ctx.needs_input_grad)
-        o, lse = ops.raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need_grad, q_start=q_start)
-        h_mid = ops.raw_gemm(o.view(t, hq * d), wo, residual=x, epilogue=EPI_RESIDUAL)
-        xn2, _, rstd2 = ops.raw_rmsnorm_fwd(h_mid, w_ln2, eps)
-        gu = ops.raw_gemm(xn2, wgu)
-        act = ops.raw_swiglu_fwd(gu)
-        h_out = ops.raw_gemm(act, wd, residual=h_mid, epilogue=EPI_RESIDUAL)
-        if need_grad:
-            ctx.save_for_backward(x, cos, sin, key_valid, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse,
-                                  h_mid, rstd2, xn2, gu, q_start)
-            ctx.meta = meta
-            ctx.shape = (b, s, hd)
-        return h_out.view(b, s, hd)
-
-    @staticmethod
-    def backward(ctx, d_hout):
-        (x, cos, sin, key_valid, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse, h_mid, rstd2, xn2,
-         gu, q_start) = ctx.saved_tensors
-        eps, hq, hkv, d, scale, causal = ctx.meta
-        b, s, hd = ctx.shape
-        t = b * s
-        dh = d_hout.contiguous().view(t, hd)
-        # ---- MLP
-        d_act = ops.raw_gemm(dh, wd, b_kn=True)                                  # [T, I]
-        d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True, inplace=True)   # d_gu aliases gu
-        del d_act
-        dwd = ops.raw_gemm(dh, act, a_km=True, b_kn=True)                        # [hd, I]
-        del act
-        d_xn2 = ops.raw_gemm(d_gu, wgu, b_kn=True)                               # [T, hd]
-        dwgu = ops.raw_gemm(d_gu, xn2, a_km=True, b_kn=True)                     # [2I, hd]
-        d_hmid, dw_ln2 = ops.raw_rmsnorm_bwd(d_xn2, h_mid, w_ln2, rstd2, dres=dh)
-        del d_xn2
-        # ---- attention
-        o2 = o.view(t, hq * d)
-        d_o = ops.raw_gemm(d_hmid, wo, b_kn=True)                                # [T, Hq*D]
-        dwo = ops.raw_gemm(d_hmid, o2, a_km=True, b_kn=True)
-        d_qkv = torch.empty_like(qkv)
-        q = qkv[:, : hq * d].view(b, s, hq, d)
-        k = qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
-        v = qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
-        dq = d_qkv[:, : hq * d].view(b, s, hq, d)
-        dk = d_qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
-        dv = d_qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
-        ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, hq, d), scale, causal, key_valid, dq=dq, dk=dk, dv=dv,
-                         q_start=q_start)
-        del d_o
-        ops.raw_rope_(d_qkv, cos, sin, s, hq + hkv, d, conj=True)
-        d_xn = ops.raw_gemm(d_qkv, wqkv, b_kn=True)
-        dwqkv = ops.raw_gemm(d_qkv, xn, a_km=True, b_kn=True)                    # [(Hq+2Hkv)D, hd]
-        d_hin, dw_ln1 = ops.raw_rmsnorm_bwd(d_xn, x, w_ln1, rstd1, dres=d_hmid)
-        nq, nk = hq * d, hkv * d
-        inter = wgu.shape[0] // 2
-        return (d_hin.view(b, s, hd), None, None, None, dw_ln1, None, dwqkv[:nq], dwqkv[nq:nq + nk],
-                dwqkv[nq + nk:], dwo, dw_ln2, None, dwgu[:inter], dwgu[inter:], dwd, None, None)
 
 
 class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
@@ -197,12 +119,13 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
         from ..attention import split_mask
         key_valid, q_start = split_mask(attention_mask, b, s)
         qkv, gu = attn._fused(), mlp._fused()
-        meta = (float(self.input_layernorm.variance_epsilon), attn.config.num_attention_heads,
-                attn.config.num_key_value_heads, attn.head_dim, float(attn.scaling), bool(attn.is_causal) and s > 1)
-        return LlamaLayerFn.apply(hidden_states, cos, sin, key_valid, self.input_layernorm.weight, qkv.weight(),
-                                  attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight, attn.o_proj.weight,
-                                  self.post_attention_layernorm.weight, gu.weight(), mlp.gate_proj.weight,
-                                  mlp.up_proj.weight, mlp.down_proj.weight, meta, q_start)
+        return layer_ops.llama_layer(
+            hidden_states, cos, sin, key_valid, q_start, self.input_layernorm.weight, qkv.weight(),
+            attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight, attn.o_proj.weight,
+            self.post_attention_layernorm.weight, gu.weight(), mlp.gate_proj.weight, mlp.up_proj.weight,
+            mlp.down_proj.weight, eps=self.input_layernorm.variance_epsilon, hq=attn.config.num_attention_heads,
+            hkv=attn.config.num_key_value_heads, d=attn.head_dim, scale=attn.scaling,
+            causal=bool(attn.is_causal) and s > 1)
 
 
 def fused_causal_lm_forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,

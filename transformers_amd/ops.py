@@ -4,11 +4,15 @@ Three layers, all thin:
 
 1. ``raw_*``   -- one Python function per C-ABI entry point (include/tamd.h): argument checks,
                  output allocation with torch's caching allocator, launch on the *current* HIP
-                 stream of the calling thread.  No autograd.
-2. ``torch.ops.tamd.*`` -- the same functions registered with ``torch.library`` (the reference's own
-                 precedent: src/transformers/integrations/moe.py:245-257), with Meta ("fake")
-                 implementations so they compose with torch's tooling.
-3. ``*Fn``     -- ``torch.autograd.Function``s implementing the backward contract of SURVEY.md §8a.
+                 stream of the calling thread.  No autograd.  These are the IMPLEMENTATIONS of ...
+2. ``torch.ops.tamd.*`` -- ... the dispatcher ops (``torch.library``; the reference's own precedent is
+                 src/transformers/integrations/moe.py:245-257): kernel-level ops (``gemm``, ``attn_fwd``,
+                 ``rmsnorm_bwd`` ...) with fake (Meta) implementations, and differentiable ops (``linear``,
+                 ``attention``, ``rmsnorm``, ``llama_layer`` ...) whose backward -- the contract of SURVEY.md
+                 section 8a -- is attached with ``torch.library.register_autograd``.
+3. wrappers    -- ``ops.linear(...)``, ``ops.attention(...)`` ...: Python conveniences (default arguments, the
+                 "does anything need a gradient" flag) around ``torch.ops.tamd.*``.  The model code under
+                 ``transformers_amd/models/`` uses only these and ``torch.ops.tamd.*``.
 
 The HIP library is mandatory: there is no CPU or eager fallback in this module.  If libtamd.so is
 missing, or a tensor is not on a GPU, the call raises.
@@ -94,11 +98,39 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _prep(*tensors):
+    """Backend + operand checks: every operand on a GPU, all on ONE device; the launch runs with that device current
+    (a tensor of another device than torch's current one -- device_map pipelines, several GPUs in one process --
+    would otherwise be launched in the wrong device context)."""
     be = backend()
+    dev = None
     for t in tensors:
         if t is not None:
             be.check_tensor(t)
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise TamdError(f"tamd op operands live on different devices: {dev} and {t.device}")
+    if dev is not None and dev.type == "cuda" and dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)  # restored by `_device_guard` around the raw_* call
     return be
+
+
+def _device_guard(fn):
+    """Run a raw_* launcher with the operands' device current, restoring torch's current device afterwards."""
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(*args, **kwargs):
+        if not torch.cuda.is_available():
+            return fn(*args, **kwargs)
+        cur = torch.cuda.current_device()
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            if torch.cuda.current_device() != cur:
+                torch.cuda.set_device(cur)
+
+    return guarded
 
 
 def _c(t: torch.Tensor) -> torch.Tensor:
@@ -106,6 +138,7 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- raw ops
+@_device_guard
 def raw_rmsnorm_fwd(x, w, eps, residual=None):
     """-> (y, h, rstd); h is x+residual (or x itself when residual is None)."""
     cols = x.shape[-1]
@@ -122,6 +155,7 @@ def raw_rmsnorm_fwd(x, w, eps, residual=None):
     return y.view(x.shape), h.view(x.shape), rstd
 
 
+@_device_guard
 def raw_rmsnorm_bwd(dy, h, w, rstd, dres=None):
     cols = h.shape[-1]
     dy2, h2 = _c(dy).view(-1, cols), _c(h).view(-1, cols)
@@ -138,6 +172,7 @@ def raw_rmsnorm_bwd(dy, h, w, rstd, dres=None):
     return dx.view(h.shape), dw
 
 
+@_device_guard
 def raw_layernorm_fwd(x, w, b, eps, residual=None):
     cols = x.shape[-1]
     x2 = _c(x).view(-1, cols)
@@ -155,6 +190,7 @@ def raw_layernorm_fwd(x, w, b, eps, residual=None):
     return y.view(x.shape), h.view(x.shape), mean, rstd
 
 
+@_device_guard
 def raw_layernorm_bwd(dy, h, w, mean, rstd, dres=None, need_db=True):
     cols = h.shape[-1]
     dy2, h2 = _c(dy).view(-1, cols), _c(h).view(-1, cols)
@@ -173,6 +209,7 @@ def raw_layernorm_bwd(dy, h, w, mean, rstd, dres=None, need_db=True):
     return dx.view(h.shape), dw, db
 
 
+@_device_guard
 def raw_rope_(x2d, cos, sin, seq, nheads, head_dim, conj=False):
     """In-place rotary on the first `nheads` heads of every row of x2d [tokens, row_stride]."""
     be = _prep(x2d, cos, sin)
@@ -187,6 +224,7 @@ def raw_rope_(x2d, cos, sin, seq, nheads, head_dim, conj=False):
     return x2d
 
 
+@_device_guard
 def raw_embedding_fwd(ids, table):
     be = _prep(ids, table)
     ids_c = _c(ids)
@@ -200,6 +238,7 @@ def raw_embedding_fwd(ids, table):
     return out
 
 
+@_device_guard
 def raw_embedding_bwd(ids, dout, vocab, padding_idx=-1):
     be = _prep(ids, dout)
     dim = dout.shape[-1]
@@ -216,6 +255,7 @@ def raw_embedding_bwd(ids, dout, vocab, padding_idx=-1):
     return dtable
 
 
+@_device_guard
 def raw_bert_embeddings_fwd(input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, keep_pre_ln):
     be = _prep(input_ids, word, typ, pos, ln_w, ln_b)
     n = input_ids.numel()
@@ -235,6 +275,7 @@ def raw_bert_embeddings_fwd(input_ids, token_type_ids, position_ids, word, typ, 
     return out, pre, mean, rstd
 
 
+@_device_guard
 def raw_swiglu_fwd(gu):
     """gu [T, 2I] = [gate | up]  ->  act [T, I]"""
     be = _prep(gu)
@@ -247,6 +288,7 @@ def raw_swiglu_fwd(gu):
     return act
 
 
+@_device_guard
 def raw_swiglu_bwd(gu, dact, want_act=False, inplace=False):
     be = _prep(gu, dact)
     t, two_i = gu.shape
@@ -260,6 +302,7 @@ def raw_swiglu_bwd(gu, dact, want_act=False, inplace=False):
     return dgu, act
 
 
+@_device_guard
 def raw_bias_act_fwd(x, bias, act):
     x2 = _c(x).view(-1, x.shape[-1])
     be = _prep(x2, bias)
@@ -269,6 +312,7 @@ def raw_bias_act_fwd(x, bias, act):
     return y.view(x.shape)
 
 
+@_device_guard
 def raw_bias_act_bwd(x, bias, dy, act):
     x2, dy2 = _c(x).view(-1, x.shape[-1]), _c(dy).view(-1, x.shape[-1])
     be = _prep(x2, bias, dy2)
@@ -278,6 +322,7 @@ def raw_bias_act_bwd(x, bias, dy, act):
     return dx.view(x.shape)
 
 
+@_device_guard
 def raw_add(a, b):
     a, b = _c(a), _c(b)
     be = _prep(a, b)
@@ -286,6 +331,7 @@ def raw_add(a, b):
     return out
 
 
+@_device_guard
 def raw_adamw_step_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     """In-place fused AdamW step on one tensor (p, m, v updated); torch.optim.AdamW semantics, include/tamd.h."""
     be = _prep(p, g, m, v)
@@ -299,6 +345,7 @@ def raw_adamw_step_(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, gr
                                         _code(m), be.stream(p)), "tamd_adamw_step")
 
 
+@_device_guard
 def raw_colsum(x2d):
     be = _prep(x2d)
     rows, cols = x2d.shape
@@ -310,6 +357,7 @@ def raw_colsum(x2d):
     return out
 
 
+@_device_guard
 def raw_transpose(x2d):
     be = _prep(x2d)
     rows, cols = x2d.shape
@@ -319,6 +367,7 @@ def raw_transpose(x2d):
     return out
 
 
+@_device_guard
 def raw_cross_entropy_fwd(logits2d, labels, ignore_index=-100):
     be = _prep(logits2d, labels)
     t, v = logits2d.shape
@@ -330,6 +379,7 @@ def raw_cross_entropy_fwd(logits2d, labels, ignore_index=-100):
     return lse, row_loss
 
 
+@_device_guard
 def raw_cross_entropy_bwd(logits2d, labels, lse, gscale, ignore_index=-100):
     be = _prep(logits2d, labels, lse, gscale)
     t, v = logits2d.shape
@@ -363,6 +413,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int) -> int:
 GEMM_SCHED = {None: 0, "pp": 1 << 8, "fl": 3 << 8}  # diagnostic schedule hints (include/tamd.h)
 
 
+@_device_guard
 def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None,
              sched=None):
     """C[M,N] = epi(A . B^T).  a: [M,K] (or [K,M] if a_km); b: [N,K] (or [K,N] if b_kn)."""
@@ -413,6 +464,15 @@ def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=
     return p
 
 
+def _check_key_valid(key_valid, q, k):
+    """[batch, seq_k] key-validity plane (1 = attend): the kernels index it as key_valid[b * seq_k + key]."""
+    if key_valid is None:
+        return None
+    if tuple(key_valid.shape) != (q.shape[0], k.shape[1]):
+        raise TamdError(f"key_valid must be [batch, seq_k] = {(q.shape[0], k.shape[1])}, got {tuple(key_valid.shape)}")
+    return _c(key_valid.to(torch.uint8))
+
+
 def _check_q_start(q_start, q, causal):
     """packed sequences: int32 [2, B, S] = (first token of each query's sequence, last token of each key's sequence),
     include/tamd.h; build it with `packed_q_start`."""
@@ -425,6 +485,7 @@ def _check_q_start(q_start, q, causal):
     return _c(q_start)
 
 
+@_device_guard
 def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None, dropout_p=0.0, seed=0,
                  q_start=None):
     """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32."""
@@ -432,14 +493,14 @@ def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None
     b, sq, hq, d = q.shape
     o = out if out is not None else torch.empty(b, sq, hq, d, dtype=q.dtype, device=q.device)
     lse = torch.empty(b, hq, sq, dtype=torch.float32, device=q.device) if need_lse else None
-    if key_valid is not None:
-        key_valid = _c(key_valid.to(torch.uint8))
+    key_valid = _check_key_valid(key_valid, q, k)
     q_start = _check_q_start(q_start, q, causal)
     p = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start)
     be.lib.check(be.lib.tamd_attn_fwd(ctypes.byref(p), be.stream(q)), "tamd_attn_fwd")
     return o, lse
 
 
+@_device_guard
 def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, dk=None, dv=None,
                  dropout_p=0.0, seed=0, q_start=None):
     """Gradients written into dq/dk/dv (views with the strides of q/k/v) or freshly allocated."""
@@ -453,8 +514,7 @@ def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, 
     if dv is None:
         dv = torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
-    if key_valid is not None:
-        key_valid = _c(key_valid.to(torch.uint8))
+    key_valid = _check_key_valid(key_valid, q, k)
     delta = torch.empty((2,) + tuple(lse.shape), dtype=torch.float32, device=lse.device)  # delta | lse*log2(e)
     bp = _cabi.AttnBwdParams()
     q_start = _check_q_start(q_start, q, causal)
@@ -465,188 +525,677 @@ def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, 
     return dq, dk, dv
 
 
-# --------------------------------------------------------------------------- autograd functions
-class RMSNormFn(torch.autograd.Function):
-    """y = LlamaRMSNorm(x).  Reference: models/llama/modeling_llama.py:62-67."""
-
-    @staticmethod
-    def forward(ctx, x, w, eps):
-        y, h, rstd = raw_rmsnorm_fwd(x, w, eps, None)
-        ctx.save_for_backward(h, w, rstd)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        h, w, rstd = ctx.saved_tensors
-        dx, dw = raw_rmsnorm_bwd(dy, h, w, rstd)
-        return dx, dw, None
+# --------------------------------------------------------------------------- torch.ops.tamd.*
+# Every kernel entry point is a dispatcher op (`torch.ops.tamd.<name>`, CUDA key = HIP on ROCm) with a fake (Meta)
+# implementation; the differentiable ops additionally carry their backward through `torch.library.register_autograd`
+# -- the reference's own precedent for custom ops: src/transformers/integrations/moe.py:245-257.  The model code in
+# `transformers_amd/models/` only ever calls `torch.ops.tamd.*` (through the thin wrappers at the end of this file).
+# The "CPU" registrations are the same functions: with the product backend a CPU tensor raises TamdError in `_prep`
+# (there is no CPU implementation); tests/hipemu swaps in the CPU execution model of the kernels.
+_LIB = torch.library.Library("tamd", "DEF")
+T = torch.ops.tamd  # op namespace (attributes resolve lazily, after the definitions below)
 
 
-class AddRMSNormFn(torch.autograd.Function):
-    """h = x + residual; y = LlamaRMSNorm(h) -> (y, h): the residual add of LlamaDecoderLayer.forward
-    (modeling_llama.py:317,323) fused into the norm that follows it."""
-
-    @staticmethod
-    def forward(ctx, x, residual, w, eps):
-        y, h, rstd = raw_rmsnorm_fwd(x, w, eps, residual)
-        ctx.save_for_backward(h, w, rstd)
-        ctx.set_materialize_grads(False)
-        return y, h
-
-    @staticmethod
-    def backward(ctx, dy, dh):
-        h, w, rstd = ctx.saved_tensors
-        if dy is None:
-            return dh, dh, None, None
-        dx, dw = raw_rmsnorm_bwd(dy, h, w, rstd, dres=dh)
-        return dx, dx, dw, None
+def define_op(schema: str, impl, fake, backward=None, setup_context=None):
+    """Define `tamd::<name>`: schema + CUDA/CPU implementation + fake (Meta) + optional autograd formula."""
+    name = schema.split("(", 1)[0].strip()
+    _LIB.define(schema)
+    _LIB.impl(name, impl, "CUDA")
+    _LIB.impl(name, impl, "CPU")
+    torch.library.register_fake(f"tamd::{name}", fake, lib=_LIB)
+    if backward is not None:
+        torch.library.register_autograd(f"tamd::{name}", backward, setup_context=setup_context, lib=_LIB)
+    return name
 
 
-class LayerNormFn(torch.autograd.Function):
-    """y = nn.LayerNorm(x).  Call sites: models/bert/modeling_bert.py:62,106; gpt2 :252-254; clip :358-360."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, eps):
-        y, h, mean, rstd = raw_layernorm_fwd(x, w, b, eps, None)
-        ctx.save_for_backward(h, w, mean, rstd)
-        ctx.has_b = b is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        h, w, mean, rstd = ctx.saved_tensors
-        dx, dw, db = raw_layernorm_bwd(dy, h, w, mean, rstd, need_db=ctx.has_b)
-        return dx, dw, db, None
+def _rows(x):
+    return x.numel() // x.shape[-1]
 
 
-class AddLayerNormFn(torch.autograd.Function):
-    """y = LayerNorm(x + residual) -> (y, h): BertSelfOutput / BertOutput (modeling_bert.py:289-293, :347-351)."""
-
-    @staticmethod
-    def forward(ctx, x, residual, w, b, eps):
-        y, h, mean, rstd = raw_layernorm_fwd(x, w, b, eps, residual)
-        ctx.save_for_backward(h, w, mean, rstd)
-        ctx.has_b = b is not None
-        ctx.set_materialize_grads(False)
-        return y, h
-
-    @staticmethod
-    def backward(ctx, dy, dh):
-        h, w, mean, rstd = ctx.saved_tensors
-        if dy is None:
-            return dh, dh, None, None, None
-        dx, dw, db = raw_layernorm_bwd(dy, h, w, mean, rstd, dres=dh, need_db=ctx.has_b)
-        return dx, dx, dw, db, None
+def _f32(x, *shape):
+    return x.new_empty(shape, dtype=torch.float32)
 
 
+def _nothing(x):
+    """Placeholder for an absent tensor in an op's return tuple (op schemas cannot return `Tensor?`)."""
+    return x.new_empty(0)
+
+
+# ---- kernel-level ops (one per C-ABI entry point, no autograd) ---------------------------------------------
+def _rmsnorm_fwd_impl(x, w, eps, residual=None):
+    y, h, rstd = raw_rmsnorm_fwd(x, w, eps, residual)
+    return y, (h if residual is not None else _nothing(x)), rstd  # (an op output must not alias an input)
+
+
+define_op("rmsnorm_fwd(Tensor x, Tensor w, float eps, Tensor? residual=None) -> (Tensor, Tensor, Tensor)",
+          _rmsnorm_fwd_impl,
+          lambda x, w, eps, residual=None: (torch.empty_like(x),
+                                            torch.empty_like(x) if residual is not None else _nothing(x),
+                                            _f32(x, _rows(x))))
+define_op("rmsnorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor rstd, Tensor? dres=None) -> (Tensor, Tensor)",
+          raw_rmsnorm_bwd, lambda dy, h, w, rstd, dres=None: (torch.empty_like(h), torch.empty_like(w)))
+
+
+def _layernorm_fwd_impl(x, w, b, eps, residual=None):
+    y, h, mean, rstd = raw_layernorm_fwd(x, w, b, eps, residual)
+    return y, (h if residual is not None else _nothing(x)), mean, rstd
+
+
+define_op("layernorm_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor? residual=None) -> "
+          "(Tensor, Tensor, Tensor, Tensor)", _layernorm_fwd_impl,
+          lambda x, w, b, eps, residual=None: (torch.empty_like(x),
+                                               torch.empty_like(x) if residual is not None else _nothing(x),
+                                               _f32(x, _rows(x)), _f32(x, _rows(x))))
+
+
+def _layernorm_bwd_impl(dy, h, w, mean, rstd, dres=None, need_db=True):
+    dx, dw, db = raw_layernorm_bwd(dy, h, w, mean, rstd, dres, need_db)
+    return dx, dw, db if db is not None else _nothing(w)
+
+
+define_op("layernorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd, Tensor? dres=None, "
+          "bool need_db=True) -> (Tensor, Tensor, Tensor)", _layernorm_bwd_impl,
+          lambda dy, h, w, mean, rstd, dres=None, need_db=True: (torch.empty_like(h), torch.empty_like(w),
+                                                                 torch.empty_like(w) if need_db else _nothing(w)))
+
+
+def _rope_impl(x2d, cos, sin, seq, nheads, head_dim, conj=False):
+    raw_rope_(x2d, cos, sin, seq, nheads, head_dim, conj)
+
+
+define_op("rope_(Tensor(a!) x2d, Tensor cos, Tensor sin, int seq, int nheads, int head_dim, bool conj=False) -> ()",
+          _rope_impl, lambda x2d, cos, sin, seq, nheads, head_dim, conj=False: None)
+define_op("embedding_fwd(Tensor ids, Tensor table) -> Tensor", raw_embedding_fwd,
+          lambda ids, table: table.new_empty(*ids.shape, table.shape[1]))
+define_op("embedding_bwd(Tensor ids, Tensor dout, int vocab, int padding_idx=-1) -> Tensor", raw_embedding_bwd,
+          lambda ids, dout, vocab, padding_idx=-1: dout.new_empty(vocab, dout.shape[-1]))
+
+
+def _bert_embeddings_fwd_impl(input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, keep_pre_ln):
+    out, pre, mean, rstd = raw_bert_embeddings_fwd(input_ids, token_type_ids, position_ids, word, typ, pos, ln_w,
+                                                   ln_b, eps, keep_pre_ln)
+    return out, pre if pre is not None else _nothing(out), mean, rstd
+
+
+define_op("bert_embeddings_fwd(Tensor input_ids, Tensor token_type_ids, Tensor position_ids, Tensor word, Tensor typ, "
+          "Tensor pos, Tensor ln_w, Tensor ln_b, float eps, bool keep_pre_ln) -> (Tensor, Tensor, Tensor, Tensor)",
+          _bert_embeddings_fwd_impl,
+          lambda input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, keep_pre_ln: (
+              word.new_empty(*input_ids.shape, word.shape[1]),
+              word.new_empty(*input_ids.shape, word.shape[1]) if keep_pre_ln else _nothing(word),
+              _f32(word, input_ids.numel()), _f32(word, input_ids.numel())))
+define_op("swiglu_fwd(Tensor gu) -> Tensor", raw_swiglu_fwd, lambda gu: gu.new_empty(gu.shape[0], gu.shape[1] // 2))
+
+
+def _swiglu_bwd_impl(gu, dact, want_act=False):
+    dgu, act = raw_swiglu_bwd(gu, dact, want_act=want_act)
+    return dgu, act if act is not None else _nothing(gu)
+
+
+define_op("swiglu_bwd(Tensor gu, Tensor dact, bool want_act=False) -> (Tensor, Tensor)", _swiglu_bwd_impl,
+          lambda gu, dact, want_act=False: (torch.empty_like(gu), torch.empty_like(dact) if want_act else _nothing(gu)))
+define_op("bias_act_fwd(Tensor x, Tensor? bias, int act) -> Tensor", raw_bias_act_fwd,
+          lambda x, bias, act: torch.empty_like(x))
+define_op("bias_act_bwd(Tensor x, Tensor? bias, Tensor dy, int act) -> Tensor", raw_bias_act_bwd,
+          lambda x, bias, dy, act: torch.empty_like(x))
+define_op("add(Tensor a, Tensor b) -> Tensor", raw_add, lambda a, b: torch.empty_like(a))
+define_op("colsum(Tensor x2d) -> Tensor", raw_colsum, lambda x2d: x2d.new_empty(x2d.shape[1]))
+define_op("transpose(Tensor x2d) -> Tensor", raw_transpose, lambda x2d: x2d.new_empty(x2d.shape[1], x2d.shape[0]))
+define_op("cross_entropy_fwd(Tensor logits2d, Tensor labels, int ignore_index=-100) -> (Tensor, Tensor)",
+          raw_cross_entropy_fwd,
+          lambda logits2d, labels, ignore_index=-100: (_f32(logits2d, logits2d.shape[0]),
+                                                       _f32(logits2d, logits2d.shape[0])))
+define_op("cross_entropy_bwd(Tensor logits2d, Tensor labels, Tensor lse, Tensor gscale, int ignore_index=-100) -> Tensor",
+          raw_cross_entropy_bwd, lambda logits2d, labels, lse, gscale, ignore_index=-100: torch.empty_like(logits2d))
+
+
+def _adamw_impl(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    raw_adamw_step_(p, g, m, v, lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, step=step,
+                    grad_scale=grad_scale)
+
+
+define_op("adamw_step_(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, "
+          "float eps, float weight_decay, int step, float grad_scale=1.0) -> ()", _adamw_impl,
+          lambda p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0: None)
+
+
+def _gemm_shape(a, b, a_km, b_kn):
+    return (a.shape[1] if a_km else a.shape[0]), (b.shape[1] if b_kn else b.shape[0])
+
+
+def _gemm_impl(a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0):
+    return raw_gemm(a, b, a_km=a_km, b_kn=b_kn, bias=bias, residual=residual, epilogue=epilogue, act=act)
+
+
+def _gemm_out_impl(out, a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0):
+    raw_gemm(a, b, a_km=a_km, b_kn=b_kn, bias=bias, residual=residual, epilogue=epilogue, act=act, out=out)
+
+
+define_op("gemm(Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, Tensor? residual=None, "
+          "int epilogue=0, int act=0) -> Tensor", _gemm_impl,
+          lambda a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0: a.new_empty(
+              *_gemm_shape(a, b, a_km, b_kn)))
+define_op("gemm_out(Tensor(a!) out, Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, "
+          "Tensor? residual=None, int epilogue=0, int act=0) -> ()", _gemm_out_impl,
+          lambda out, a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0: None)
+
+
+def _attn_fwd_impl(q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None):
+    o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need_lse, dropout_p=dropout_p, seed=seed,
+                          q_start=q_start)
+    return o, lse if lse is not None else _nothing(q)
+
+
+define_op("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None, "
+          "bool need_lse=True, float dropout_p=0.0, int seed=0, Tensor? q_start=None) -> (Tensor, Tensor)",
+          _attn_fwd_impl,
+          lambda q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None: (
+              q.new_empty(q.shape), _f32(q, q.shape[0], q.shape[2], q.shape[1]) if need_lse else _nothing(q)))
+
+
+def _attn_bwd_impl(q, k, v, o, lse, dout, scale, causal, key_valid=None, dropout_p=0.0, seed=0, q_start=None):
+    return raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid, dropout_p=dropout_p, seed=seed,
+                        q_start=q_start)
+
+
+define_op("attn_bwd(Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor dout, float scale, bool causal, "
+          "Tensor? key_valid=None, float dropout_p=0.0, int seed=0, Tensor? q_start=None) -> (Tensor, Tensor, Tensor)",
+          _attn_bwd_impl,
+          lambda q, k, v, o, lse, dout, scale, causal, key_valid=None, dropout_p=0.0, seed=0, q_start=None: (
+              torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device),
+              torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device),
+              torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)))
+
+
+# ---- differentiable ops --------------------------------------------------------------------------------------
+# Convention: forward ops return what the backward needs as extra outputs (saved in `setup_context`); auxiliary
+# outputs never receive gradients (`set_materialize_grads(False)` -> None).  A `train` flag tells a forward op whether
+# anything will be differentiated (it runs below autograd and cannot see `requires_grad`).
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+# RMSNorm -- LlamaRMSNorm.forward, models/llama/modeling_llama.py:62-67
+def _rmsnorm_impl(x, w, eps):
+    y, _, rstd = raw_rmsnorm_fwd(x, w, eps, None)
+    return y, rstd
+
+
+def _rmsnorm_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], output[1])
+    ctx.set_materialize_grads(False)
+
+
+def _rmsnorm_backward(ctx, dy, _drstd):
+    if dy is None:
+        return None, None, None
+    x, w, rstd = ctx.saved_tensors
+    dx, dw = T.rmsnorm_bwd(dy, x, w, rstd)
+    return dx, dw, None
+
+
+define_op("rmsnorm(Tensor x, Tensor w, float eps) -> (Tensor, Tensor)", _rmsnorm_impl,
+          lambda x, w, eps: (torch.empty_like(x), _f32(x, _rows(x))), _rmsnorm_backward, _rmsnorm_setup)
+
+
+# h = x + residual; y = RMSNorm(h): the residual add of LlamaDecoderLayer.forward (modeling_llama.py:317,323)
+def _add_rmsnorm_impl(x, residual, w, eps):
+    return raw_rmsnorm_fwd(x, w, eps, residual)
+
+
+def _add_rmsnorm_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1], inputs[2], output[2])
+    ctx.set_materialize_grads(False)
+
+
+def _add_rmsnorm_backward(ctx, dy, dh, _drstd):
+    if dy is None:
+        return dh, dh, None, None
+    h, w, rstd = ctx.saved_tensors
+    dx, dw = T.rmsnorm_bwd(dy, h, w, rstd, dh)
+    return dx, dx, dw, None
+
+
+define_op("add_rmsnorm(Tensor x, Tensor residual, Tensor w, float eps) -> (Tensor, Tensor, Tensor)",
+          _add_rmsnorm_impl, lambda x, residual, w, eps: (torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x))),
+          _add_rmsnorm_backward, _add_rmsnorm_setup)
+
+
+# LayerNorm -- call sites models/bert/modeling_bert.py:62,106; gpt2 :252-254; clip :358-360
+def _layernorm_impl(x, w, b, eps):
+    y, _, mean, rstd = raw_layernorm_fwd(x, w, b, eps, None)
+    return y, mean, rstd
+
+
+def _layernorm_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], output[1], output[2])
+    ctx.has_b = inputs[2] is not None
+    ctx.set_materialize_grads(False)
+
+
+def _layernorm_backward(ctx, dy, _dm, _dr):
+    if dy is None:
+        return None, None, None, None
+    x, w, mean, rstd = ctx.saved_tensors
+    dx, dw, db = T.layernorm_bwd(dy, x, w, mean, rstd, None, ctx.has_b)
+    return dx, dw, (db if ctx.has_b else None), None
+
+
+define_op("layernorm(Tensor x, Tensor w, Tensor? b, float eps) -> (Tensor, Tensor, Tensor)", _layernorm_impl,
+          lambda x, w, b, eps: (torch.empty_like(x), _f32(x, _rows(x)), _f32(x, _rows(x))),
+          _layernorm_backward, _layernorm_setup)
+
+
+# y = LayerNorm(x + residual) -> (y, h): BertSelfOutput / BertOutput (modeling_bert.py:289-293, :347-351)
+def _add_layernorm_impl(x, residual, w, b, eps):
+    return raw_layernorm_fwd(x, w, b, eps, residual)
+
+
+def _add_layernorm_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1], inputs[2], output[2], output[3])
+    ctx.has_b = inputs[3] is not None
+    ctx.set_materialize_grads(False)
+
+
+def _add_layernorm_backward(ctx, dy, dh, _dm, _dr):
+    if dy is None:
+        return dh, dh, None, None, None
+    h, w, mean, rstd = ctx.saved_tensors
+    dx, dw, db = T.layernorm_bwd(dy, h, w, mean, rstd, dh, ctx.has_b)
+    return dx, dx, dw, (db if ctx.has_b else None), None
+
+
+define_op("add_layernorm(Tensor x, Tensor residual, Tensor w, Tensor? b, float eps) -> "
+          "(Tensor, Tensor, Tensor, Tensor)", _add_layernorm_impl,
+          lambda x, residual, w, b, eps: (torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x)),
+                                          _f32(x, _rows(x))), _add_layernorm_backward, _add_layernorm_setup)
+
+
+# y = act(x W^T + b) [+ residual] on the MFMA GEMM; dX and dW use the k-major operand modes (no HBM transposes).
+# nn.Linear call sites: see csrc/gemm.hip header.
+def _linear_impl(x, w, bias, residual, act, train):
+    k = x.shape[-1]
+    x2 = _c(x).view(-1, k)
+    epi, r2 = EPI_NONE, None
+    if act != ACT_NONE and (bias is None or residual is not None):
+        raise TamdError("activation epilogue needs a bias and no residual")
+    if residual is not None:
+        epi, r2 = EPI_RESIDUAL, _c(residual).view(-1, w.shape[0])
+    elif bias is not None and act != ACT_NONE:
+        epi = EPI_BIAS_ACT
+    elif bias is not None:
+        epi = EPI_BIAS
+    if epi == EPI_BIAS_ACT and train:
+        # keep the pre-activation for the backward: GEMM+bias, then the activation kernel
+        pre = raw_gemm(x2, w, bias=bias, epilogue=EPI_BIAS)
+        y = raw_bias_act_fwd(pre, None, act)
+    else:
+        pre = _nothing(x)
+        y = raw_gemm(x2, w, bias=bias, residual=r2, epilogue=epi, act=act)
+    return y.view(*x.shape[:-1], w.shape[0]), pre
+
+
+def _linear_setup(ctx, inputs, output):
+    x, w, bias, residual, act, _train = inputs
+    ctx.save_for_backward(x, w, output[1])
+    ctx.has_bias, ctx.has_res, ctx.act = bias is not None, residual is not None, act
+    ctx.set_materialize_grads(False)
+
+
+def _linear_backward(ctx, dy, _dpre):
+    if dy is None:
+        return None, None, None, None, None, None
+    x, w, pre = ctx.saved_tensors
+    n, k = w.shape
+    dy2 = _c(dy).view(-1, n)
+    dres = dy if ctx.has_res else None
+    if ctx.act != ACT_NONE:
+        if pre.numel() == 0:
+            raise TamdError("linear(act=...) was run with train=False but is being differentiated")
+        dy2 = T.bias_act_bwd(pre, None, dy2, ctx.act)
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        dx = T.gemm(dy2, w, False, True).view(x.shape)                      # dX = dY . W
+    if ctx.needs_input_grad[1]:
+        dw = T.gemm(dy2, _c(x).view(-1, k), True, True)                     # dW = dY^T . X
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+        db = T.colsum(dy2)
+    return dx, dw, db, dres, None, None
+
+
+define_op("linear(Tensor x, Tensor w, Tensor? bias, Tensor? residual, int act, bool train) -> (Tensor, Tensor)",
+          _linear_impl,
+          lambda x, w, bias, residual, act, train: (
+              x.new_empty(*x.shape[:-1], w.shape[0]),
+              x.new_empty(_rows(x), w.shape[0]) if (train and act != ACT_NONE) else _nothing(x)),
+          _linear_backward, _linear_setup)
+
+
+# y = x . Wf^T (+ bf), Wf = row-concatenation of the member weights (fused QKV / gate|up, fused_params.py).
+# Gradients go to the member parameters: one fused dW GEMM, each member receives its row slice.
+def _fused_linear_impl(x, wf, bf, members):
+    x2 = _c(x).view(-1, x.shape[-1])
+    y = raw_gemm(x2, wf, bias=bf, epilogue=EPI_BIAS if bf is not None else EPI_NONE)
+    return y.view(*x.shape[:-1], wf.shape[0])
+
+
+def _fused_linear_setup(ctx, inputs, output):
+    x, wf, bf, members = inputs
+    ctx.save_for_backward(x, wf)
+    ctx.has_bias = bf is not None
+    n_w = len(members) // 2 if bf is not None else len(members)
+    ctx.splits = [m.shape[0] for m in members[:n_w]]
+
+
+def _fused_linear_backward(ctx, dy):
+    x, wf = ctx.saved_tensors
+    dy2 = _c(dy).view(-1, wf.shape[0])
+    dx = T.gemm(dy2, wf, False, True).view(x.shape) if ctx.needs_input_grad[0] else None
+    grads = list(torch.split(T.gemm(dy2, _c(x).view(-1, x.shape[-1]), True, True), ctx.splits, dim=0))
+    if ctx.has_bias:
+        grads += list(torch.split(T.colsum(dy2), ctx.splits, dim=0))
+    return dx, None, None, grads
+
+
+define_op("fused_linear(Tensor x, Tensor wf, Tensor? bf, Tensor[] members) -> Tensor", _fused_linear_impl,
+          lambda x, wf, bf, members: x.new_empty(*x.shape[:-1], wf.shape[0]), _fused_linear_backward,
+          _fused_linear_setup)
+
+
+# y = x @ W + b with W stored [in, out] (GPT-2 Conv1D, pytorch_utils.py:117-121): the k-major B operand
+def _conv1d_impl(x, w, b):
+    x2 = _c(x).view(-1, x.shape[-1])
+    y = raw_gemm(x2, w, b_kn=True, bias=b, epilogue=EPI_BIAS if b is not None else EPI_NONE)
+    return y.view(*x.shape[:-1], w.shape[1])
+
+
+def _conv1d_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+    ctx.has_bias = inputs[2] is not None
+
+
+def _conv1d_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    dy2 = _c(dy).view(-1, w.shape[1])
+    dx = T.gemm(dy2, w).view(x.shape)                                       # dX = dY . W^T  (W is [N=in, K=out])
+    dw = T.gemm(_c(x).view(-1, x.shape[-1]), dy2, True, True)               # dW[in,out] = X^T . dY
+    return dx, dw, (T.colsum(dy2) if ctx.has_bias else None)
+
+
+define_op("conv1d(Tensor x, Tensor w, Tensor? b) -> Tensor", _conv1d_impl,
+          lambda x, w, b: x.new_empty(*x.shape[:-1], w.shape[1]), _conv1d_backward, _conv1d_setup)
+
+
+# Rotary embedding on the first `nheads` heads of a [B, S, row] projection output
+# (models/llama/modeling_llama.py:130-160).  Out of place at this level (autograd needs the input intact).
+def _rope_fn_impl(x, cos, sin, nheads, head_dim, conj=False):
+    b, s, row = x.shape
+    y = x.clone(memory_format=torch.contiguous_format)
+    raw_rope_(y.view(b * s, row), cos, sin, s, nheads, head_dim, conj=conj)
+    return y
+
+
+def _rope_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1], inputs[2])
+    ctx.meta = inputs[3:]
+
+
+def _rope_backward(ctx, dy):
+    cos, sin = ctx.saved_tensors
+    nheads, head_dim, conj = ctx.meta
+    return T.rope(dy, cos, sin, nheads, head_dim, not conj), None, None, None, None, None
+
+
+define_op("rope(Tensor x, Tensor cos, Tensor sin, int nheads, int head_dim, bool conj=False) -> Tensor", _rope_fn_impl,
+          lambda x, cos, sin, nheads, head_dim, conj=False: torch.empty_like(x, memory_format=torch.contiguous_format),
+          _rope_backward, _rope_setup)
+
+
+# softmax(scale QK^T + mask) V on [B,S,H,D] views.  Reference: eager_attention_forward,
+# models/llama/modeling_llama.py:191-213 and siblings.
+def _attention_impl(q, k, v, key_valid, scale, causal, dropout_p, seed, q_start, train):
+    o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=train, dropout_p=dropout_p, seed=seed,
+                          q_start=q_start)
+    return o, lse if lse is not None else _nothing(q)
+
+
+def _attention_setup(ctx, inputs, output):
+    q, k, v, key_valid, scale, causal, dropout_p, seed, q_start, _train = inputs
+    ctx.save_for_backward(q, k, v, output[0], output[1], key_valid, q_start)
+    ctx.meta = (scale, causal, dropout_p, seed)
+    ctx.set_materialize_grads(False)
+
+
+def _attention_backward(ctx, do, _dlse):
+    none = (None,) * 10
+    if do is None:
+        return none
+    q, k, v, o, lse, key_valid, q_start = ctx.saved_tensors
+    if lse.numel() == 0:
+        raise TamdError("attention was run with train=False but is being differentiated")
+    scale, causal, dropout_p, seed = ctx.meta
+    dq, dk, dv = T.attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid, dropout_p, seed, q_start)
+    return (dq, dk, dv) + none[3:]
+
+
+define_op("attention(Tensor q, Tensor k, Tensor v, Tensor? key_valid, float scale, bool causal, float dropout_p, "
+          "int seed, Tensor? q_start, bool train) -> (Tensor, Tensor)", _attention_impl,
+          lambda q, k, v, key_valid, scale, causal, dropout_p, seed, q_start, train: (
+              q.new_empty(q.shape), _f32(q, q.shape[0], q.shape[2], q.shape[1]) if train else _nothing(q)),
+          _attention_backward, _attention_setup)
+
+
+# act = silu(gate) * up on a fused [T, 2I] projection output (modeling_llama.py:174-176)
+def _swiglu_impl(gu):
+    shape = gu.shape
+    return raw_swiglu_fwd(_c(gu).view(-1, shape[-1])).view(*shape[:-1], shape[-1] // 2)
+
+
+def _swiglu_backward(ctx, dact):
+    (gu,) = ctx.saved_tensors
+    gu2 = _c(gu).view(-1, gu.shape[-1])
+    dgu, _ = T.swiglu_bwd(gu2, _c(dact).view(gu2.shape[0], -1), False)
+    return dgu.view(gu.shape)
+
+
+define_op("swiglu(Tensor gu) -> Tensor", _swiglu_impl, lambda gu: gu.new_empty(*gu.shape[:-1], gu.shape[-1] // 2),
+          _swiglu_backward, lambda ctx, inputs, output: ctx.save_for_backward(inputs[0]))
+
+
+def _bias_act_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+    ctx.act = inputs[2]
+
+
+def _bias_act_backward(ctx, dy):
+    x, bias = ctx.saved_tensors
+    dx = T.bias_act_bwd(x, bias, dy, ctx.act)
+    db = T.colsum(dx.view(-1, dx.shape[-1])) if bias is not None else None
+    return dx, db, None
+
+
+define_op("bias_act(Tensor x, Tensor? bias, int act) -> Tensor", raw_bias_act_fwd,
+          lambda x, bias, act: torch.empty_like(x), _bias_act_backward, _bias_act_setup)
+
+
+# nn.Embedding (models/llama/modeling_llama.py:381): bit-exact gather, sorted scatter-add backward
+def _embedding_impl(ids, table, padding_idx=-1):
+    return raw_embedding_fwd(ids, table)
+
+
+def _embedding_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0])
+    ctx.meta = (inputs[1].shape[0], inputs[2])
+
+
+def _embedding_backward(ctx, dout):
+    (ids,) = ctx.saved_tensors
+    vocab, padding_idx = ctx.meta
+    return None, T.embedding_bwd(ids, dout, vocab, padding_idx), None
+
+
+define_op("embedding(Tensor ids, Tensor table, int padding_idx=-1) -> Tensor", _embedding_impl,
+          lambda ids, table, padding_idx=-1: table.new_empty(*ids.shape, table.shape[1]), _embedding_backward,
+          _embedding_setup)
+
+
+# BertEmbeddings.forward (modeling_bert.py:68-108) as one kernel: 3 gathers + 2 adds + LayerNorm
+def _bert_embeddings_setup(ctx, inputs, output):
+    input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, _ln_b, _eps, padding_idx, _train = inputs
+    ctx.save_for_backward(input_ids, token_type_ids, position_ids, output[1], ln_w, output[2], output[3])
+    ctx.meta = (word.shape[0], typ.shape[0], pos.shape[0], padding_idx)
+    ctx.set_materialize_grads(False)
+
+
+def _bert_embeddings_backward(ctx, dy, _dpre, _dm, _dr):
+    none = (None,) * 11
+    if dy is None:
+        return none
+    input_ids, token_type_ids, position_ids, pre, ln_w, mean, rstd = ctx.saved_tensors
+    if pre.numel() == 0:
+        raise TamdError("bert_embeddings was run with train=False but is being differentiated")
+    vocab, tvocab, npos, padding_idx = ctx.meta
+    d_pre, dw, db = T.layernorm_bwd(dy, pre, ln_w, mean, rstd)
+    d_word = T.embedding_bwd(input_ids, d_pre, vocab, padding_idx)
+    d_typ = T.embedding_bwd(token_type_ids, d_pre, tvocab, -1)
+    d_pos = T.embedding_bwd(position_ids, d_pre, npos, -1)
+    return (None, None, None, d_word, d_typ, d_pos, dw, db, None, None, None)
+
+
+define_op("bert_embeddings(Tensor input_ids, Tensor token_type_ids, Tensor position_ids, Tensor word, Tensor typ, "
+          "Tensor pos, Tensor ln_w, Tensor ln_b, float eps, int padding_idx, bool train) -> "
+          "(Tensor, Tensor, Tensor, Tensor)",
+          lambda input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, padding_idx, train:
+          _bert_embeddings_fwd_impl(input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, train),
+          lambda input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, padding_idx, train: (
+              word.new_empty(*input_ids.shape, word.shape[1]),
+              word.new_empty(*input_ids.shape, word.shape[1]) if train else _nothing(word),
+              _f32(word, input_ids.numel()), _f32(word, input_ids.numel())),
+          _bert_embeddings_backward, _bert_embeddings_setup)
+
+
+# fixed_cross_entropy on `logits.float()` (loss/loss_utils.py:32-46) without materialising fp32 logits.
+# Returns the SUM of per-token losses; the caller divides (mean over valid labels or num_items_in_batch).
+def _cross_entropy_sum_impl(logits2d, labels, ignore_index=-100):
+    lse, row_loss = raw_cross_entropy_fwd(logits2d, labels, ignore_index)
+    return row_loss.sum(), lse
+
+
+def _cross_entropy_sum_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], output[1])
+    ctx.ignore_index = inputs[2]
+    ctx.set_materialize_grads(False)
+
+
+def _cross_entropy_sum_backward(ctx, g, _dlse):
+    if g is None:
+        return None, None, None
+    logits2d, labels, lse = ctx.saved_tensors
+    gs = g.detach().to(torch.float32).reshape(1).contiguous()
+    return T.cross_entropy_bwd(logits2d, labels, lse, gs, ctx.ignore_index), None, None
+
+
+define_op("cross_entropy_sum(Tensor logits2d, Tensor labels, int ignore_index=-100) -> (Tensor, Tensor)",
+          _cross_entropy_sum_impl,
+          lambda logits2d, labels, ignore_index=-100: (_f32(logits2d), _f32(logits2d, logits2d.shape[0])),
+          _cross_entropy_sum_backward, _cross_entropy_sum_setup)
+
+
+# lm_head + causal-LM loss without ever holding the [tokens, vocab] logits (SURVEY section 8 row f1; reference:
+# `logits = self.lm_head(hidden)` then ForCausalLMLoss, modeling_llama.py:477-484 / loss/loss_utils.py:49-71).
+# Tokens are processed in chunks: logits_c = h_c W^T (MFMA GEMM) -> cross-entropy forward (lse, per-token loss) ->
+# dlogits_c, already scaled by 1/normaliser -> dh_c = dlogits_c W and dW += dlogits_c^T h_c (accumulate epilogue).
+# The same three GEMMs as the unfused path, no recomputation; the gradients are produced in the forward and only
+# multiplied by the upstream scalar in the backward.  Peak extra memory: one chunk of logits instead of 2 x [T, V].
+# dW accumulates in the storage dtype across chunks (<= 8 roundings at the default chunking).
+def _linear_cross_entropy_impl(h2d, w, labels, normaliser, ignore_index, chunk, need_dh, need_dw):
+    t = h2d.shape[0]
+    gs = (1.0 / normaliser.to(torch.float32)).reshape(1).contiguous()
+    loss = torch.zeros((), dtype=torch.float32, device=h2d.device)
+    dh = torch.empty_like(h2d) if need_dh else _nothing(h2d)
+    dw = torch.empty_like(w) if need_dw else _nothing(w)
+    first = True
+    for c0 in range(0, t, chunk):
+        c1 = min(c0 + chunk, t)
+        hc, lc = h2d[c0:c1], labels[c0:c1]
+        logits = raw_gemm(hc, w)
+        lse, row_loss = raw_cross_entropy_fwd(logits, lc, ignore_index)
+        loss = loss + row_loss.sum()
+        if need_dh or need_dw:
+            dlog = raw_cross_entropy_bwd(logits, lc, lse, gs, ignore_index)
+            del logits
+            if need_dh:
+                raw_gemm(dlog, w, b_kn=True, out=dh[c0:c1])
+            if need_dw:
+                raw_gemm(dlog, hc, a_km=True, b_kn=True, epilogue=EPI_NONE if first else EPI_ACCUM, out=dw)
+            del dlog
+        first = False
+    return loss * gs[0], dh, dw
+
+
+def _linear_cross_entropy_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1], output[2])
+    ctx.set_materialize_grads(False)
+
+
+def _linear_cross_entropy_backward(ctx, g, _ddh, _ddw):
+    none = (None,) * 8
+    if g is None:
+        return none
+    dh, dw = ctx.saved_tensors
+    g = g.detach()
+    if (ctx.needs_input_grad[0] and dh.numel() == 0) or (ctx.needs_input_grad[1] and dw.numel() == 0):
+        raise TamdError("linear_cross_entropy: a gradient is requested that the forward was told not to produce")
+    return ((dh * g.to(dh.dtype)) if ctx.needs_input_grad[0] else None,
+            (dw * g.to(dw.dtype)) if ctx.needs_input_grad[1] else None) + none[2:]
+
+
+define_op("linear_cross_entropy(Tensor h2d, Tensor w, Tensor labels, Tensor normaliser, int ignore_index, int chunk, "
+          "bool need_dh, bool need_dw) -> (Tensor, Tensor, Tensor)", _linear_cross_entropy_impl,
+          lambda h2d, w, labels, normaliser, ignore_index, chunk, need_dh, need_dw: (
+              _f32(h2d), torch.empty_like(h2d) if need_dh else _nothing(h2d),
+              torch.empty_like(w) if need_dw else _nothing(w)),
+          _linear_cross_entropy_backward, _linear_cross_entropy_setup)
+
+
+# --------------------------------------------------------------------------- Python-level wrappers
 def rmsnorm(x, w, eps, residual=None):
     """-> y  (or (y, h) with h = x + residual when a residual is given)."""
     if residual is None:
-        return RMSNormFn.apply(x, w, eps)
-    return AddRMSNormFn.apply(x, residual, w, eps)
+        return T.rmsnorm(x, w, float(eps))[0]
+    y, h, _ = T.add_rmsnorm(x, residual, w, float(eps))
+    return y, h
 
 
 def layernorm(x, w, b, eps, residual=None):
     if residual is None:
-        return LayerNormFn.apply(x, w, b, eps)
-    return AddLayerNormFn.apply(x, residual, w, b, eps)
-
-
-class LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b) [+ residual] on the MFMA GEMM; dX and dW use the k-major operand modes
-    (no HBM transposes).  nn.Linear call sites: see csrc/gemm.hip header."""
-
-    @staticmethod
-    def forward(ctx, x, w, bias, residual, act):
-        k = x.shape[-1]
-        x2 = _c(x).view(-1, k)
-        epi, r2 = EPI_NONE, None
-        if residual is not None:
-            epi, r2 = EPI_RESIDUAL, _c(residual).view(-1, w.shape[0])
-        elif bias is not None and act != ACT_NONE:
-            epi = EPI_BIAS_ACT
-        elif bias is not None:
-            epi = EPI_BIAS
-        pre = None
-        if act != ACT_NONE and (bias is None or residual is not None):
-            raise TamdError("activation epilogue needs a bias and no residual")
-        if epi == EPI_BIAS_ACT and any(ctx.needs_input_grad[:3]):
-            # keep the pre-activation for the backward: GEMM+bias, then the activation kernel
-            pre = raw_gemm(x2, w, bias=bias, epilogue=EPI_BIAS)
-            y = raw_bias_act_fwd(pre, None, act)
-        else:
-            y = raw_gemm(x2, w, bias=bias, residual=r2, epilogue=epi, act=act)
-        ctx.save_for_backward(x2, w, pre)
-        ctx.has_bias, ctx.has_res, ctx.act = bias is not None, residual is not None, act
-        ctx.x_shape = x.shape
-        return y.view(*x.shape[:-1], w.shape[0])
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, w, pre = ctx.saved_tensors
-        n = w.shape[0]
-        dy2 = _c(dy).view(-1, n)
-        dres = dy if ctx.has_res else None
-        if pre is not None:
-            dy2 = raw_bias_act_bwd(pre, None, dy2, ctx.act)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = raw_gemm(dy2, w, b_kn=True).view(ctx.x_shape)          # dX = dY . W
-        if ctx.needs_input_grad[1]:
-            dw = raw_gemm(dy2, x2, a_km=True, b_kn=True)                # dW = dY^T . X
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = raw_colsum(dy2)
-        return dx, dw, db, dres, None
+        return T.layernorm(x, w, b, float(eps))[0]
+    y, h, _, _ = T.add_layernorm(x, residual, w, b, float(eps))
+    return y, h
 
 
 def linear(x, w, bias=None, residual=None, act=ACT_NONE):
-    return LinearFn.apply(x, w, bias, residual, act)
+    return T.linear(x, w, bias, residual, int(act), _wants_grad(x, w, bias, residual))[0]
 
 
-class RopeFn(torch.autograd.Function):
-    """Rotary embedding applied to the first `nheads` heads of a [B, S, row] projection output
-    (models/llama/modeling_llama.py:130-160).  Out of place at this level (autograd needs the input intact)."""
-
-    @staticmethod
-    def forward(ctx, x, cos, sin, nheads, head_dim):
-        b, s, row = x.shape
-        y = x.clone()
-        raw_rope_(y.view(b * s, row), cos, sin, s, nheads, head_dim, conj=False)
-        ctx.save_for_backward(cos, sin)
-        ctx.meta = (nheads, head_dim)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        cos, sin = ctx.saved_tensors
-        nheads, head_dim = ctx.meta
-        b, s, row = dy.shape
-        dx = dy.clone()
-        raw_rope_(dx.view(b * s, row), cos, sin, s, nheads, head_dim, conj=True)
-        return dx, None, None, None, None
+def fused_linear(x, wf, bf, members):
+    return T.fused_linear(x, wf, bf, list(members))
 
 
-class AttentionFn(torch.autograd.Function):
-    """softmax(scale QK^T + mask) V on [B,S,H,D] views.  Reference: eager_attention_forward,
-    models/llama/modeling_llama.py:191-213 and siblings."""
+def conv1d(x, w, b=None):
+    return T.conv1d(x, w, b)
 
-    @staticmethod
-    def forward(ctx, q, k, v, key_valid, scale, causal, dropout_p=0.0, seed=0, q_start=None):
-        need = any(ctx.needs_input_grad[:3])
-        o, lse = raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=need, dropout_p=dropout_p, seed=seed,
-                              q_start=q_start)
-        if need:
-            ctx.save_for_backward(q, k, v, o, lse, key_valid, q_start)
-        ctx.meta = (scale, causal, dropout_p, seed)
-        return o
 
-    @staticmethod
-    def backward(ctx, do):
-        q, k, v, o, lse, key_valid, q_start = ctx.saved_tensors
-        scale, causal, dropout_p, seed = ctx.meta
-        dq, dk, dv = raw_attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid, dropout_p=dropout_p, seed=seed,
-                                  q_start=q_start)
-        return dq, dk, dv, None, None, None, None, None, None
+def rope(x, cos, sin, nheads, head_dim):
+    return T.rope(x, cos, sin, int(nheads), int(head_dim))
+
+
+def swiglu(gu):
+    return T.swiglu(gu)
+
+
+def bias_act(x, bias, act):
+    return T.bias_act(x, bias, int(act))
 
 
 def dropout_seed() -> int:
@@ -677,7 +1226,8 @@ def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int,
 def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None, q_start=None):
     if dropout_p > 0.0 and seed is None:
         seed = dropout_seed()
-    return AttentionFn.apply(q, k, v, key_valid, scale, causal, float(dropout_p), int(seed or 0), q_start)
+    return T.attention(q, k, v, key_valid, float(scale), bool(causal), float(dropout_p), int(seed or 0), q_start,
+                       _wants_grad(q, k, v))[0]
 
 
 def packed_q_start(seq_ids: torch.Tensor) -> torch.Tensor:
@@ -695,75 +1245,12 @@ def packed_q_start(seq_ids: torch.Tensor) -> torch.Tensor:
     return torch.stack((start, end)).to(torch.int32).contiguous()
 
 
-class SwiGLUFn(torch.autograd.Function):
-    """act = silu(gate) * up on a fused [T, 2I] projection output (modeling_llama.py:174-176)."""
-
-    @staticmethod
-    def forward(ctx, gu):
-        shape = gu.shape
-        gu2 = _c(gu).view(-1, shape[-1])
-        ctx.save_for_backward(gu2)
-        ctx.shape = shape
-        return raw_swiglu_fwd(gu2).view(*shape[:-1], shape[-1] // 2)
-
-    @staticmethod
-    def backward(ctx, dact):
-        (gu2,) = ctx.saved_tensors
-        dgu, _ = raw_swiglu_bwd(gu2, _c(dact).view(gu2.shape[0], -1))
-        return dgu.view(ctx.shape)
-
-
-class BiasActFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, bias, act):
-        ctx.save_for_backward(x, bias)
-        ctx.act = act
-        return raw_bias_act_fwd(x, bias, act)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, bias = ctx.saved_tensors
-        dx = raw_bias_act_bwd(x, bias, dy, ctx.act)
-        db = raw_colsum(dx.view(-1, dx.shape[-1])) if bias is not None else None
-        return dx, db, None
-
-
-class EmbeddingFn(torch.autograd.Function):
-    """nn.Embedding (models/llama/modeling_llama.py:381): bit-exact gather, sorted scatter-add backward."""
-
-    @staticmethod
-    def forward(ctx, ids, table, padding_idx):
-        ctx.save_for_backward(ids)
-        ctx.meta = (table.shape[0], padding_idx)
-        return raw_embedding_fwd(ids, table)
-
-    @staticmethod
-    def backward(ctx, dout):
-        (ids,) = ctx.saved_tensors
-        vocab, padding_idx = ctx.meta
-        return None, raw_embedding_bwd(ids, dout, vocab, padding_idx), None
-
-
 def embedding(ids, table, padding_idx=None):
-    return EmbeddingFn.apply(ids, table, padding_idx)
+    return T.embedding(ids, table, -1 if padding_idx is None else int(padding_idx))
 
 
-class CrossEntropyFn(torch.autograd.Function):
-    """fixed_cross_entropy on `logits.float()` (loss/loss_utils.py:32-46) without materialising fp32 logits.
-    Returns the SUM of per-token losses; the caller divides (mean over valid labels or num_items_in_batch)."""
-
-    @staticmethod
-    def forward(ctx, logits2d, labels, ignore_index):
-        lse, row_loss = raw_cross_entropy_fwd(logits2d, labels, ignore_index)
-        ctx.save_for_backward(logits2d, labels, lse)
-        ctx.ignore_index = ignore_index
-        return row_loss.sum()
-
-    @staticmethod
-    def backward(ctx, g):
-        logits2d, labels, lse = ctx.saved_tensors
-        gs = g.detach().to(torch.float32).reshape(1).contiguous()
-        return raw_cross_entropy_bwd(logits2d, labels, lse, gs, ctx.ignore_index), None, None
+def cross_entropy_sum(logits2d, labels, ignore_index=-100):
+    return T.cross_entropy_sum(logits2d, labels, int(ignore_index))[0]
 
 
 def causal_lm_loss(logits, labels, vocab_size, num_items_in_batch=None, ignore_index=-100, shift_labels=None,
@@ -774,58 +1261,13 @@ def causal_lm_loss(logits, labels, vocab_size, num_items_in_batch=None, ignore_i
         shift_labels = labels[..., 1:].contiguous()
     logits2d = logits.reshape(-1, vocab_size)
     shift_labels = shift_labels.reshape(-1).to(logits.device)
-    total = CrossEntropyFn.apply(logits2d, shift_labels, ignore_index)
+    total = cross_entropy_sum(logits2d, shift_labels, ignore_index)
     if num_items_in_batch is not None:
         if torch.is_tensor(num_items_in_batch):
             num_items_in_batch = num_items_in_batch.to(total.device)
         return total / num_items_in_batch
     n_valid = (shift_labels != ignore_index).sum()
     return total / n_valid
-
-
-class FusedLinearCrossEntropyFn(torch.autograd.Function):
-    """lm_head + causal-LM loss without ever holding the [tokens, vocab] logits (reference:
-    `logits = self.lm_head(hidden)` then ForCausalLMLoss, modeling_llama.py / loss/loss_utils.py:49-71).
-
-    Tokens are processed in chunks: logits_c = h_c W^T (MFMA GEMM) -> cross-entropy forward (lse, per-token loss) ->
-    dlogits_c, already scaled by 1/normaliser -> dh_c = dlogits_c W and dW += dlogits_c^T h_c (accumulate epilogue).
-    The same three GEMMs as the unfused path, no recomputation; the gradients are produced in the forward and only
-    multiplied by the upstream scalar in the backward.  Peak extra memory: one chunk of logits instead of 2 x [T, V].
-    dW accumulates in the storage dtype across chunks (<= 8 roundings at the default chunking)."""
-
-    @staticmethod
-    def forward(ctx, h2d, w, labels, normaliser, ignore_index, chunk):
-        t, v = h2d.shape[0], w.shape[0]
-        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gs = (1.0 / normaliser.to(torch.float32)).reshape(1).contiguous()
-        loss = torch.zeros((), dtype=torch.float32, device=h2d.device)
-        dh = torch.empty_like(h2d) if need_h else None
-        dw = torch.empty_like(w) if need_w else None
-        first = True
-        for c0 in range(0, t, chunk):
-            c1 = min(c0 + chunk, t)
-            hc, lc = h2d[c0:c1], labels[c0:c1]
-            logits = raw_gemm(hc, w)
-            lse, row_loss = raw_cross_entropy_fwd(logits, lc, ignore_index)
-            loss = loss + row_loss.sum()
-            if need_h or need_w:
-                dlog = raw_cross_entropy_bwd(logits, lc, lse, gs, ignore_index)
-                del logits
-                if need_h:
-                    raw_gemm(dlog, w, b_kn=True, out=dh[c0:c1])
-                if need_w:
-                    raw_gemm(dlog, hc, a_km=True, b_kn=True, epilogue=EPI_NONE if first else EPI_ACCUM, out=dw)
-                del dlog
-            first = False
-        ctx.save_for_backward(dh, dw)
-        return loss * gs[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        dh, dw = ctx.saved_tensors
-        g = g.detach()
-        return (None if dh is None else dh * g.to(dh.dtype), None if dw is None else dw * g.to(dw.dtype), None, None,
-                None, None)
 
 
 def fused_linear_cross_entropy(hidden, weight, labels, num_items_in_batch=None, ignore_index=-100, shift=True,
@@ -845,53 +1287,13 @@ def fused_linear_cross_entropy(hidden, weight, labels, num_items_in_batch=None, 
         norm = torch.as_tensor(num_items_in_batch, device=hidden.device)
     else:
         norm = (labels != ignore_index).sum()
-    return FusedLinearCrossEntropyFn.apply(h2d, weight, labels, norm, ignore_index, int(chunk_tokens))
+    grad = torch.is_grad_enabled()
+    return T.linear_cross_entropy(h2d, weight, labels, norm, int(ignore_index), int(chunk_tokens),
+                                  grad and hidden.requires_grad, grad and weight.requires_grad)[0]
 
 
-# --------------------------------------------------------------------------- torch.ops registration
-_LIB = torch.library.Library("tamd", "DEF")
-_registered = False
-
-
-def _register():
-    """torch.ops.tamd.<name>: the raw kernels as dispatcher ops (CUDA key = HIP on ROCm) + Meta shapes."""
-    global _registered
-    if _registered:
-        return
-    _registered = True
-    defs = [
-        ("rmsnorm_fwd(Tensor x, Tensor w, float eps, Tensor? residual=None) -> (Tensor, Tensor, Tensor)",
-         raw_rmsnorm_fwd,
-         lambda x, w, eps, residual=None: (torch.empty_like(x), torch.empty_like(x),
-                                           x.new_empty(x.numel() // x.shape[-1], dtype=torch.float32))),
-        ("rmsnorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor rstd, Tensor? dres=None) -> (Tensor, Tensor)",
-         raw_rmsnorm_bwd, lambda dy, h, w, rstd, dres=None: (torch.empty_like(h), torch.empty_like(w))),
-        ("layernorm_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor? residual=None) -> "
-         "(Tensor, Tensor, Tensor, Tensor)", raw_layernorm_fwd,
-         lambda x, w, b, eps, residual=None: (torch.empty_like(x), torch.empty_like(x),
-                                              x.new_empty(x.numel() // x.shape[-1], dtype=torch.float32),
-                                              x.new_empty(x.numel() // x.shape[-1], dtype=torch.float32))),
-        ("swiglu_fwd(Tensor gu) -> Tensor", raw_swiglu_fwd,
-         lambda gu: gu.new_empty(gu.shape[0], gu.shape[1] // 2)),
-        ("embedding_fwd(Tensor ids, Tensor table) -> Tensor", raw_embedding_fwd,
-         lambda ids, table: table.new_empty(*ids.shape, table.shape[1])),
-        ("gemm(Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, Tensor? residual=None, "
-         "int epilogue=0, int act=0) -> Tensor",
-         lambda a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0: raw_gemm(
-             a, b, a_km=a_km, b_kn=b_kn, bias=bias, residual=residual, epilogue=epilogue, act=act),
-         lambda a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0: a.new_empty(
-             a.shape[1] if a_km else a.shape[0], b.shape[1] if b_kn else b.shape[0])),
-        ("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None) -> "
-         "(Tensor, Tensor)",
-         lambda q, k, v, scale, causal, key_valid=None: raw_attn_fwd(q, k, v, scale, causal, key_valid),
-         lambda q, k, v, scale, causal, key_valid=None: (
-             q.new_empty(q.shape), q.new_empty(q.shape[0], q.shape[2], q.shape[1], dtype=torch.float32))),
-    ]
-    for schema, impl, meta in defs:
-        _LIB.define(schema)
-        name = schema.split("(")[0]
-        _LIB.impl(name, impl, "CUDA")
-        _LIB.impl(name, meta, "Meta")
-
-
-_register()
+def bert_embeddings(input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, padding_idx=None):
+    """BertEmbeddings.forward (modeling_bert.py:68-108) minus the dropout: 3 gathers + 2 adds + LayerNorm, one kernel."""
+    train = _wants_grad(word, typ, pos, ln_w, ln_b)
+    return T.bert_embeddings(_c(input_ids), _c(token_type_ids), _c(position_ids), word, typ, pos, ln_w, ln_b,
+                             float(eps), -1 if padding_idx is None else int(padding_idx), train)[0]

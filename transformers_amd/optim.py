@@ -23,6 +23,24 @@ class TamdAdamW(torch.optim.Optimizer):
                         maximize=maximize)
         super().__init__(params, defaults)
 
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict casts every floating-point state tensor to its parameter's dtype: with
+        `fp32_moments=True` and bf16 parameters a resumed run would silently continue on bf16 moments.  Re-install the
+        checkpoint's moments in the dtype this optimizer is configured for."""
+        super().load_state_dict(state_dict)
+        saved = state_dict["state"]
+        ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        params = [p for g in self.param_groups for p in g["params"]]
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        for i, p in zip(ids, params):
+            if i not in saved or p not in self.state:
+                continue
+            want = torch.float32 if group_of[id(p)]["fp32_moments"] else p.dtype
+            for key in ("exp_avg", "exp_avg_sq"):
+                src = saved[i].get(key)
+                if torch.is_tensor(src) and self.state[p][key].dtype != want:
+                    self.state[p][key] = src.detach().to(device=p.device, dtype=want).clone()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -49,7 +67,7 @@ class TamdAdamW(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.is_contiguous():  # (fused-weight views are row slices of a contiguous buffer: contiguous)
                     raise RuntimeError("TamdAdamW needs contiguous parameters")
-                ops.raw_adamw_step_(p, g, st["exp_avg"], st["exp_avg_sq"], lr=lr, beta1=b1, beta2=b2, eps=group["eps"],
-                                    weight_decay=group["weight_decay"], step=int(st["step"].item()),
-                                    grad_scale=-1.0 if group["maximize"] else 1.0)
+                torch.ops.tamd.adamw_step_(p, g, st["exp_avg"], st["exp_avg_sq"], float(lr), float(b1), float(b2),
+                                           float(group["eps"]), float(group["weight_decay"]), int(st["step"].item()),
+                                           -1.0 if group["maximize"] else 1.0)
         return loss

@@ -58,7 +58,16 @@ def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bo
             raise TypeError("fused_lm_head_loss=True is implemented for LlamaForCausalLM")
         model.forward = types.MethodType(fused_causal_lm_forward, model)  # instance attribute: the class is untouched
     if attn_implementation and hasattr(model, "set_attn_implementation"):
-        model.set_attn_implementation(attention.ATTN_KEY)
+        dtypes = {p.dtype for p in model.parameters() if p.is_floating_point()}
+        if dtypes and not dtypes & {torch.bfloat16, torch.float16}:
+            # the kernels are bf16/fp16: an fp32 model keeps the attention backend it has (under autocast the
+            # registered function still accepts the fp32 q/k/v autocast leaves behind, attention.py)
+            import warnings
+
+            warnings.warn("transformers_amd.accelerate: fp32 model -- attn_implementation is left unchanged "
+                          "(the MI355X kernels run bf16/fp16; load with dtype=torch.bfloat16 to use them)")
+        else:
+            model.set_attn_implementation(attention.ATTN_KEY)
     # eager weight fusion (before DDP wraps the model)
     for m in model.modules():
         fuse = getattr(m, "_fused", None)
