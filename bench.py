@@ -2,14 +2,23 @@
 """Headline benchmark (BASELINE.json): fwd+bwd tokens/s of Llama-3-8B at seq 4096 on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          # self-launching: re-executes itself under torch.distributed.run
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # (what the driver does; both forms are the same run)
 
 A step = one forward + backward of `LlamaForCausalLM` (random-init Llama-3-8B architecture, bf16 weights,
 synthetic token ids, labels = ids, loss included) through the unchanged reference model classes with
 `transformers_amd.accelerate(model)` applied; per-GPU batch 8 x 4096 tokens (weak scaling: global batch 8N).
 With N > 1 the model is wrapped in torch DDP (what Trainer/accelerate do, src/transformers/trainer.py:1609-1635)
 and gradients are all-reduced over RCCL/xGMI, overlapped with the backward.
+
+`--config` selects the workload; the other BASELINE.json configurations print the same JSON schema:
+    llama3-8b (default)  BASELINE config 3/4, the headline metric
+    bert-base            BASELINE config 2: BertForMaskedLM fwd+bwd, batch 32 x seq 512, bf16, train mode (dropout 0.1)
+    llava                BASELINE config 5: LLaVA-1.5-7B-shaped forward, one 336x336 image + 512 text tokens
+    llama-tiny           debugging only
+`--fused-lm-head-loss` runs the Llama step with `accelerate(model, fused_lm_head_loss=True)` (SURVEY section 8 row f1:
+lm_head GEMM + loss chunk by chunk, no [tokens, vocab] logits): same FLOPs, same loss, ~17 GB less memory.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel family (the MFMA GEMM, csrc/gemm.hip): algorithmic FLOPs of its launches
@@ -22,6 +31,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -30,44 +41,71 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-import torch  # noqa: E402
-
+LLAMA3_8B = dict(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, max_position_embeddings=8192,
+                 rope_parameters={"rope_type": "default", "rope_theta": 500000.0})
 CONFIGS = {
-    # SURVEY.md §8 "L3": public Llama-3-8B config.json values
-    "llama3-8b": dict(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
-                      num_attention_heads=32, num_key_value_heads=8, rms_norm_eps=1e-5, max_position_embeddings=8192,
-                      rope_parameters={"rope_type": "default", "rope_theta": 500000.0}, batch=8, seq=4096),
+    # SURVEY.md section 8 "L3": public Llama-3-8B config.json values
+    "llama3-8b": dict(kind="llama", model=LLAMA3_8B, batch=8, seq=4096),
     # debugging only (never reported as the headline metric)
-    "llama-tiny": dict(vocab_size=4096, hidden_size=1024, intermediate_size=2816, num_hidden_layers=4,
-                       num_attention_heads=8, num_key_value_heads=2, rms_norm_eps=1e-5, max_position_embeddings=4096,
-                       rope_parameters={"rope_type": "default", "rope_theta": 500000.0}, batch=4, seq=2048),
+    "llama-tiny": dict(kind="llama", batch=4, seq=2048,
+                       model=dict(vocab_size=4096, hidden_size=1024, intermediate_size=2816, num_hidden_layers=4,
+                                  num_attention_heads=8, num_key_value_heads=2, rms_norm_eps=1e-5,
+                                  max_position_embeddings=4096,
+                                  rope_parameters={"rope_type": "default", "rope_theta": 500000.0})),
+    # SURVEY.md section 8 "BB": BertConfig() defaults = bert-base-uncased
+    "bert-base": dict(kind="bert", model={}, batch=32, seq=512),
+    # SURVEY.md section 8 "LV": CLIP ViT-L/14-336 + Llama-2-7B-shaped LLM, 576 image + 512 text positions, forward only
+    "llava": dict(kind="llava", batch=1, seq=1088,
+                  model=dict(vision=dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                                         num_attention_heads=16, image_size=336, patch_size=14),
+                             text=dict(vocab_size=32064, hidden_size=4096, intermediate_size=11008,
+                                       num_hidden_layers=32, num_attention_heads=32, num_key_value_heads=32,
+                                       max_position_embeddings=4096, rms_norm_eps=1e-5))),
 }
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+GEMM_TRAFFIC_FILES = ("r02_gemm_traffic.json", "r01_gemm_traffic.json")
 
 
-def flops_per_token(c) -> float:
-    """Algorithmic fwd+bwd FLOPs per token: 3 x forward; causal attention counted at half."""
-    h, i, l, v = c["hidden_size"], c["intermediate_size"], c["num_hidden_layers"], c["vocab_size"]
-    d = h // c["num_attention_heads"]
-    nq, nkv, s = c["num_attention_heads"] * d, c["num_key_value_heads"] * d, c["seq"]
-    per_layer = 2 * h * (nq + 2 * nkv) + 2 * nq * h + 3 * 2 * h * i + 4 * nq * s / 2
-    return 3.0 * (l * per_layer + 2 * h * v)
+def llama_flops_per_token(m, seq, backward=True) -> float:
+    """Algorithmic FLOPs per token: fwd+bwd = 3 x forward; causal attention counted at half."""
+    h, i, l, v = m["hidden_size"], m["intermediate_size"], m["num_hidden_layers"], m["vocab_size"]
+    d = h // m["num_attention_heads"]
+    nq, nkv = m["num_attention_heads"] * d, m["num_key_value_heads"] * d
+    per_layer = 2 * h * (nq + 2 * nkv) + 2 * nq * h + 3 * 2 * h * i + 4 * nq * seq / 2
+    return (3.0 if backward else 1.0) * (l * per_layer + 2 * h * v)
+
+
+def bert_flops_per_token(seq, h=768, i=3072, layers=12, vocab=30522) -> float:
+    """bert-base MLM fwd+bwd: 4 h^2 projections + 2 h*i MLP + bidirectional attention + the MLM head."""
+    per_layer = 2 * (4 * h * h + 2 * h * i) + 4 * h * seq
+    return 3.0 * (layers * per_layer + 2 * h * h + 2 * h * vocab)
+
+
+def llava_flops(c) -> float:
+    v, t = c["model"]["vision"], c["model"]["text"]
+    n_img = (v["image_size"] // v["patch_size"]) ** 2 + 1
+    hv, iv = v["hidden_size"], v["intermediate_size"]
+    clip = n_img * v["num_hidden_layers"] * (2 * (4 * hv * hv + 2 * hv * iv) + 4 * hv * n_img)
+    proj = (n_img - 1) * 2 * (hv * t["hidden_size"] + t["hidden_size"] ** 2)
+    return clip + proj + c["seq"] * llama_flops_per_token(t, c["seq"], backward=False)
 
 
 def gemm_traffic():
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); written by
     tools/prof_traffic.py into profiles/.  None when no profile of the current kernel is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        return {"unit": "bytes/launch", "hbm_bytes": t["hbm_bytes_per_launch"],
-                "fetch_bytes": t["fetch_bytes_per_launch"], "write_bytes": t["write_bytes_per_launch"],
-                "source": "profiles/r01_gemm_traffic.json"}
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in GEMM_TRAFFIC_FILES:
+        try:
+            with open(ROOT / "profiles" / name) as f:
+                t = json.load(f)
+            return {"unit": "bytes/launch", "hbm_bytes": t["hbm_bytes_per_launch"],
+                    "fetch_bytes": t["fetch_bytes_per_launch"], "write_bytes": t["write_bytes_per_launch"],
+                    "source": f"profiles/{name}"}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 class GemmTimer:
@@ -79,6 +117,8 @@ class GemmTimer:
         self.enabled = False
 
     def install(self):
+        import torch
+
         from transformers_amd import ops
 
         inner = ops.raw_gemm
@@ -96,8 +136,8 @@ class GemmTimer:
             timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n)))
             return out
 
+        # every caller (the torch.ops implementations in ops.py / layer_ops.py) looks `raw_gemm` up at call time
         ops.raw_gemm = timed_gemm
-        # modules captured `ops.raw_gemm` by attribute lookup at call time (ops.raw_gemm(...)), so this is enough
 
     def summary(self):
         if not self.records:
@@ -107,36 +147,72 @@ class GemmTimer:
         return dict(launches=len(self.records), flops=fl, ms=ms, bytes=sum(r[3] for r in self.records))
 
 
-def cpu_baseline(cfg_dict, threads=None):
-    """Reference eager path on the host cores: ONE decoder layer at (1, seq, hidden), bf16, fwd+bwd."""
+def cpu_baseline(model_cfg, seq, layers, threads=None, iters=3):
+    """Reference eager path on the host cores: ONE decoder layer at (1, seq, hidden), bf16, fwd+bwd, averaged."""
+    import torch
     from transformers import LlamaConfig
     from transformers.models.llama.modeling_llama import LlamaDecoderLayer, LlamaRotaryEmbedding
 
     threads = threads or os.cpu_count() or 1
     torch.set_num_threads(threads)
-    c = {k: v for k, v in cfg_dict.items() if k not in ("batch", "seq")}
-    cfg = LlamaConfig(**c, attn_implementation="eager")
-    seq = cfg_dict["seq"]
+    cfg = LlamaConfig(**model_cfg, attn_implementation="eager")
     torch.manual_seed(0)
     layer = LlamaDecoderLayer(cfg, 0).to(torch.bfloat16)
     rot = LlamaRotaryEmbedding(cfg)
-    x = torch.randn(1, seq, cfg.hidden_size, dtype=torch.bfloat16, requires_grad=True)
-    pos = torch.arange(seq)[None]
-    pe = rot(x, pos)
-    mask = torch.full((seq, seq), torch.finfo(torch.bfloat16).min, dtype=torch.bfloat16).triu(1)[None, None]
 
-    def step():
+    def make(s):
+        x = torch.randn(1, s, cfg.hidden_size, dtype=torch.bfloat16, requires_grad=True)
+        pe = rot(x, torch.arange(s)[None])
+        mask = torch.full((s, s), torch.finfo(torch.bfloat16).min, dtype=torch.bfloat16).triu(1)[None, None]
+        return x, pe, mask
+
+    def step(x, pe, mask):
         y = layer(x, attention_mask=mask, position_embeddings=pe)
         y.backward(torch.ones_like(y))
 
-    step()  # warm-up (allocator, thread pool)
-    t0 = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t0
-    layers = cfg_dict["num_hidden_layers"]
+    step(*make(min(seq, 512)))  # warm-up (allocator, thread pool) on a short sequence
+    args = make(seq)
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step(*args)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
     return dict(value=seq / (dt * layers), unit="tokens/s", cores=threads, kind="reference",
                 sample=(f"transformers eager LlamaDecoderLayer (Llama-3-8B dims) fwd+bwd, batch 1 x seq {seq}, bf16, "
-                        f"{dt:.2f} s/layer x {layers} layers extrapolated; embedding/lm_head/loss excluded"))
+                        f"mean of {iters} iterations ({', '.join(f'{t:.1f}' for t in times)} s) = {dt:.2f} s/layer x "
+                        f"{layers} layers extrapolated; embedding/lm_head/loss excluded"))
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def build_llama(c, dev, args):
+    import torch
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    import transformers_amd
+
+    cfg = LlamaConfig(**c["model"], attn_implementation="eager")
+    torch.manual_seed(0)  # identical weights on every rank
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    with torch.device(dev):
+        model = LlamaForCausalLM(cfg)
+    torch.set_default_dtype(old)
+    model.train()
+    transformers_amd.accelerate(model, fused_lm_head_loss=args.fused_lm_head_loss)
+    return model, cfg
 
 
 def main():
@@ -146,55 +222,113 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="llama3-8b", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fused-lm-head-loss", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="wrap in DDP over RCCL even with one rank (exercises init / bucket all-reduce / destroy)")
     ap.add_argument("--bucket-mb", type=int, default=int(os.environ.get("TAMD_DDP_BUCKET_MB", "256")))
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    ddp = world > 1 or args.force_ddp
+    if ddp:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not launched:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" on ROCm is RCCL
 
     import transformers_amd
-    from transformers import LlamaConfig, LlamaForCausalLM
 
     c = CONFIGS[args.config]
-    batch, seq = c["batch"], c["seq"]
-    cfg = LlamaConfig(**{k: v for k, v in c.items() if k not in ("batch", "seq")}, attn_implementation="eager")
-    torch.manual_seed(0)  # identical weights on every rank
-    old = torch.get_default_dtype()
-    torch.set_default_dtype(torch.bfloat16)
-    with torch.device(dev):
-        model = LlamaForCausalLM(cfg)
-    torch.set_default_dtype(old)
-    model.train()
-    transformers_amd.accelerate(model)
+    batch, seq, kind = c["batch"], c["seq"], c["kind"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)  # different synthetic data per rank
+    backward = True
+    if kind == "llama":
+        model, cfg = build_llama(c, dev, args)
+        ids = torch.randint(0, cfg.vocab_size, (batch, seq), device=dev, generator=g)
+        fwd = lambda net: net(input_ids=ids, labels=ids, use_cache=False)  # noqa: E731
+        flops_step = batch * seq * llama_flops_per_token(c["model"], seq)
+        workload = (f"{args.config}: LlamaForCausalLM fwd+bwd incl. lm_head + causal-LM loss"
+                    f"{' (fused lm_head+loss, no logits tensor)' if args.fused_lm_head_loss else ''}, "
+                    f"random-init bf16 weights, per-GPU batch {batch} x seq {seq}")
+        metric = f"fwd+bwd tokens/sec (whole job), {'Llama-3-8B' if args.config == 'llama3-8b' else args.config} seq={seq}"
+    elif kind == "bert":
+        from transformers import BertConfig, BertForMaskedLM
+
+        cfg = BertConfig(**c["model"], attn_implementation="eager")
+        torch.manual_seed(0)
+        model = BertForMaskedLM(cfg).to(torch.bfloat16).to(dev).train()
+        transformers_amd.accelerate(model)
+        ids = torch.randint(1000, cfg.vocab_size, (batch, seq), device=dev, generator=g)
+        labels = ids.clone()
+        labels[torch.rand(batch, seq, device=dev, generator=g) < 0.85] = -100  # MLM: 15 % of the positions are scored
+        fwd = lambda net: net(input_ids=ids, labels=labels)  # noqa: E731
+        flops_step = batch * seq * bert_flops_per_token(seq)
+        workload = (f"bert-base-uncased BertForMaskedLM fwd+bwd, random-init bf16, batch {batch} x seq {seq}, train mode "
+                    "(hidden/attention dropout 0.1 as shipped), attention_mask=None")
+        metric = "fwd+bwd tokens/sec (whole job), bert-base-uncased seq=512"
+    else:  # llava: forward only
+        from transformers import CLIPVisionConfig, LlamaConfig, LlavaConfig, LlavaForConditionalGeneration
+
+        backward = False
+        vcfg = CLIPVisionConfig(**c["model"]["vision"])
+        tcfg = LlamaConfig(**c["model"]["text"])
+        cfg = LlavaConfig(vision_config=vcfg, text_config=tcfg, image_token_id=32000, vision_feature_layer=-2,
+                          vision_feature_select_strategy="default", attn_implementation="eager")
+        torch.manual_seed(0)
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.bfloat16)
+        with torch.device(dev):
+            model = LlavaForConditionalGeneration(cfg)
+        torch.set_default_dtype(old)
+        model.eval()
+        transformers_amd.accelerate(model)
+        n_img = (vcfg.image_size // vcfg.patch_size) ** 2
+        txt = torch.randint(0, 31000, (1, seq - n_img), device=dev, generator=g)
+        ids = torch.cat([txt[:, :5], torch.full((1, n_img), 32000, device=dev), txt[:, 5:]], dim=1)
+        px = torch.randn(1, 3, vcfg.image_size, vcfg.image_size, device=dev, generator=g).bfloat16()
+        fwd = lambda net: net(input_ids=ids, pixel_values=px, use_cache=False)  # noqa: E731
+        flops_step = llava_flops(c)
+        workload = (f"LLaVA-1.5-7B-shaped LlavaForConditionalGeneration forward (no grad): CLIP ViT-L/14-336 tower "
+                    f"(hidden_states[-2]) + projector + Llama-2-7B-shaped LLM, one 336x336 image ({n_img} positions) + "
+                    f"{seq - n_img} text tokens, random-init bf16")
+        metric = "forward tokens/sec (whole job), LLaVA-1.5-7B 336px image + 512 text tokens"
+
     timer = GemmTimer()
     timer.install()
     net = model
-    if world > 1:
+    if ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
         net = DDP(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_mb, gradient_as_bucket_view=True,
                   broadcast_buffers=False, find_unused_parameters=False, static_graph=True)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)  # different synthetic data per rank
-    ids = torch.randint(0, cfg.vocab_size, (batch, seq), device=dev, generator=g)
 
     def step():
-        out = net(input_ids=ids, labels=ids, use_cache=False)
+        if not backward:
+            with torch.no_grad():
+                return fwd(net).logits[0, -1, 0].float()
+        out = fwd(net)
         out.loss.backward()
         model.zero_grad(set_to_none=True)
-        return out.loss
+        return out.loss.detach()
 
     def barrier():
         if world > 1:
@@ -218,7 +352,6 @@ def main():
     tokens = batch * seq * world * args.steps
     value = tokens / dt
     if rank == 0:
-        fpt = flops_per_token(c)
         gs = timer.summary()
         roofline = None
         if gs:
@@ -226,34 +359,33 @@ def main():
             roofline = dict(bound="mfma", kernel="tamd::gemm_fl_kernel (csrc/gemm.hip; forward, dX and dW layouts, "
                                                  "all epilogues; avg over the launches of a step)",
                             achieved=ach, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=ach / PEAK_BF16_TFLOPS,
-                            traffic=gemm_traffic(), launches_per_step=gs["launches"] // args.steps,
+                            traffic=gemm_traffic() if args.config == "llama3-8b" else None,
+                            launches_per_step=gs["launches"] // args.steps,
                             avg_launch_ms=gs["ms"] / gs["launches"],
                             avg_launch_tflop=gs["flops"] / gs["launches"] / 1e12,
                             avg_launch_algorithmic_bytes=gs["bytes"] / gs["launches"],
                             gemm_share_of_step_time=gs["ms"] * 1e-3 / dt)
         line = {
-            "metric": "fwd+bwd tokens/sec (whole job), Llama-3-8B seq=4096",
+            "metric": metric,
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: LlamaForCausalLM fwd+bwd incl. lm_head + causal-LM loss, "
-                                   f"random-init bf16 weights, per-GPU batch {batch} x seq {seq}",
-                       "model": args.config, "global_batch": batch * world, "seq_len": seq,
-                       "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "model": args.config, "global_batch": batch * world, "seq_len": seq,
+                       "parallelism": f"dp{world}" + (" (DDP over RCCL)" if ddp else "")},
             "tokens_per_sec_per_gpu": value / world,
-            "model_tflops_per_gpu": value / world * fpt / 1e12,
-            "mfu_vs_2500TF": value / world * fpt / (PEAK_BF16_TFLOPS * 1e12),
+            "model_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
+            "mfu_vs_2500TF": flops_step * args.steps / dt / (PEAK_BF16_TFLOPS * 1e12),
             "loss": float(loss),
             "max_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.config == "llama3-8b":
             try:
-                line["cpu_baseline"] = cpu_baseline(c)
+                line["cpu_baseline"] = cpu_baseline(c["model"], seq, c["model"]["num_hidden_layers"])
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if ddp:
         torch.distributed.destroy_process_group()
 
 
