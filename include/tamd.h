@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 3
+#define TAMD_ABI_VERSION 4
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -215,6 +215,22 @@ size_t tamd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags, int
 int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N, int64_t K,
                  int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act, int dtype,
                  void* workspace, size_t workspace_bytes, tamd_stream_t stream);
+
+/* The gate|up projection of LlamaMLP with the SiLU*up product in the GEMM epilogue
+ * (models/llama/modeling_llama.py:174-176: down_proj(act_fn(gate_proj(x)) * up_proj(x))):
+ *   GU[M, 2I]  = X[M, K] . Wgu[2I, K]^T      Wgu = [gate_proj.weight ; up_proj.weight] (rows), GU = gate | up columns
+ *   ACT[M, I]  = silu(gate) * up              rounded exactly as tamd_gemm followed by tamd_swiglu_fwd
+ * GU may be NULL (inference: the projection outputs are never written to HBM).  K % 64 == 0, I % 8 == 0. */
+int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* ACT, int64_t M, int64_t I, int64_t K, int64_t ldx,
+                     int64_t ldw, int64_t ldgu, int64_t ldact, int dtype, tamd_stream_t stream);
+
+/* Backward of that product fused into the GEMM that produces its incoming gradient (the dX product of down_proj):
+ *   d_act[M, I] = dY[M, K] . Wd[K, I]   with Wd = down_proj.weight as stored, [hidden = K, I]
+ *   DGU[M, 2I]  = d_gate | d_up,  ACT[M, I] = silu(gate) * up   from the saved GU[M, 2I] = gate | up
+ * d_act never reaches HBM; results are bit-identical to tamd_gemm (TAMD_GEMM_B_KN) followed by tamd_swiglu_bwd. */
+int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* DGU, void* ACT, int64_t M, int64_t I,
+                         int64_t K, int64_t lddy, int64_t ldw, int64_t ldgu, int64_t lddgu, int64_t ldact, int dtype,
+                         tamd_stream_t stream);
 
 /* ------------------------------------------------------------------ attention (MFMA, flash-style) */
 

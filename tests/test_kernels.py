@@ -8,7 +8,7 @@ import math
 import pytest
 import torch
 
-from conftest import max_err, rel_err
+from conftest import max_err, record, rel_err
 from transformers_amd import ops
 
 BF16_EPS = 2.0 ** -8
@@ -589,3 +589,51 @@ def test_attention_fully_masked_rows_are_zero(env):
     kv = torch.zeros(1, 64, dtype=torch.bool, device=dev)
     o, lse = ops.raw_attn_fwd(q, k, v, 0.125, False, kv)
     assert (o == 0).all() and torch.isinf(lse).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_swiglu_epilogue_is_bit_identical_to_unfused(env, dtype):
+    """gate|up GEMM with the SiLU*up product in the epilogue (tamd_gemm_swiglu) against the two-kernel path (tamd_gemm,
+    tamd_swiglu_fwd) it replaces in the fused Llama layer: same fp32 k-order, same rounding points -> same bits, for
+    gate|up and for act; ragged token counts, feature counts that are not a multiple of the 128-feature tile, and the
+    inference form that never writes gate|up."""
+    torch.manual_seed(31)
+    shapes = [(4096, 14336, 4096), (1000, 2816, 1024), (333, 1000, 512)] if env.big else [(130, 192, 64), (64, 72, 128)]
+    for t, inter, k in shapes:
+        x = torch.randn(t, k).to(dtype).to(env.device)
+        wgu = (torch.randn(2 * inter, k) * k ** -0.5).to(dtype).to(env.device)
+        assert ops.gemm_swiglu_supported(x, wgu)
+        gu_ref = ops.raw_gemm(x, wgu)
+        act_ref = ops.raw_swiglu_fwd(gu_ref)
+        gu, act = ops.raw_gemm_swiglu(x, wgu, need_gu=True)
+        assert torch.equal(gu, gu_ref), (t, inter, k)
+        assert torch.equal(act, act_ref), (t, inter, k)
+        none, act2 = ops.raw_gemm_swiglu(x, wgu, need_gu=False)
+        assert none is None and torch.equal(act2, act_ref)
+        # against the fp32 formula of the reference (modeling_llama.py:174-176) on the same rounded inputs
+        g32, u32 = (x.float() @ wgu.float().t()).split(inter, dim=1)
+        want = torch.nn.functional.silu(g32) * u32
+        err = rel_err(act, want)
+        record("gemm_swiglu", f"{dtype}:{t}x{inter}x{k}", err)
+        assert err < 6e-3
+    o, a = torch.ops.tamd.gemm_swiglu(x, wgu, True)
+    assert torch.equal(o, gu_ref) and torch.equal(a, act_ref)
+
+
+def test_gemm_swiglu_bwd_epilogue_is_bit_identical_to_unfused(env):
+    """dX product of down_proj with the SwiGLU backward in its epilogue (tamd_gemm_swiglu_bwd) against the two-kernel
+    path (tamd_gemm with the k-major B operand, tamd_swiglu_bwd): d_gate | d_up and the re-materialised act, same bits."""
+    torch.manual_seed(32)
+    shapes = [(4096, 14336, 4096), (1000, 2816, 1024), (333, 1000, 512)] if env.big else [(130, 192, 64), (64, 72, 128)]
+    for t, inter, hd in shapes:
+        dy = torch.randn(t, hd).bfloat16().to(env.device)
+        wd = (torch.randn(hd, inter) * inter ** -0.5).bfloat16().to(env.device)
+        gu = torch.randn(t, 2 * inter).bfloat16().to(env.device)
+        assert ops.gemm_swiglu_bwd_supported(dy, wd, gu)
+        d_act = ops.raw_gemm(dy, wd, b_kn=True)
+        dgu_ref, act_ref = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
+        dgu, act = ops.raw_gemm_swiglu_bwd(dy, wd, gu)
+        assert torch.equal(dgu, dgu_ref), (t, inter, hd)
+        assert torch.equal(act, act_ref), (t, inter, hd)
+    a, b = torch.ops.tamd.gemm_swiglu_bwd(dy, wd, gu)
+    assert torch.equal(a, dgu_ref) and torch.equal(b, act_ref)

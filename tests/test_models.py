@@ -553,7 +553,7 @@ def test_full_size_layer_matches_fp32_reference():
     pos = torch.arange(s)[None]
 
     def run_reference(layer, dtype):
-        xr = x.to(dtype).requires_grad_(True)
+        xr = x.detach().to(dtype).clone().requires_grad_(True)  # (a fresh leaf: .to() of the same dtype returns x itself)
         pe = rot(xr, pos)
         mask = torch.full((s, s), torch.finfo(dtype).min, dtype=dtype).triu(1)[None, None]
         y = layer(xr, attention_mask=mask, position_embeddings=pe)
@@ -575,7 +575,7 @@ def test_full_size_layer_matches_fp32_reference():
         if hasattr(m, "config"):
             m.config = fcfg
     assert type(fast).__name__ == "TamdLlamaDecoderLayer"
-    xf = x.to(dev).requires_grad_(True)
+    xf = x.detach().to(dev).requires_grad_(True)
     pe = rot.to(dev)(xf, pos.to(dev))
     assert fast._fused_ok(xf, None)
     yf = fast(xf, position_embeddings=pe)

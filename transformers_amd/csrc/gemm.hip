@@ -62,8 +62,22 @@ struct GemmArgs {
   // [s*stages_per_split, ...) and writes an fp32 partial tile to ws[s][M][N]; splitk_reduce_kernel sums and rounds
   float* ws;
   int splits, stages_per_split;
+  // SwiGLU epilogue (kEpiSwiGLU): B = [gate rows (n_half) ; up rows (n_half)], C2 = act [M, n_half] (ldc2), C = the
+  // [M, 2*n_half] gate|up output or nullptr when nothing will be differentiated
+  void* C2;
+  int64_t ldc2, n_half;
 };
 constexpr int kEpiSplitK = 100;
+constexpr int kEpiSwiGLU = 101;
+constexpr int kEpiSwiGLUBwd = 102;
+
+// the LlamaMLP inner product (models/llama/modeling_llama.py:174-176; same expression as swiglu_fwd_kernel in
+// elementwise.hip, so the fused epilogue and the stand-alone kernel agree bit for bit)
+__device__ __forceinline__ float gemm_silu(float x) { return x * (1.f / (1.f + __expf(-x))); }
+__device__ __forceinline__ float gemm_dsilu(float x) {  // = dsilu_f in elementwise.hip
+  const float sg = 1.f / (1.f + __expf(-x));
+  return sg * (1.f + x * (1.f - sg));
+}
 
 template <int ACT>
 __device__ __forceinline__ float gemm_act(float x) {
@@ -195,6 +209,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
       const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
       const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
       u32x4 v = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)slot * 16u);
+      if (EPI == kEpiSwiGLUBwd) {
+        // v = d_act[gm_, gn..gn+7] (rounded, as the two-kernel path stores it); R = the saved gate|up [M, 2I]:
+        // d_gate | d_up -> C [M, 2I], act = silu(gate)*up re-materialised -> C2 [M, I]   (swiglu_bwd_kernel's formulas)
+        if (gm_ < g.M && gn < g.N) {
+          float d[8], gt[8], up[8], dg[8], du[8], ac[8];
+          unpack16<T>(v, d);
+          unpack16<T>(ld16(R + gm_ * g.ldr + gn), gt);
+          unpack16<T>(ld16(R + gm_ * g.ldr + g.n_half + gn), up);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float sl = round_through<T>(gemm_silu(gt[e]));
+            du[e] = d[e] * sl;
+            dg[e] = round_through<T>(d[e] * up[e]) * gemm_dsilu(gt[e]);
+            ac[e] = sl * up[e];
+          }
+          st16(C + gm_ * g.ldc + gn, pack16<T>(dg));
+          st16(C + gm_ * g.ldc + g.n_half + gn, pack16<T>(du));
+          st16(reinterpret_cast<T*>(g.C2) + gm_ * g.ldc2 + gn, pack16<T>(ac));
+        }
+        continue;
+      }
       if (gm_ < g.M && gn < g.N) {
         if (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) {
           const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
@@ -207,6 +242,68 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
         }
         st16(C + gm_ * g.ldc + gn, v);
       }
+    }
+    wave_lockstep_point();
+  }
+}
+
+// SwiGLU epilogue of one wave of gemm_fl_kernel<..., kEpiSwiGLU>.  The tile's 256 B-rows are 8 blocks of 32 weight rows,
+// alternately from the gate and the up half of the fused [2*I, K] weight (block b: feature block b>>1, part b&1), so
+// a wave's four 32-column accumulators are (gate, up) x 2 feature blocks with identical lane layouts:
+//     act = round(round(silu(round(g))) * round(u))          lane-local, the roundings of the unfused path
+// Per 64 output rows: stage [gate 64 | up 64] and [act 64] in this wave's LDS region, then full 128-byte row segments
+// to C[m, f0..] (gate), C[m, I + f0..] (up) -- skipped when C == nullptr -- and C2[m, f0..] (act).
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x16 (&acc)[4][4], char* smem, unsigned st_off,
+                                                     int64_t row0, int64_t f0, int lane) {
+  constexpr int GU_ROWB = 128 * 2 + 16, ACT_ROWB = 64 * 2 + 16;
+  constexpr unsigned ACT_OFF = 64u * GU_ROWB;
+  const int hi = lane >> 5, l31 = lane & 31;
+  T* C = reinterpret_cast<T*>(g.C);
+  T* C2 = reinterpret_cast<T*>(g.C2);
+  const int64_t I = g.n_half;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int nl = p * 32 + 8 * qd + 4 * hi;  // first of 4 consecutive local features
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const int mi = half * 2 + m2;
+          float gg[4], uu[4], aa[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            gg[e] = round_through<T>(acc[2 * p][mi][qd * 4 + e]);
+            uu[e] = round_through<T>(acc[2 * p + 1][mi][qd * 4 + e]);
+            aa[e] = round_through<T>(gemm_silu(gg[e])) * uu[e];
+          }
+          const unsigned r = (unsigned)(m2 * 32 + l31);
+          lds_write8(smem, st_off + r * GU_ROWB + (unsigned)nl * 2u, u32x2{pack2<T>(gg[0], gg[1]), pack2<T>(gg[2], gg[3])});
+          lds_write8(smem, st_off + r * GU_ROWB + (unsigned)(64 + nl) * 2u,
+                     u32x2{pack2<T>(uu[0], uu[1]), pack2<T>(uu[2], uu[3])});
+          lds_write8(smem, st_off + ACT_OFF + r * ACT_ROWB + (unsigned)nl * 2u,
+                     u32x2{pack2<T>(aa[0], aa[1]), pack2<T>(aa[2], aa[3])});
+        }
+      }
+    }
+    wave_lockstep_point();
+    if (C != nullptr) {
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {  // 64 rows x 16 slots of 16 B: 4 rows per wave instruction
+        const int row = it * 4 + (lane >> 4), slot = lane & 15;
+        const int64_t gm_ = row0 + half * 64 + row, f = f0 + (slot & 7) * 8;
+        const u32x4 v = lds_read16(smem, st_off + (unsigned)row * GU_ROWB + (unsigned)slot * 16u);
+        if (gm_ < g.M && f < I) st16(C + gm_ * g.ldc + (slot >= 8 ? I : 0) + f, v);
+      }
+    }
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {  // 64 rows x 8 slots: 8 rows per wave instruction
+      const int row = it * 8 + (lane >> 3), slot = lane & 7;
+      const int64_t gm_ = row0 + half * 64 + row, f = f0 + slot * 8;
+      const u32x4 v = lds_read16(smem, st_off + ACT_OFF + (unsigned)row * ACT_ROWB + (unsigned)slot * 16u);
+      if (gm_ < g.M && f < I) st16(C2 + gm_ * g.ldc2 + f, v);
     }
     wave_lockstep_point();
   }
@@ -369,7 +466,8 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   int64_t kinc_b = B_KN ? (int64_t)kXK * g.ldb * 2 : kXK * 2;
   // operand bases (tile origin - 4096 B so that no lane offset goes negative after the immediate is taken out)
   const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096 + (int64_t)st0 * kinc_a;
-  const char* base_b = (const char*)(B_KN ? B + n0 : B + n0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
+  const int64_t nb0 = (EPI == kEpiSwiGLU) ? 0 : n0;  // SwiGLU: per-lane offsets address the whole fused weight
+  const char* base_b = (const char*)(B_KN ? B + n0 : B + nb0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (wave * 8 + i) * 8 + (lane >> 3);
@@ -379,9 +477,14 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     const int64_t gca = (m0 + col < g.M) ? m0 + col : g.M - 8;
     const int64_t ra = (m0 + row < g.M) ? m0 + row : g.M - 1;
     const int64_t gcb = (n0 + col < g.N) ? n0 + col : g.N - 8;
-    const int64_t rb = (n0 + row < g.N) ? n0 + row : g.N - 1;
+    int64_t rb = (n0 + row < g.N) ? n0 + row : g.N - 1;
+    if (EPI == kEpiSwiGLU) {  // tile row -> row of the fused [gate ; up] weight (see gemm_epilogue_swiglu)
+      int64_t feat = (n0 >> 1) + ((row >> 6) << 5) + (row & 31);
+      if (feat >= g.n_half) feat = g.n_half - 1;
+      rb = ((row >> 5) & 1) * g.n_half + feat;
+    }
     const int64_t oa = A_KM ? (int64_t)kr * g.lda + (gca - m0) : (ra - m0) * g.lda + c * 8;
-    const int64_t ob = B_KN ? (int64_t)kr * g.ldb + (gcb - n0) : (rb - n0) * g.ldb + c * 8;
+    const int64_t ob = B_KN ? (int64_t)kr * g.ldb + (gcb - n0) : (rb - nb0) * g.ldb + c * 8;
     voff[i] = (unsigned)(oa * 2 + 4096 - (i & 3) * 1024);
     voff[8 + i] = (unsigned)(ob * 2 + 4096 - (i & 3) * 1024);
   }
@@ -550,7 +653,12 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     }
     return;
   }
-  gemm_epilogue<T, (EPI == kEpiSplitK ? TAMD_EPI_NONE : EPI), ACT, 4, 4>(
+  if (EPI == kEpiSwiGLU) {
+    gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), m0 + wm * 128,
+                            (n0 >> 1) + wn * 64, lane);
+    return;
+  }
+  gemm_epilogue<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT, 4, 4>(
       g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, lane);
 }
 
@@ -708,6 +816,9 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->ws = nullptr;
   g->splits = 1;
   g->stages_per_split = 0;
+  g->C2 = nullptr;
+  g->ldc2 = 0;
+  g->n_half = 0;
   return TAMD_OK;
 }
 
@@ -799,5 +910,56 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
   } else {
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   }
+  return TAMD_E_DTYPE;
+}
+
+// gate|up projection of LlamaMLP with the SiLU*up product in the GEMM epilogue (models/llama/modeling_llama.py:174-176):
+//   GU[M, 2I] = X[M,K] . Wgu[2I,K]^T  (gate columns | up columns; skipped when GU == NULL),  ACT[M, I] = silu(gate) * up
+// with the roundings of the unfused path (tamd_gemm then tamd_swiglu_fwd): results are bit-identical to it.
+extern "C" int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* ACT, int64_t M, int64_t I, int64_t K,
+                                int64_t ldx, int64_t ldw, int64_t ldgu, int64_t ldact, int dtype, tamd_stream_t stream) {
+  if (!X || !Wgu || !ACT) return TAMD_E_NULL;
+  if (M <= 0 || I <= 0 || K <= 0) return TAMD_E_SHAPE;
+  if ((K % kXK) || (I % 8) || (ldx % 8) || (ldw % 8) || (ldact % 8) || (GU && (ldgu % 8))) return TAMD_E_SHAPE;
+  if (!aligned16(X) || !aligned16(Wgu) || !aligned16(ACT) || (GU && !aligned16(GU))) return TAMD_E_ALIGN;
+  if ((int64_t)2 * I * ldw * 2 >= ((int64_t)1 << 31)) return TAMD_E_SHAPE;  // 32-bit buffer offsets over the fused weight
+  GemmArgs g;
+  gemm_fill_args(&g, X, Wgu, GU, nullptr, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 0);
+  g.tiles_n = (int)ceil_div(I, kBN / 2);  // 128 features (gate + up columns) per 256-wide tile
+  g.C2 = ACT;
+  g.ldc2 = ldact;
+  g.n_half = I;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
+  TAMD_DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, kEpiSwiGLU, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
+                       TAMD_STREAM(stream), g);
+    return launch_status();
+  });
+  return TAMD_E_DTYPE;
+}
+
+// Backward of the SwiGLU product fused into the GEMM that produces its incoming gradient:
+//   d_act[M, I] = dY[M, K] . Wd[K, I]    (Wd = down_proj.weight stored [hidden = K, I]: the k-major B operand)
+//   d_gate | d_up -> DGU[M, 2I],  act = silu(gate) * up -> ACT[M, I] (re-materialised for the down_proj weight gradient)
+// from the saved gate|up GU[M, 2I]; d_act never reaches HBM.  Formulas and roundings of tamd_gemm (B_KN) followed by
+// tamd_swiglu_bwd: bit-identical results.
+extern "C" int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* DGU, void* ACT, int64_t M,
+                                    int64_t I, int64_t K, int64_t lddy, int64_t ldw, int64_t ldgu, int64_t lddgu,
+                                    int64_t ldact, int dtype, tamd_stream_t stream) {
+  if (!dY || !Wd || !GU || !DGU || !ACT) return TAMD_E_NULL;
+  if (M <= 0 || I <= 0 || K <= 0) return TAMD_E_SHAPE;
+  if ((K % kXK) || (I % 8) || (lddy % 8) || (ldw % 8) || (ldgu % 8) || (lddgu % 8) || (ldact % 8)) return TAMD_E_SHAPE;
+  if (!aligned16(dY) || !aligned16(Wd) || !aligned16(GU) || !aligned16(DGU) || !aligned16(ACT)) return TAMD_E_ALIGN;
+  GemmArgs g;
+  gemm_fill_args(&g, dY, Wd, DGU, nullptr, GU, M, I, K, lddy, ldw, lddgu, ldgu);
+  g.C2 = ACT;
+  g.ldc2 = ldact;
+  g.n_half = I;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
+  TAMD_DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((gemm_fl_kernel<T, false, true, kEpiSwiGLUBwd, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
+                       TAMD_STREAM(stream), g);
+    return launch_status();
+  });
   return TAMD_E_DTYPE;
 }

@@ -246,14 +246,41 @@ __global__ __launch_bounds__(kNormThreads) void norm_bwd_kernel(const T* __restr
   }
 }
 
-// partial [P, cols] fp32  ->  out [cols] T
+// partial [P, cols] fp32  ->  out [cols] T.  One workgroup per 16 columns: 64 row groups x 4 column quads, each thread
+// sums P/64 rows with 16-byte loads, the row groups are combined through LDS in a fixed order (deterministic).
+// (The first version walked all P rows on one thread per column: 16 workgroups and a 512-deep serial chain, 120-140 us
+// per call -- a third of the bert-base step and 9 ms of the Llama-3-8B one, profiles/r02_bert_kernel_stats_before.csv.)
+constexpr int kColsumCols = 16, kColsumGroups = 64;
 template <typename T>
-__global__ void colsum_f32_kernel(const float* __restrict__ part, T* __restrict__ out, int P, int cols) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= cols) return;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += part[(int64_t)p * cols + col];
-  reinterpret_cast<typename elem<T>::raw*>(out)[col] = elem<T>::from_f32(s);
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ part, T* __restrict__ out, int P,
+                                                         int cols) {
+  __shared__ float sm[kColsumGroups][kColsumCols + 1];
+  const int cq = threadIdx.x & 3, rg = threadIdx.x >> 2;
+  const int col = blockIdx.x * kColsumCols + cq * 4;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < cols) {  // cols % 4 == 0 (16-byte vectors of the storage type): the quad is valid as a whole
+    for (int p = rg; p < P; p += kColsumGroups) {
+      const u32x4 v = ld16(part + (int64_t)p * cols + col);
+      a0 += u32_as_f32(v[0]);
+      a1 += u32_as_f32(v[1]);
+      a2 += u32_as_f32(v[2]);
+      a3 += u32_as_f32(v[3]);
+    }
+  }
+  sm[rg][cq * 4 + 0] = a0;
+  sm[rg][cq * 4 + 1] = a1;
+  sm[rg][cq * 4 + 2] = a2;
+  sm[rg][cq * 4 + 3] = a3;
+  block_sync();
+  if (threadIdx.x < kColsumCols) {
+    const int c = blockIdx.x * kColsumCols + (int)threadIdx.x;
+    if (c < cols) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int g = 0; g < kColsumGroups; ++g) s += sm[g][threadIdx.x];
+      reinterpret_cast<typename elem<T>::raw*>(out)[c] = elem<T>::from_f32(s);
+    }
+  }
 }
 
 // x [rows, cols] (ld) T -> partial [P, cols] fp32 ; each thread owns one 16-byte column vector
@@ -365,7 +392,7 @@ static int norm_bwd_dispatch(const void* dy, const void* h, const void* w, const
   if (!launched) return TAMD_E_SHAPE;
   int st = launch_status();
   if (st != TAMD_OK) return st;
-  dim3 g2((unsigned)ceil_div(cols, 256)), b2(256);
+  dim3 g2((unsigned)ceil_div(cols, kColsumCols)), b2(256);
   hipLaunchKernelGGL((colsum_f32_kernel<T>), g2, b2, 0, s, dwp, (T*)dw, P, (int)cols);
   if (LN && db != nullptr) hipLaunchKernelGGL((colsum_f32_kernel<T>), g2, b2, 0, s, dbp, (T*)db, P, (int)cols);
   return launch_status();
@@ -453,7 +480,7 @@ int tamd_colsum(const void* x, void* out, void* workspace, size_t workspace_byte
     dim3 g1((unsigned)ceil_div(cols / VE, 256), (unsigned)P), b1(256);
     hipLaunchKernelGGL((colsum_stage1_kernel<T>), g1, b1, 0, s, (const T*)x, part, rows, (int)cols, ld,
                        rows_per_slab);
-    dim3 g2((unsigned)ceil_div(cols, 256)), b2(256);
+    dim3 g2((unsigned)ceil_div(cols, kColsumCols)), b2(256);
     hipLaunchKernelGGL((colsum_f32_kernel<T>), g2, b2, 0, s, part, (T*)out, P, (int)cols);
   });
   return launch_status();

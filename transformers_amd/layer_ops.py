@@ -23,7 +23,7 @@ def _split_qkv(qkv, b, s, hq, hkv, d):
 
 
 # forward : rmsnorm -> QKV GEMM -> rope(in place) -> attention -> o_proj GEMM(+residual)
-#           -> rmsnorm -> gate|up GEMM -> SwiGLU -> down GEMM(+residual)
+#           -> rmsnorm -> gate|up GEMM with the SwiGLU epilogue -> down GEMM(+residual)
 def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, eps,
                       hq, hkv, d, scale, causal, train):
     b, s, hd = h_in.shape
@@ -36,8 +36,11 @@ def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, w
     o, lse = ops.raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=train, q_start=q_start)
     h_mid = ops.raw_gemm(o.view(t, hq * d), wo, residual=x, epilogue=EPI_RESIDUAL)
     xn2, _, rstd2 = ops.raw_rmsnorm_fwd(h_mid, w_ln2, eps)
-    gu = ops.raw_gemm(xn2, wgu)
-    act = ops.raw_swiglu_fwd(gu)
+    if ops.gemm_swiglu_supported(xn2, wgu):  # SiLU*up in the gate|up GEMM epilogue; gate|up itself only if saved
+        gu, act = ops.raw_gemm_swiglu(xn2, wgu, need_gu=train)
+    else:
+        gu = ops.raw_gemm(xn2, wgu)
+        act = ops.raw_swiglu_fwd(gu)
     h_out = ops.raw_gemm(act, wd, residual=h_mid, epilogue=EPI_RESIDUAL).view(b, s, hd)
     if not train:
         e = h_out.new_empty(0)
@@ -69,9 +72,12 @@ def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
     x = ops._c(h_in).view(t, hd)
     dh = ops._c(d_hout).view(t, hd)
     # ---- MLP
-    d_act = ops.raw_gemm(dh, wd, b_kn=True)                                  # [T, I]
-    d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
-    del d_act
+    if ops.gemm_swiglu_bwd_supported(dh, wd, gu):  # d_act = dh . Wd with the SwiGLU backward in its epilogue
+        d_gu, act = ops.raw_gemm_swiglu_bwd(dh, wd, gu)
+    else:
+        d_act = ops.raw_gemm(dh, wd, b_kn=True)                              # [T, I]
+        d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
+        del d_act
     dwd = ops.raw_gemm(dh, act, a_km=True, b_kn=True)                        # [hd, I]
     del act
     d_xn2 = ops.raw_gemm(d_gu, wgu, b_kn=True)                               # [T, hd]

@@ -441,6 +441,49 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
     return out
 
 
+def gemm_swiglu_supported(x2, wgu) -> bool:
+    """Shapes the fused gate|up GEMM + SiLU*up epilogue takes (csrc/gemm.hip tamd_gemm_swiglu)."""
+    two_i, k = wgu.shape
+    return (x2.dtype in (torch.bfloat16, torch.float16) and wgu.dtype == x2.dtype and k % 64 == 0 and two_i % 16 == 0
+            and x2.stride(1) == 1 and wgu.stride(1) == 1 and x2.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0
+            and two_i * wgu.stride(0) * 2 < 2 ** 31)
+
+
+@_device_guard
+def raw_gemm_swiglu(x2, wgu, need_gu=True):
+    """x2 [T, K], wgu [2I, K] = [gate_proj.weight ; up_proj.weight]  ->  (gu [T, 2I] or None, act [T, I])."""
+    be = _prep(x2, wgu)
+    t, k = x2.shape
+    inter = wgu.shape[0] // 2
+    gu = torch.empty(t, 2 * inter, dtype=x2.dtype, device=x2.device) if need_gu else None
+    act = torch.empty(t, inter, dtype=x2.dtype, device=x2.device)
+    be.lib.check(be.lib.tamd_gemm_swiglu(_p(x2), _p(wgu), _p(gu), _p(act), t, inter, k, x2.stride(0), wgu.stride(0),
+                                         2 * inter, inter, _code(x2), be.stream(x2)), "tamd_gemm_swiglu")
+    return gu, act
+
+
+@_device_guard
+def raw_gemm_swiglu_bwd(dy2, wd, gu):
+    """dy2 [T, hd], wd [hd, I] (down_proj.weight as stored), gu [T, 2I] saved gate|up  ->  (d_gu [T, 2I], act [T, I]):
+    d_act = dy2 . wd never reaches HBM (the SwiGLU backward runs in that GEMM's epilogue)."""
+    be = _prep(dy2, wd, gu)
+    t, hd = dy2.shape
+    inter = wd.shape[1]
+    dgu = torch.empty_like(gu)
+    act = torch.empty(t, inter, dtype=gu.dtype, device=gu.device)
+    be.lib.check(be.lib.tamd_gemm_swiglu_bwd(_p(dy2), _p(wd), _p(gu), _p(dgu), _p(act), t, inter, hd, dy2.stride(0),
+                                             wd.stride(0), gu.stride(0), dgu.stride(0), inter, _code(gu),
+                                             be.stream(gu)), "tamd_gemm_swiglu_bwd")
+    return dgu, act
+
+
+def gemm_swiglu_bwd_supported(dy2, wd, gu) -> bool:
+    hd, inter = wd.shape
+    return (gu.dtype in (torch.bfloat16, torch.float16) and dy2.dtype == gu.dtype and wd.dtype == gu.dtype
+            and hd % 64 == 0 and inter % 8 == 0 and gu.shape[1] == 2 * inter and gu.is_contiguous()
+            and dy2.stride(1) == 1 and wd.stride(1) == 1 and dy2.stride(0) % 8 == 0 and wd.stride(0) % 8 == 0)
+
+
 def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=0, q_start=None):
     """q/k/v/o are [B, S, H, D] *views* (any batch/seq/head strides, D contiguous)."""
     p = _cabi.AttnParams()
@@ -678,6 +721,20 @@ define_op("gemm(Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bi
 define_op("gemm_out(Tensor(a!) out, Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, "
           "Tensor? residual=None, int epilogue=0, int act=0) -> ()", _gemm_out_impl,
           lambda out, a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0: None)
+
+
+def _gemm_swiglu_impl(x2, wgu, need_gu=True):
+    gu, act = raw_gemm_swiglu(x2, wgu, need_gu)
+    return gu if gu is not None else _nothing(x2), act
+
+
+define_op("gemm_swiglu(Tensor x2, Tensor wgu, bool need_gu=True) -> (Tensor, Tensor)", _gemm_swiglu_impl,
+          lambda x2, wgu, need_gu=True: (x2.new_empty(x2.shape[0], wgu.shape[0]) if need_gu else _nothing(x2),
+                                         x2.new_empty(x2.shape[0], wgu.shape[0] // 2)))
+
+
+define_op("gemm_swiglu_bwd(Tensor dy2, Tensor wd, Tensor gu) -> (Tensor, Tensor)", raw_gemm_swiglu_bwd,
+          lambda dy2, wd, gu: (torch.empty_like(gu), gu.new_empty(gu.shape[0], wd.shape[1])))
 
 
 def _attn_fwd_impl(q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None):
