@@ -93,6 +93,20 @@ int tamd_layernorm_bwd(const void* dy, const void* h, const void* w, const float
                        const void* dres, void* dx, void* dw, void* db, void* workspace, size_t workspace_bytes,
                        int64_t rows, int64_t cols, int dtype, tamd_stream_t stream);
 
+/* Post-LN block of BERT in train mode (models/bert/modeling_bert.py:289-293, :347-351):
+ *   h = dropout(x, p) + residual;  y = LayerNorm(h)
+ * The keep mask is the counter-based hash of (seed, row * cols + col) (tamd_dropout_hash), so the backward regenerates
+ * it; kept elements are scaled by 1/(1-p) and rounded to the storage type before the residual is added, as the
+ * reference's bf16 ops do.  Backward: dx = d loss / d h (the gradient of the residual input), dx_drop = the gradient of
+ * x (dx masked and scaled); dres as in tamd_layernorm_bwd. */
+int tamd_layernorm_dropout_fwd(const void* x, const void* residual, const void* w, const void* b, void* y, void* h_out,
+                               float* mean, float* rstd, int64_t rows, int64_t cols, float eps, float dropout_p,
+                               uint64_t seed, int dtype, tamd_stream_t stream);
+int tamd_layernorm_dropout_bwd(const void* dy, const void* h, const void* w, const float* mean, const float* rstd,
+                               const void* dres, void* dx, void* dx_drop, void* dw, void* db, void* workspace,
+                               size_t workspace_bytes, int64_t rows, int64_t cols, float dropout_p, uint64_t seed,
+                               int dtype, tamd_stream_t stream);
+
 /* ------------------------------------------------------------------ rotary */
 
 /* apply_rotary_pos_emb + rotate_half, models/llama/modeling_llama.py:130-160, applied IN PLACE to

@@ -637,3 +637,39 @@ def test_gemm_swiglu_bwd_epilogue_is_bit_identical_to_unfused(env):
         assert torch.equal(act, act_ref), (t, inter, hd)
     a, b = torch.ops.tamd.gemm_swiglu_bwd(dy, wd, gu)
     assert torch.equal(a, dgu_ref) and torch.equal(b, act_ref)
+
+
+@pytest.mark.parametrize("cols", [128, 768, 1024])
+def test_dropout_add_layernorm(env, cols):
+    """LayerNorm(dropout(x, p) + residual) with the mask drawn inside the norm kernel (BertSelfOutput / BertOutput in train
+    mode, modeling_bert.py:289-293): forward and backward against torch ops applied with the SAME mask, rebuilt on the
+    host from the exported hash; same seed -> same bits, another seed -> another mask; keep rate ~ 1 - p."""
+    torch.manual_seed(33)
+    rows = 2048 if env.big else 24
+    p, seed = 0.1, 0x1234_5678_9ABC
+    dev = env.device
+    x = torch.randn(rows, cols).bfloat16().to(dev).requires_grad_(True)
+    r = torch.randn(rows, cols).bfloat16().to(dev).requires_grad_(True)
+    w = (torch.rand(cols) + 0.5).bfloat16().to(dev).requires_grad_(True)
+    b = (torch.randn(cols) * 0.1).bfloat16().to(dev).requires_grad_(True)
+    y = ops.dropout_add_layernorm(x, r, w, b, 1e-12, p, seed)
+    keep = ops.hidden_dropout_keep_mask(seed, rows, cols, p)
+    assert abs(keep.float().mean().item() - (1 - p)) < (0.01 if env.big else 0.05)
+    xr, rr, wr, br = (t.detach().float().cpu().requires_grad_(True) for t in (x, r, w, b))
+    # the reference's bf16 op chain: dropout rounds, the add rounds, LayerNorm computes in fp32
+    dropped = (xr * keep / (1 - p)).bfloat16().float()
+    h = (dropped + rr).bfloat16().float()
+    yr = torch.nn.functional.layer_norm(h, (cols,), wr, br, 1e-12)
+    assert rel_err(y, yr) < 4e-3
+    g = torch.randn(rows, cols).bfloat16()
+    y.backward(g.to(dev))
+    yr.backward(g.float())
+    assert rel_err(r.grad, rr.grad) < 6e-3 and rel_err(x.grad, xr.grad) < 8e-3
+    assert (x.grad.float().cpu()[~keep] == 0).all()  # dropped elements receive no gradient
+    assert rel_err(w.grad, wr.grad) < 1.5e-2 and rel_err(b.grad, br.grad) < 1.5e-2
+    y2 = ops.dropout_add_layernorm(x.detach(), r.detach(), w.detach(), b.detach(), 1e-12, p, seed)
+    y3 = ops.dropout_add_layernorm(x.detach(), r.detach(), w.detach(), b.detach(), 1e-12, p, seed + 1)
+    assert torch.equal(y2, y.detach()) and not torch.equal(y3, y2)
+    # p = 0 is the plain fused add + LayerNorm
+    y0 = ops.dropout_add_layernorm(x.detach(), r.detach(), w.detach(), b.detach(), 1e-12, 0.0, seed)
+    assert torch.equal(y0, ops.layernorm(x.detach(), w.detach(), b.detach(), 1e-12, residual=r.detach())[0])

@@ -46,6 +46,9 @@ SIGNATURES = {
     "tamd_rmsnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_int, P]),
     "tamd_layernorm_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_int, P]),
     "tamd_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_int, P]),
+    "tamd_layernorm_dropout_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_float, ctypes.c_uint64, c_int, P]),
+    "tamd_layernorm_dropout_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_float, ctypes.c_uint64,
+                                           c_int, P]),
     "tamd_rope_inplace": (c_int, [P, P, P, I64, I64, I64, I64, I64, I64, c_int, c_int, P]),
     "tamd_embedding_fwd": (c_int, [P, P, P, I64, I64, I64, P, c_int, P]),
     "tamd_embedding_bwd_workspace_bytes": (c_size_t, [I64, I64]),

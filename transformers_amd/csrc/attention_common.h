@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "dropout.h"
 
 namespace tamd {
 
@@ -30,29 +31,6 @@ struct AttnArgs {
   unsigned seed_lo, seed_hi;
   int nqt;           // query tiles per (b, h)
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
-};
-
-// Counter-based dropout mask: 32-bit mix of (seed, element index); identical in forward, backward and on the host
-// (tamd_dropout_hash).  index = ((b*Hq + h)*Sq + q)*Sk + k.
-__host__ __device__ __forceinline__ unsigned dropout_hash(unsigned seed_lo, unsigned seed_hi, unsigned idx_lo,
-                                                          unsigned idx_hi) {
-  unsigned x = (idx_lo ^ seed_lo) * 0x9E3779B1u;
-  x ^= x >> 15;
-  x += (idx_hi * 0x85EBCA77u) ^ seed_hi;
-  x *= 0xC2B2AE3Du;
-  x ^= x >> 13;
-  x *= 0x27D4EB2Fu;
-  x ^= x >> 16;
-  return x;
-}
-// keep-scale of element (row_index*Sk + k): 0 or 1/(1-p)
-struct DropCtx {
-  unsigned thr, seed_lo, seed_hi;
-  float scale;
-  __device__ __forceinline__ float factor(unsigned long long base, int k) const {
-    const unsigned long long idx = base + (unsigned long long)k;
-    return dropout_hash(seed_lo, seed_hi, (unsigned)idx, (unsigned)(idx >> 32)) >= thr ? scale : 0.f;
-  }
 };
 
 // One swizzle serves both read patterns of a [rows][D] tile (rows = keys or queries):

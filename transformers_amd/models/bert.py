@@ -59,11 +59,10 @@ class _DenseResidualLN:
             return ops.layernorm(y, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
         # train mode with hidden dropout (the shipped configs): LayerNorm(dropout(dense(x)) + residual) -- the dropout
         # sits between the bias and the residual add, so the residual leaves the GEMM epilogue and joins the LayerNorm
-        # kernel instead (3 launches: GEMM+bias, dropout, add+LN; the reference path takes 5)
+        # kernel, which also draws the dropout mask (2 launches: GEMM+bias, dropout+add+LN; the reference path takes 5)
         y = ops.linear(hidden_states, self.dense.weight, self.dense.bias)
-        y = torch.nn.functional.dropout(y, self.dropout.p, True)  # (not in place: y is a custom-Function output view)
-        return ops.layernorm(y, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps,
-                             residual=input_tensor)[0]  # (y, x + residual)
+        return ops.dropout_add_layernorm(y, input_tensor, self.LayerNorm.weight, self.LayerNorm.bias,
+                                         self.LayerNorm.eps, self.dropout.p)
 
     def _ok(self, x):
         return _gpu(x) and x.dtype in (torch.bfloat16, torch.float16) and self.dense.bias is not None

@@ -210,6 +210,46 @@ def raw_layernorm_bwd(dy, h, w, mean, rstd, dres=None, need_db=True):
 
 
 @_device_guard
+def raw_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed):
+    """h = dropout(x, p) + residual; y = LayerNorm(h)  ->  (y, h, mean, rstd).  Keep mask: the counter-based hash of
+    (seed, flat element index), `hidden_dropout_keep_mask` on the host."""
+    cols = x.shape[-1]
+    x2, r2 = _c(x).view(-1, cols), _c(residual).view(-1, cols)
+    be = _prep(x2, w, b, r2)
+    w = _c(w)
+    b = None if b is None else _c(b)
+    y, h = torch.empty_like(x2), torch.empty_like(x2)
+    mean = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    be.lib.check(be.lib.tamd_layernorm_dropout_fwd(_p(x2), _p(r2), _p(w), _p(b), _p(y), _p(h), _p(mean), _p(rstd),
+                                                   x2.shape[0], cols, float(eps), float(dropout_p),
+                                                   int(seed) & 0xFFFFFFFFFFFFFFFF, _code(x2), be.stream(x2)),
+                 "tamd_layernorm_dropout_fwd")
+    return y.view(x.shape), h.view(x.shape), mean, rstd
+
+
+@_device_guard
+def raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True):
+    """-> (dx = gradient of the residual input, dx_drop = gradient of the dropped-out input, dw, db)."""
+    cols = h.shape[-1]
+    dy2, h2 = _c(dy).view(-1, cols), _c(h).view(-1, cols)
+    dr2 = None if dres is None else _c(dres).view(-1, cols)
+    be = _prep(dy2, h2, w, dr2)
+    w = _c(w)
+    rows = h2.shape[0]
+    dx, dxd = torch.empty_like(h2), torch.empty_like(h2)
+    dw = torch.empty_like(w)
+    db = torch.empty_like(w) if need_db else None
+    nbytes = be.lib.tamd_norm_bwd_workspace_bytes(rows, cols)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+    be.lib.check(be.lib.tamd_layernorm_dropout_bwd(_p(dy2), _p(h2), _p(w), _p(mean), _p(rstd), _p(dr2), _p(dx), _p(dxd),
+                                                   _p(dw), _p(db), _p(ws), nbytes, rows, cols, float(dropout_p),
+                                                   int(seed) & 0xFFFFFFFFFFFFFFFF, _code(h2), be.stream(h2)),
+                 "tamd_layernorm_dropout_bwd")
+    return dx.view(h.shape), dxd.view(h.shape), dw, db
+
+
+@_device_guard
 def raw_rope_(x2d, cos, sin, seq, nheads, head_dim, conj=False):
     """In-place rotary on the first `nheads` heads of every row of x2d [tokens, row_stride]."""
     be = _prep(x2d, cos, sin)
@@ -642,6 +682,24 @@ define_op("layernorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd
                                                                  torch.empty_like(w) if need_db else _nothing(w)))
 
 
+define_op("layernorm_dropout_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor residual, float dropout_p, int seed) "
+          "-> (Tensor, Tensor, Tensor, Tensor)", raw_layernorm_dropout_fwd,
+          lambda x, w, b, eps, residual, dropout_p, seed: (torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x)),
+                                                           _f32(x, _rows(x))))
+
+
+def _layernorm_dropout_bwd_impl(dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True):
+    dx, dxd, dw, db = raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres, need_db)
+    return dx, dxd, dw, db if db is not None else _nothing(w)
+
+
+define_op("layernorm_dropout_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd, float dropout_p, int seed, "
+          "Tensor? dres=None, bool need_db=True) -> (Tensor, Tensor, Tensor, Tensor)", _layernorm_dropout_bwd_impl,
+          lambda dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True: (
+              torch.empty_like(h), torch.empty_like(h), torch.empty_like(w),
+              torch.empty_like(w) if need_db else _nothing(w)))
+
+
 def _rope_impl(x2d, cos, sin, seq, nheads, head_dim, conj=False):
     raw_rope_(x2d, cos, sin, seq, nheads, head_dim, conj)
 
@@ -866,6 +924,37 @@ define_op("add_layernorm(Tensor x, Tensor residual, Tensor w, Tensor? b, float e
           "(Tensor, Tensor, Tensor, Tensor)", _add_layernorm_impl,
           lambda x, residual, w, b, eps: (torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x)),
                                           _f32(x, _rows(x))), _add_layernorm_backward, _add_layernorm_setup)
+
+
+# y = LayerNorm(dropout(x, p) + residual) -> (y, h): BertSelfOutput / BertOutput in train mode
+# (modeling_bert.py:289-293, :347-351); the keep mask is regenerated from (seed, element index) in the backward
+def _dropout_add_layernorm_impl(x, residual, w, b, eps, dropout_p, seed):
+    return raw_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed)
+
+
+def _dropout_add_layernorm_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1], inputs[2], output[2], output[3])
+    ctx.has_b = inputs[3] is not None
+    ctx.drop = (inputs[5], inputs[6])
+    ctx.set_materialize_grads(False)
+
+
+def _dropout_add_layernorm_backward(ctx, dy, dh, _dm, _dr):
+    none = (None,) * 7
+    if dy is None:
+        if dh is None:
+            return none
+        raise TamdError("dropout_add_layernorm: only the pre-norm sum is differentiated; use ops.layernorm pieces")
+    h, w, mean, rstd = ctx.saved_tensors
+    dx, dxd, dw, db = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, ctx.drop[0], ctx.drop[1], dh, ctx.has_b)
+    return (dxd, dx, dw, (db if ctx.has_b else None)) + none[4:]
+
+
+define_op("dropout_add_layernorm(Tensor x, Tensor residual, Tensor w, Tensor? b, float eps, float dropout_p, int seed) "
+          "-> (Tensor, Tensor, Tensor, Tensor)", _dropout_add_layernorm_impl,
+          lambda x, residual, w, b, eps, dropout_p, seed: (torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x)),
+                                                           _f32(x, _rows(x))),
+          _dropout_add_layernorm_backward, _dropout_add_layernorm_setup)
 
 
 # y = act(x W^T + b) [+ residual] on the MFMA GEMM; dX and dW use the k-major operand modes (no HBM transposes).
@@ -1229,6 +1318,19 @@ def layernorm(x, w, b, eps, residual=None):
         return T.layernorm(x, w, b, float(eps))[0]
     y, h, _, _ = T.add_layernorm(x, residual, w, b, float(eps))
     return y, h
+
+
+def dropout_add_layernorm(x, residual, w, b, eps, dropout_p, seed=None):
+    """LayerNorm(dropout(x, p) + residual) -> y, the dropout inside the norm kernel (seed from torch's CPU generator
+    unless given: `torch.manual_seed` repeats it, activation checkpointing regenerates it)."""
+    if seed is None:
+        seed = dropout_seed()
+    return T.dropout_add_layernorm(x, residual, w, b, float(eps), float(dropout_p), int(seed))[0]
+
+
+def hidden_dropout_keep_mask(seed: int, rows: int, cols: int, p: float) -> torch.Tensor:
+    """The keep mask [rows, cols] of `dropout_add_layernorm`, rebuilt on the host (tests / debugging)."""
+    return dropout_keep_mask(seed, 1, 1, rows, cols, p)[0, 0]
 
 
 def linear(x, w, bias=None, residual=None, act=ACT_NONE):
