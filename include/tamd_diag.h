@@ -15,6 +15,11 @@ extern "C" {
 int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K, void* trace,
                     tamd_stream_t stream);
 
+/* Clock probe of the 4-wave GEMM kernels: while `buf` (uint64[2 * workgroups], device memory) is set, every workgroup
+ * of a tamd_gemm launch stores {shader-clock ticks, 100 MHz real-time ticks} of its K loop at buf[2 * workgroup].
+ * NULL switches it off.  tools/gemm_clock.py */
+int tamd_gemm_set_clock_buffer(void* buf);
+
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
  * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
  * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */

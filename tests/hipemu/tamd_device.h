@@ -342,6 +342,11 @@ template <int IMM>
 inline void glds16_buf(const void* base, unsigned voff, char* smem, unsigned lds_base_off) {
   glds16<0>(reinterpret_cast<const char*>(base) + voff + IMM, smem, lds_base_off + (unsigned)IMM);
 }
+inline u32x4 buf_load16(const void* base, unsigned voff) {
+  u32x4 v;
+  memcpy(&v, reinterpret_cast<const char*>(base) + voff, 16);
+  return v;
+}
 // 4-byte variant (global_load_lds_dword): LDS destination = wave-uniform base + lane*4
 inline void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   const int lane = hipemu::cur_lane();
@@ -389,6 +394,7 @@ inline void wave_lockstep_point() {
 inline void setprio_hi() {}
 inline void setprio_lo() {}
 inline unsigned long long device_clock() { return 0ull; }
+inline unsigned long long device_realtime() { return 0ull; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_log2(float x) { return log2f(x); }

@@ -81,6 +81,7 @@ SIGNATURES = {
 # include/tamd_diag.h -- exported by libtamd_diag.so only (tools/, tests/test_gpu_probe.py), never by the product library
 DIAG_SIGNATURES = {
     "tamd_gemm_trace": (c_int, [P, P, P, I64, I64, I64, P, P]),
+    "tamd_gemm_set_clock_buffer": (c_int, [P]),
     "tamd_probe": (c_int, [P, P, P, c_int, c_int, P]),
     "tamd_bw_probe": (c_int, [P, c_size_t, c_int, c_size_t, c_int, c_int, c_int, P, P]),
 }

@@ -49,6 +49,23 @@ constexpr int kGemmSmem = (kRing * kStageBytes > 8 * kStageWaveBytes) ? kRing * 
 
 __device__ __attribute__((aligned(16))) static const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
+// Diagnostic build only (tamd_gemm_set_clock_buffer, include/tamd_diag.h): every workgroup of the 4-wave kernels
+// stores {shader-clock ticks, 100 MHz real-time ticks} of its K loop (prologue included, epilogue excluded) at
+// clock[2 * workgroup]: ticks ratio = the clock the kernel ran at, 64 MFMAs x 32 cycles per stage / ticks = how busy
+// the matrix pipe was.  tools/gemm_clock.py
+#ifdef TAMD_DIAG
+#define TAMD_CLOCK_BEGIN \
+  const unsigned long long clk_t0 = g.trace ? device_clock() : 0ull, clk_r0 = g.trace ? device_realtime() : 0ull;
+#define TAMD_CLOCK_END                                          \
+  if (g.trace != nullptr && threadIdx.x == 0) {                 \
+    g.trace[2 * (size_t)blockIdx.x] = device_clock() - clk_t0;  \
+    g.trace[2 * (size_t)blockIdx.x + 1] = device_realtime() - clk_r0; \
+  }
+#else
+#define TAMD_CLOCK_BEGIN
+#define TAMD_CLOCK_END
+#endif
+
 struct GemmArgs {
   const void* A;
   const void* B;
@@ -434,6 +451,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   const int wave = wave_id_uniform();
   const int wm = wave >> 1, wn = wave & 1;
   const int hi = lane >> 5, l31 = lane & 31;
+  TAMD_CLOCK_BEGIN
   int tile_m, tile_n;
   const int split = (EPI == kEpiSplitK) ? (int)(blockIdx.x % (unsigned)g.splits) : 0;
   gemm_tile_of_block(g, (EPI == kEpiSplitK) ? (int)(blockIdx.x / (unsigned)g.splits) : (int)blockIdx.x, &tile_m, &tile_n);
@@ -636,6 +654,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   wait_vmcnt<0>();
   wait_lgkmcnt0();
   raw_barrier();
+  TAMD_CLOCK_END
   if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per register quad
     float* ws = g.ws + (int64_t)split * g.M * g.N;
 #pragma unroll
@@ -691,6 +710,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
 }
 
 // ============================================================================================ host dispatch
+#ifndef TAMD_GEMM_KERNELS_ONLY  // (tools/gemm_isa.sh instantiates single kernels for a look at their ISA)
 #define TAMD_EPI_SWITCH(LAUNCH)                                           \
   switch (epilogue) {                                                     \
     case TAMD_EPI_NONE: LAUNCH(TAMD_EPI_NONE, TAMD_ACT_NONE)              \
@@ -796,6 +816,14 @@ static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, h
 
 using namespace tamd;
 
+#ifdef TAMD_DIAG
+static unsigned long long* g_gemm_clock = nullptr;
+extern "C" int tamd_gemm_set_clock_buffer(void* buf) {
+  g_gemm_clock = reinterpret_cast<unsigned long long*>(buf);
+  return TAMD_OK;
+}
+#endif
+
 static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, const void* bias, const void* R,
                           int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr) {
   g->A = A;
@@ -812,7 +840,11 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->ldr = ldr;
   g->tiles_m = (int)ceil_div(M, kBM);
   g->tiles_n = (int)ceil_div(N, kBN);
+#ifdef TAMD_DIAG
+  g->trace = g_gemm_clock;
+#else
   g->trace = nullptr;
+#endif
   g->ws = nullptr;
   g->splits = 1;
   g->stages_per_split = 0;
@@ -963,3 +995,6 @@ extern "C" int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* 
   });
   return TAMD_E_DTYPE;
 }
+#else
+}  // namespace tamd
+#endif  // TAMD_GEMM_KERNELS_ONLY

@@ -177,6 +177,11 @@ __device__ __forceinline__ void glds16_buf(const void* base, unsigned voff, char
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_base_off), 16,
                                            (int)voff, 0, IMM, 0);
 }
+// 16-byte buffer load into registers (buffer_load_dwordx4 ... offen): wave-uniform `base`, per-lane 32-bit byte offset
+__device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
 // 4-byte variant (global_load_lds_dword): the wave writes 64 x 4 B = 256 B contiguous at smem + wave_base_off
 __device__ __forceinline__ void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -208,6 +213,8 @@ __device__ __forceinline__ void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 
 // shader clock (s_memtime), for the in-kernel phase traces of the diagnostic GEMM variant
 __device__ __forceinline__ unsigned long long device_clock() { return __builtin_amdgcn_s_memtime(); }
+// constant-rate (100 MHz) counter: shader-clock ticks / real-time ticks = the clock a kernel actually ran at
+__device__ __forceinline__ unsigned long long device_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 
 // fast transcendental pieces
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
