@@ -30,6 +30,11 @@ int tamd_probe(const void* in, const void* in2, void* out, int which, int dtype,
 int tamd_bw_probe(const void* buf, size_t bytes, int seg, size_t row_stride, int iters, int mode, int blocks,
                   void* sink, tamd_stream_t stream);
 
+/* MFMA power probe: `blocks` workgroups of 4 waves run `iters` rounds of 32 x 32x32x16 (mode 0) or 64 x 16x16x32 (mode 1)
+ * bf16 MFMAs per wave (1.05 MFLOP per wave and round either way) on operand bits from `in` (61 x 256 uint32) and store
+ * {shader ticks, 100 MHz ticks} per workgroup in clk.  tools/mfma_power.py */
+int tamd_mfma_power(const void* in, int iters, int mode, int blocks, void* clk, void* sink, tamd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

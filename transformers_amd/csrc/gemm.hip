@@ -174,55 +174,46 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int bid, i
   *tile_n = (logical % group_size) / gm;
 }
 
-// Epilogue of one wave: acc[ni][mi][r] = D[n = ni*32 + (r&3) + 8*(r>>2) + 4*hi][m = mi*32 + l31] for NI x MI
-// 32x32 accumulators covering a (MI*32) x (NI*32) piece of C at (row0, col0).  Round (+bias, +activation) ->
-// stage 64 rows at a time in this wave's private LDS region -> full-row 16-byte stores (+residual / +C).
-template <typename T, int EPI, int ACT, int NI, int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, unsigned st_off,
-                                              int64_t row0, int64_t col0, int lane) {
-  constexpr int ROWB = NI * 32 * 2 + 16;  // staged row: NI*32 columns + 16 B pad
-  constexpr int SLOTS = NI * 4;           // 16-byte slots per row
-  constexpr int RPI = 64 / SLOTS;         // rows per wave instruction on the way out
-  const int hi = lane >> 5, l31 = lane & 31;
-  const T* bias = reinterpret_cast<const T*>(g.bias);
+// Epilogue of one wave over a (HALVES*64) x (NCOLS) piece of C at (row0, col0).  Per 64 rows: `stage(half, bias4)` rounds
+// the accumulators (+bias, +activation) into this wave's private LDS region (row pitch NCOLS*2 + 16 bytes; the
+// accumulator layout is the caller's business: stage32 / stage16 below), then full-row 16-byte stores (+residual / +C /
+// SwiGLU backward) leave from there.
+template <typename T, int EPI, int ACT, int NCOLS, int HALVES, typename StageFn>
+__device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem, unsigned st_off, int64_t row0, int64_t col0,
+                                                   int lane, StageFn stage) {
+  constexpr int ROWB = NCOLS * 2 + 16;   // staged row + 16 B pad
+  constexpr int SLOTS = NCOLS / 8;       // 16-byte slots per row
+  constexpr int RPI = 64 / SLOTS;        // rows per wave instruction on the way out
   T* C = reinterpret_cast<T*>(g.C);
   const T* R = reinterpret_cast<const T*>(g.R);
+  // operands the way out reads from memory (residual / previous C / the saved gate|up): all of a half's loads are issued
+  // BEFORE the accumulators are rounded and staged, so their latency overlaps that work and 16-32 KiB per wave are in
+  // flight instead of 4 (the way out was latency-bound at ~2.7 TB/s: 1.05 ms of the 3.8 ms SwiGLU-backward GEMM)
+  constexpr int NR = (EPI == kEpiSwiGLUBwd) ? 2 : ((EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0);
+  constexpr int NIT = 64 / RPI;
 #pragma unroll
-  for (int half = 0; half < MI / 2; ++half) {
+  for (int half = 0; half < HALVES; ++half) {
+    u32x4 pre[NR > 0 ? NIT * NR : 1];
+    if (NR > 0) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int nl = ni * 32 + 8 * qd + 4 * hi;  // first of 4 consecutive local columns
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (EPI == TAMD_EPI_BIAS || EPI == TAMD_EPI_BIAS_ACT || (EPI == TAMD_EPI_RESIDUAL && bias != nullptr)) {
-          const int64_t gn = col0 + nl;
-          if (gn < g.N) {  // N % 8 == 0 and nl % 4 == 0: the 4 columns are valid together
-            const u32x2 bq = ld8(bias + gn);
-            bv[0] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] & 0xffffu));
-            bv[1] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] >> 16));
-            bv[2] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] & 0xffffu));
-            bv[3] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] >> 16));
-          }
-        }
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
-          const int mi = half * 2 + m2;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = acc[ni][mi][qd * 4 + e] + bv[e];
-            if (EPI == TAMD_EPI_BIAS_ACT) x = gemm_act<ACT>(round_through<T>(x));
-            v[e] = x;
-          }
-          const u32x2 pk = {pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
-          lds_write8(smem, st_off + (unsigned)(m2 * 32 + l31) * ROWB + (unsigned)nl * 2u, pk);
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
+        const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
+        const bool ok = gm_ < g.M && gn < g.N;
+        if (EPI == kEpiSwiGLUBwd) {
+          pre[2 * it] = ok ? ld16(R + gm_ * g.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
+          pre[2 * it + 1] = ok ? ld16(R + gm_ * g.ldr + g.n_half + gn) : u32x4{0u, 0u, 0u, 0u};
+        } else {
+          const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
+          pre[it] = ok ? ld16(rp) : u32x4{0u, 0u, 0u, 0u};
         }
       }
+      sched_fence();
     }
+    stage(half);
     wave_lockstep_point();  // wave-private region: this wave's writes are ordered before its reads
-#pragma unroll 4
-    for (int it = 0; it < 64 / RPI; ++it) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
       const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
       const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
       u32x4 v = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)slot * 16u);
@@ -232,8 +223,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
         if (gm_ < g.M && gn < g.N) {
           float d[8], gt[8], up[8], dg[8], du[8], ac[8];
           unpack16<T>(v, d);
-          unpack16<T>(ld16(R + gm_ * g.ldr + gn), gt);
-          unpack16<T>(ld16(R + gm_ * g.ldr + g.n_half + gn), up);
+          unpack16<T>(pre[NR == 2 ? 2 * it : 0], gt);
+          unpack16<T>(pre[NR == 2 ? 2 * it + 1 : 0], up);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float sl = round_through<T>(gemm_silu(gt[e]));
@@ -249,10 +240,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
       }
       if (gm_ < g.M && gn < g.N) {
         if (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) {
-          const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
           float a[8], b[8];
           unpack16<T>(v, a);
-          unpack16<T>(ld16(rp), b);
+          unpack16<T>(pre[NR == 1 ? it : 0], b);
 #pragma unroll
           for (int e = 0; e < 8; ++e) a[e] += b[e];
           v = pack16<T>(a);
@@ -264,18 +254,95 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
   }
 }
 
+// bias of 4 consecutive columns starting at global column gn (zero when the epilogue has none)
+template <typename T, int EPI>
+__device__ __forceinline__ void gemm_bias4(const GemmArgs& g, int64_t gn, float* bv) {
+  bv[0] = bv[1] = bv[2] = bv[3] = 0.f;
+  const T* bias = reinterpret_cast<const T*>(g.bias);
+  if (EPI == TAMD_EPI_BIAS || EPI == TAMD_EPI_BIAS_ACT || (EPI == TAMD_EPI_RESIDUAL && bias != nullptr)) {
+    if (gn < g.N) {  // N % 8 == 0 and gn % 4 == 0: the 4 columns are valid together
+      const u32x2 bq = ld8(bias + gn);
+      bv[0] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] & 0xffffu));
+      bv[1] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] >> 16));
+      bv[2] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] & 0xffffu));
+      bv[3] = elem<T>::to_f32((typename elem<T>::raw)(bq[1] >> 16));
+    }
+  }
+}
+// 4 accumulator values of one output row -> rounded (+bias, +activation) -> 8 staged bytes
+template <typename T, int EPI, int ACT>
+__device__ __forceinline__ u32x2 gemm_round4(float a0, float a1, float a2, float a3, const float* bv) {
+  float v[4] = {a0 + bv[0], a1 + bv[1], a2 + bv[2], a3 + bv[3]};
+  if (EPI == TAMD_EPI_BIAS_ACT) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gemm_act<ACT>(round_through<T>(v[e]));
+  }
+  return u32x2{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+}
+
+// 32x32x16 accumulators (gemm_pp_kernel): acc[ni][mi][r] = D[n = ni*32 + (r&3) + 8*(r>>2) + 4*hi][m = mi*32 + l31]
+template <typename T, int EPI, int ACT, int NI, int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, unsigned st_off,
+                                              int64_t row0, int64_t col0, int lane) {
+  constexpr int ROWB = NI * 32 * 2 + 16;
+  const int hi = lane >> 5, l31 = lane & 31;
+  gemm_epilogue_rows<T, EPI, ACT, NI * 32, MI / 2>(g, smem, st_off, row0, col0, lane, [&](int half) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int nl = ni * 32 + 8 * qd + 4 * hi;  // first of 4 consecutive local columns
+        float bv[4];
+        gemm_bias4<T, EPI>(g, col0 + nl, bv);
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const int mi = half * 2 + m2;
+          lds_write8(smem, st_off + (unsigned)(m2 * 32 + l31) * ROWB + (unsigned)nl * 2u,
+                     gemm_round4<T, EPI, ACT>(acc[ni][mi][qd * 4 + 0], acc[ni][mi][qd * 4 + 1], acc[ni][mi][qd * 4 + 2],
+                                              acc[ni][mi][qd * 4 + 3], bv));
+        }
+      }
+    }
+  });
+}
+
+// 16x16x32 accumulators (gemm_fl_kernel): acc[nb][mb][r] = D[n = nb*16 + 4*(lane>>4) + r][m = mb*16 + (lane&15)],
+// 8 x 8 blocks = a 128 x 128 piece of C
+template <typename T, int EPI, int ACT>
+__device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, f32x4 (&acc)[8][8], char* smem, unsigned st_off,
+                                                int64_t row0, int64_t col0, int lane) {
+  constexpr int ROWB = 128 * 2 + 16;
+  const int g4 = lane >> 4, l15 = lane & 15;
+  gemm_epilogue_rows<T, EPI, ACT, 128, 2>(g, smem, st_off, row0, col0, lane, [&](int half) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int nl = nb * 16 + 4 * g4;  // first of 4 consecutive local columns
+      float bv[4];
+      gemm_bias4<T, EPI>(g, col0 + nl, bv);
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        const f32x4 a = acc[nb][half * 4 + m4];
+        lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
+                   gemm_round4<T, EPI, ACT>(a[0], a[1], a[2], a[3], bv));
+      }
+    }
+  });
+}
+
 // SwiGLU epilogue of one wave of gemm_fl_kernel<..., kEpiSwiGLU>.  The tile's 256 B-rows are 8 blocks of 32 weight rows,
 // alternately from the gate and the up half of the fused [2*I, K] weight (block b: feature block b>>1, part b&1), so
-// a wave's four 32-column accumulators are (gate, up) x 2 feature blocks with identical lane layouts:
+// of a wave's eight 16-column accumulator blocks nb = 4p + 2*part + sub (p = feature block, sub = its 16-column half)
+// the gate and up blocks of one feature (nb, nb + 2) have identical lane layouts:
 //     act = round(round(silu(round(g))) * round(u))          lane-local, the roundings of the unfused path
 // Per 64 output rows: stage [gate 64 | up 64] and [act 64] in this wave's LDS region, then full 128-byte row segments
-// to C[m, f0..] (gate), C[m, I + f0..] (up) -- skipped when C == nullptr -- and C2[m, f0..] (act).
+// to C[m, f0..] (gate), C[m, I + f0..] (up) -- streaming stores (saved for the backward only), skipped when C == nullptr --
+// and C2[m, f0..] (act).
 template <typename T>
-__device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x16 (&acc)[4][4], char* smem, unsigned st_off,
+__device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&acc)[8][8], char* smem, unsigned st_off,
                                                      int64_t row0, int64_t f0, int lane) {
   constexpr int GU_ROWB = 128 * 2 + 16, ACT_ROWB = 64 * 2 + 16;
   constexpr unsigned ACT_OFF = 64u * GU_ROWB;
-  const int hi = lane >> 5, l31 = lane & 31;
+  const int g4 = lane >> 4, l15 = lane & 15;
   T* C = reinterpret_cast<T*>(g.C);
   T* C2 = reinterpret_cast<T*>(g.C2);
   const int64_t I = g.n_half;
@@ -284,19 +351,19 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x16 (
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int nl = p * 32 + 8 * qd + 4 * hi;  // first of 4 consecutive local features
+      for (int sub = 0; sub < 2; ++sub) {
+        const int nl = p * 32 + sub * 16 + 4 * g4;  // first of 4 consecutive local features
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
-          const int mi = half * 2 + m2;
+        for (int m4 = 0; m4 < 4; ++m4) {
+          const int mb = half * 4 + m4;
           float gg[4], uu[4], aa[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            gg[e] = round_through<T>(acc[2 * p][mi][qd * 4 + e]);
-            uu[e] = round_through<T>(acc[2 * p + 1][mi][qd * 4 + e]);
+            gg[e] = round_through<T>(acc[4 * p + sub][mb][e]);
+            uu[e] = round_through<T>(acc[4 * p + 2 + sub][mb][e]);
             aa[e] = round_through<T>(gemm_silu(gg[e])) * uu[e];
           }
-          const unsigned r = (unsigned)(m2 * 32 + l31);
+          const unsigned r = (unsigned)(m4 * 16 + l15);
           lds_write8(smem, st_off + r * GU_ROWB + (unsigned)nl * 2u, u32x2{pack2<T>(gg[0], gg[1]), pack2<T>(gg[2], gg[3])});
           lds_write8(smem, st_off + r * GU_ROWB + (unsigned)(64 + nl) * 2u,
                      u32x2{pack2<T>(uu[0], uu[1]), pack2<T>(uu[2], uu[3])});
@@ -312,7 +379,7 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x16 (
         const int row = it * 4 + (lane >> 4), slot = lane & 15;
         const int64_t gm_ = row0 + half * 64 + row, f = f0 + (slot & 7) * 8;
         const u32x4 v = lds_read16(smem, st_off + (unsigned)row * GU_ROWB + (unsigned)slot * 16u);
-        if (gm_ < g.M && f < I) st16(C + gm_ * g.ldc + (slot >= 8 ? I : 0) + f, v);
+        if (gm_ < g.M && f < I) st16_nt(C + gm_ * g.ldc + (slot >= 8 ? I : 0) + f, v);
       }
     }
 #pragma unroll 4
@@ -419,21 +486,26 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
 
 // ============================================================================================ full-line feed
 // 4 waves x (128 x 128): 256 accumulator registers per wave (the unified 512-entry file of gfx950), one wave per
-// SIMD.  A ring stage is 64 k deep so one row-major operand row of a stage is exactly one 128-byte L2 line and
+// SIMD, on v_mfma_f32_16x16x32: 8 x 8 accumulator blocks of 16 x 16.  Why the small MFMA: this GEMM is bounded by the
+// power budget, not by its schedule -- the K loop of the 32x32x16 version issued an MFMA on 90-94 % of the cycles of a
+// clock the part had lowered to 1.45-1.65 GHz (profiles/r02_gemm_variants.md) -- and a register-only stream of 16x16x32
+// MFMAs on random operands sustains 2.06 PFLOP/s at 2.04 GHz where 32x32x16 sustains 1.80 at 1.76 (the 32-deep dot
+// product halves the accumulator updates per flop; tools/mfma_power.py, profiles/r02g_mfma_power.jsonl).
+// A ring stage is 64 k deep so one row-major operand row of a stage is exactly one 128-byte L2 line and
 // one LDS-DMA wave-instruction covers 8 rows x 128 B = 8 whole lines (k-major stages are 512-byte k-rows: whole
 // lines too).  32-deep stages request every line in two 64-byte halves, one k-step apart: rocprofv3 shows 2.0x
-// the TCP_TCC_READ_REQ of hipBLASLt's MT256x256x64 kernel for the same bytes (profiles/r01_gemm_pmc.txt), and the
-// L2 request path, not the schedule, bounded that loop (profiles/r01_gemm_variants.md): +14-30 % from this alone.
-// LDS: 5 half-slots of 32 KiB = all 160 KiB.  Operand-stage A_j lives in slot (2j) % 5, B_j in (2j+1) % 5; row r of
-// an operand stage is 128 B at r*128, logical 16-byte chunk c at slot c ^ ((r>>1)&7) (applied on the source
-// address, undone on the fragment read; 16 consecutive rows x one chunk cover all 64 banks once).
-// Schedule of stage s (4 k-steps of 16; fragments double-buffered one k-step ahead; 4 LDS-DMA pieces per k-step):
-//     k-step 0 : 16 MFMA | 8 fragment reads | B_{s+1}[4:8]   (second half of the slot A_{s-1} vacated)
-//     k-step 1 : 16 MFMA | 8 fragment reads | A_{s+2}[0:4]   (into the slot B_{s-1} vacated)
-//     k-step 2 : 16 MFMA | 8 fragment reads (the last reads of stage s) | A_{s+2}[4:8]
+// the TCP_TCC_READ_REQ of hipBLASLt's MT256x256x64 kernel for the same bytes (profiles/r01_gemm_pmc.txt).
+// LDS: 5 half-slots of 32 KiB = all 160 KiB.  Operand-stage A_j lives in slot (2j) % 5, B_j in (2j+1) % 5.
+//   row-major operand stage: row r is 128 B at r*128, logical 16-byte chunk c at slot c ^ ((r>>1)&7);
+//   k-major operand stage  : [64 k][256 cols], 512-byte k-rows, chunk slot' = slot ^ (((k&3)<<2) | (((k>>3)&1)<<1))
+// (applied on the LDS-DMA source address, undone on the fragment read; both fragment reads are conflict-free: a 16-row
+// x 4-chunk ds_read_b128, a 2 x (4 k-rows x 16 columns) ds_read_b64_tr_b16 per 32 lanes).
+// Schedule of stage s (2 k-steps of 32; fragments double-buffered one k-step ahead, 16 + 16 registers x 4):
+//     k-step 0 : 64 MFMA | 16 fragment reads (second half of stage s) | A_{s+2}[0:8]  (into the slot B_{s-1} vacated)
 //     hand-off : vmcnt(8) retires this wave's B_{s+1} (A_{s+1} is older), lgkmcnt(0), barrier
-//     k-step 3 : 16 MFMA | 8 fragment reads of stage s+1 | B_{s+2}[0:4]   (into the slot A_s vacated)
-// so 8-16 pieces per wave (32-64 KiB per CU) are in flight across every barrier, one barrier per 64 k.
+//     k-step 1 : 64 MFMA | 16 fragment reads of stage s+1 | B_{s+2}[0:8]  (into the slot A_s vacated)
+// The reads sit behind MFMA pairs 0..15 of a k-step (every read has at least 32 MFMAs to land), the pieces behind the odd
+// pairs 17..31; 8-16 pieces per wave (32-64 KiB per CU) are in flight across every barrier, one barrier per 64 k.
 // Rows past M / N are clamped to the last valid row (their products land in rows / columns the epilogue never
 // stores); requires K % 64 == 0 (host dispatch).
 constexpr int kFlThreads = 256;
@@ -441,6 +513,15 @@ constexpr int kXK = 64;
 constexpr unsigned kXHalf = 256u * kXK * 2u;  // one operand of one stage: 32 KiB
 constexpr int kXSlots = 5;
 constexpr int kXSmem = kXSlots * (int)kXHalf;  // 163840 = the whole LDS of a CU
+
+// byte offset (without the k-step / block immediates) of a lane's 16x16x32 fragment inside a k-major operand stage:
+// two ds_read_b64_tr_b16 (k rows +0..3 and +4..7 of the lane group's 8) of the 16 columns starting at c16
+__device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
+  const int g4 = lane >> 4, kq = (lane & 15) >> 2;
+  const int col = c16 + 4 * (lane & 3);
+  const int slot = (col >> 3) ^ ((kq << 2) | ((g4 & 1) << 1));  // (k&3) == kq, ((k>>3)&1) == g4&1 for every k-step
+  return (unsigned)(8 * g4 + kq) * 512u + (unsigned)slot * 16u + (unsigned)(col & 7) * 2u;
+}
 
 // DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_GEMM_DBG=n, wrong results): 1 no LDS-DMA after the prologue, 2 no LDS
 // fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier
@@ -450,7 +531,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
   const int wm = wave >> 1, wn = wave & 1;
-  const int hi = lane >> 5, l31 = lane & 31;
+  const int g4 = lane >> 4, l15 = lane & 15;
   TAMD_CLOCK_BEGIN
   int tile_m, tile_n;
   const int split = (EPI == kEpiSplitK) ? (int)(blockIdx.x % (unsigned)g.splits) : 0;
@@ -459,23 +540,20 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
 
-  f32x16 acc[4][4];  // [ni][mi]
+  f32x4 acc[8][8];  // [nb][mb]
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+  for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nst_all = (int)(g.K / kXK);
   const int st0 = (EPI == kEpiSplitK) ? split * g.stages_per_split : 0;  // first stage of this workgroup's K range
   const int nst = (EPI == kEpiSplitK) ? (nst_all - st0 < g.stages_per_split ? nst_all - st0 : g.stages_per_split) : nst_all;
-  // per-lane source pointers: this wave's 8 A pieces ([0..7]) and 8 B pieces ([8..15]) of an operand stage.
+  // per-lane source offsets: this wave's 8 A pieces ([0..7]) and 8 B pieces ([8..15]) of an operand stage.
   //   row-major operand: piece i = rows (wave*8+i)*8 .. +7, lane -> (row = lane>>3, physical chunk = lane&7);
   //                      next stage = +128 B
-  //   k-major operand  : stage = [64 k][256 cols] (512-byte k-rows, chunk slot' = slot ^ ((k&3)<<2) as in the
-  //                      ping-pong kernel); piece i = k-rows (wave*8+i)*2 .. +1, lane -> (k = lane>>5, physical
-  //                      chunk = lane&31); next stage = +64 rows
+  //   k-major operand  : piece i = k-rows (wave*8+i)*2 .. +1, lane -> (k = lane>>5, physical chunk = lane&31);
+  //                      next stage = +64 rows
   // Rows / column chunks outside the matrix are clamped to the last valid one.
   // Feed: buffer_load ... lds (tamd_device.h glds16_buf).  Wave-uniform operand base stepped per stage, loop-invariant
   // 32-bit lane offsets, one M0 per 4 pieces through the shared immediate.
@@ -491,7 +569,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     const int row = (wave * 8 + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     const int kr = (wave * 8 + i) * 2 + (lane >> 5);
-    const int col = ((lane & 31) ^ ((kr & 3) << 2)) * 8;
+    const int col = ((lane & 31) ^ (((kr & 3) << 2) | (((kr >> 3) & 1) << 1))) * 8;
     const int64_t gca = (m0 + col < g.M) ? m0 + col : g.M - 8;
     const int64_t ra = (m0 + row < g.M) ? m0 + row : g.M - 1;
     const int64_t gcb = (n0 + col < g.N) ? n0 + col : g.N - 8;
@@ -506,7 +584,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     voff[i] = (unsigned)(oa * 2 + 4096 - (i & 3) * 1024);
     voff[8 + i] = (unsigned)(ob * 2 + 4096 - (i & 3) * 1024);
   }
-  // past the last stage: keep the load counts uniform and re-read the last valid stage
+  // past the last stage: keep the load counts uniform and re-read the last valid stage (idempotent)
   auto park = [&]() {
     base_a -= kinc_a;
     base_b -= kinc_b;
@@ -528,17 +606,21 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     if (p == 7) base_a += kinc_a;  // every piece of the operand stage is out: step to the next stage
     if (p == 15) base_b += kinc_b;
   };
-  // fragment offsets inside a half-slot.  row-major: one per k-step (row (wm|wn)*128 + t*32 + l31: t is the
-  // immediate t*4096); k-major: one per 32-column block t (k-step ks is the immediate ks*8192)
-  unsigned offx[4], offw[4];
+  // fragment offsets inside a half-slot (block t = 16 rows / columns of this wave's 128, k-step q = 32 of the stage's 64)
+  //   row-major: one register per k-step, the block is the immediate t*2048;
+  //   k-major  : one register per block, the k-step is the immediate q*16384
+  constexpr int NOX = A_KM ? 8 : 2, NOW = B_KN ? 8 : 2;
+  unsigned offx[NOX], offw[NOW];
   {
-    const unsigned sw = (unsigned)(l31 >> 1) & 7u;
+    const unsigned sw = (unsigned)(l15 >> 1) & 7u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned ch = ((unsigned)(j * 2 + hi) ^ sw) * 16u;
-      offx[j] = A_KM ? pp_frag_off<true>(wm * 128 + j * 32, 0, lane) : (unsigned)(wm * 128 + l31) * 128u + ch;
-      offw[j] = B_KN ? pp_frag_off<true>(wn * 128 + j * 32, 0, lane) : (unsigned)(wn * 128 + l31) * 128u + ch;
-    }
+    for (int j = 0; j < NOX; ++j)
+      offx[j] = A_KM ? fl_frag_off_km(wm * 128 + j * 16, lane)
+                     : (unsigned)(wm * 128 + l15) * 128u + (((unsigned)(j * 4 + g4) ^ sw) * 16u);
+#pragma unroll
+    for (int j = 0; j < NOW; ++j)
+      offw[j] = B_KN ? fl_frag_off_km(wn * 128 + j * 16, lane)
+                     : (unsigned)(wn * 128 + l15) * 128u + (((unsigned)(j * 4 + g4) ^ sw) * 16u);
   }
   // k-major fragments: two transposing 8-byte reads (k rows +0..3 and +4..7), issued untracked (tamd_device.h:
   // the compiler would drain vmcnt in front of each); every k-step therefore opens with an explicit lgkmcnt(0)
@@ -547,107 +629,78 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     const u32x2 h2 = lds_read8_tr16_untracked(smem, off, imm + 4 * 512);
     return u32x4{lo[0], lo[1], h2[0], h2[1]};
   };
-  auto frag_a = [&](int slot, int ks, int i) -> u32x4 {
-    if (A_KM) return frag_km((unsigned)slot * kXHalf + offx[i], ks * 8192);
-    return lds_read16(smem, (unsigned)slot * kXHalf + offx[ks] + (unsigned)i * 4096u);
+  auto frag_a = [&](int slot, int q, int t) -> u32x4 {
+    if (A_KM) return frag_km((unsigned)slot * kXHalf + offx[A_KM ? t : 0], q * 16384);
+    return lds_read16(smem, (unsigned)slot * kXHalf + offx[A_KM ? 0 : q] + (unsigned)t * 2048u);
   };
-  auto frag_b = [&](int slot, int ks, int i) -> u32x4 {
-    if (B_KN) return frag_km((unsigned)slot * kXHalf + offw[i], ks * 8192);
-    return lds_read16(smem, (unsigned)slot * kXHalf + offw[ks] + (unsigned)i * 4096u);
+  auto frag_b = [&](int slot, int q, int t) -> u32x4 {
+    if (B_KN) return frag_km((unsigned)slot * kXHalf + offw[B_KN ? t : 0], q * 16384);
+    return lds_read16(smem, (unsigned)slot * kXHalf + offw[B_KN ? 0 : q] + (unsigned)t * 2048u);
   };
   auto kstep_open = [&]() {  // fragments of this k-step (read during the previous one) are in registers
     if (A_KM || B_KN) wait_lgkmcnt0();
     sched_fence();
   };
-  u32x4 fx[2][4], fw[2][4];  // [buffer][mi / ni]
-  // One k-step = 16 MFMAs issued as 8 pairs; between consecutive pairs exactly one small group of feed
-  // instructions, pinned with sched_barrier(0) so the matrix pipe (one wave per SIMD: nobody else fills it) never
-  // waits behind a clump of LDS / LDS-DMA issues.  pair p covers acc[p>>1][2*(p&1) .. +1].
-  auto mfma_pair = [&](int buf, int p) {
-    const int ni = p >> 1, mi = (p & 1) * 2;
-    acc[ni][mi] = mfma32<T>(fw[buf][ni], fx[buf][mi], acc[ni][mi]);
-    acc[ni][mi + 1] = mfma32<T>(fw[buf][ni], fx[buf][mi + 1], acc[ni][mi + 1]);
-  };
-  // fragment read number q (0..7) of k-step ks of stage slots (sa, sb) into buffer buf: w0 x0 w1 x1 ...
-  auto rd1 = [&](int sa, int sb, int ks, int buf, int q) {
+  u32x4 fx[2][8], fw[2][8];  // [buffer][mb / nb]
+  // fragment read number r (0..15) of k-step q of stage slots (sa, sb) into buffer buf, in the order the MFMAs of the
+  // next k-step want them: w0 x0 x1 .. x7 w1 .. w7
+  auto rd1 = [&](int sa, int sb, int q, int buf, int r) {
     if ((DBG & 2) && !dma_on) return;
-    const int i = q >> 1;
-    if (q & 1)
-      fx[buf][i] = frag_a(sa, ks, i);
+    if (r == 0)
+      fw[buf][0] = frag_b(sb, q, 0);
+    else if (r <= 8)
+      fx[buf][r - 1] = frag_a(sa, q, r - 1);
     else
-      fw[buf][i] = frag_b(sb, ks, i);
+      fw[buf][r - 8] = frag_b(sb, q, r - 8);
+  };
+  // one k-step: 64 MFMAs from fragment buffer `buf` issued as 32 pairs, acc[nb][mb] with mb innermost (the W fragment
+  // stays on the MFMA's A port for 8 instructions); behind pair p < 16 fragment read p of the NEXT k-step (stage slots
+  // ra / rb, k-step rq, into the other buffer), behind the odd pairs 17..31 the LDS-DMA pieces pb .. pb+7 into half-slot
+  // ps -- one small group of feed instructions per gap, pinned with sched_barrier(0) so the matrix pipe (one wave per
+  // SIMD: nobody else fills it) never waits behind a clump of LDS / LDS-DMA issues.
+  auto kstep = [&](int buf, int ra, int rb, int rq, int pb, int ps) __attribute__((always_inline)) {
+    kstep_open();
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      const int nb = p >> 2, mb = (p & 3) * 2;
+      acc[nb][mb] = mfma16<T>(fw[buf][nb], fx[buf][mb], acc[nb][mb]);
+      acc[nb][mb + 1] = mfma16<T>(fw[buf][nb], fx[buf][mb + 1], acc[nb][mb + 1]);
+      sched_fence();
+      if (p < 16) rd1(ra, rb, rq, buf ^ 1, p);
+      if (p >= 16 && (p & 1)) issue(pb + ((p - 17) >> 1), ps);
+      sched_fence();
+    }
   };
   // prologue: A_0 B_0 A_1 B_1 into half-slots 0..3
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if (j == nst) park();
 #pragma unroll
-    for (int p = 0; p < (j == 1 ? 12 : 16); ++p) issue(p, 2 * j + (p >> 3));  // B_1[4:8] goes out in stage 0
+    for (int p = 0; p < 16; ++p) issue(p, 2 * j + (p >> 3));
   }
   wait_vmcnt<0>();
   raw_barrier();
 #pragma unroll
-  for (int q = 0; q < 8; ++q) rd1(0, 1, 0, 0, q);
+  for (int r = 0; r < 16; ++r) rd1(0, 1, 0, 0, r);
   dma_on = false;
   for (int s0 = 0; s0 < nst; s0 += kXSlots) {
 #pragma unroll
     for (int u = 0; u < kXSlots; ++u) {
       const int s = s0 + u;
       if (s < nst) {
-        const int sa = (2 * u) % kXSlots, sb = (2 * u + 1) % kXSlots;                  // A_s, B_s
-        const int sa1 = (2 * u + 2) % kXSlots, sb1 = (2 * u + 3) % kXSlots;            // A_{s+1}, B_{s+1}
-        const int sa2 = (2 * u + 4) % kXSlots;                                         // A_{s+2} (= slot of B_{s-1})
-        const int sb2 = sa;                                                            // B_{s+2} (= slot of A_s)
-        // The 8 fragment reads of a k-step go into its first six gaps (2 2 1 1 1 1) so the last one has more than
-        // an LDS latency to land before the next k-step's first MFMA; four LDS-DMA pieces fill gaps 2..5 of every
-        // k-step: B_{s+1}[4:8] | A_{s+2}[0:4] | A_{s+2}[4:8] | B_{s+2}[0:4].
-        // k-step 0 | fragments of k-step 1
+        const int sa = (2 * u) % kXSlots, sb = (2 * u + 1) % kXSlots;        // A_s, B_s
+        const int sa1 = (2 * u + 2) % kXSlots, sb1 = (2 * u + 3) % kXSlots;  // A_{s+1}, B_{s+1}
+        const int sa2 = (2 * u + 4) % kXSlots;                               // A_{s+2} (= slot of B_{s-1})
+        const int sb2 = sa;                                                  // B_{s+2} (= slot of A_s)
         sched_fence();
-        kstep_open();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          mfma_pair(0, p);
-          sched_fence();
-          if (p < 2) rd1(sa, sb, 1, 1, 2 * p), rd1(sa, sb, 1, 1, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa, sb, 1, 1, p + 2), issue(12 + p - 2, sb1);
-          sched_fence();
-        }
         if (s + 2 == nst) park();
-        // k-step 1 | fragments of k-step 2
-        kstep_open();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          mfma_pair(1, p);
-          sched_fence();
-          if (p < 2) rd1(sa, sb, 2, 0, 2 * p), rd1(sa, sb, 2, 0, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa, sb, 2, 0, p + 2), issue(p - 2, sa2);
-          sched_fence();
-        }
-        // k-step 2 | fragments of k-step 3: the last reads of stage s
-        kstep_open();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          mfma_pair(0, p);
-          sched_fence();
-          if (p < 2) rd1(sa, sb, 3, 1, 2 * p), rd1(sa, sb, 3, 1, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa, sb, 3, 1, p + 2), issue(4 + p - 2, sa2);
-          sched_fence();
-        }
+        kstep(0, sa, sb, 1, 0, sa2);  // k-step 0 | second-half fragments of stage s | A_{s+2}
         // hand-off: stage s+1 has landed for everybody; everybody's reads of stage s are in registers
         if (!(DBG & 4)) wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 newest (A_{s+2}) stay in flight
         wait_lgkmcnt0();
         if (!(DBG & 8)) raw_barrier();
         sched_fence();
-        // k-step 3 | fragments of k-step 0 of stage s+1, B_{s+2}[0:4] into the slot A_s vacated
-        kstep_open();
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-          mfma_pair(1, p);
-          sched_fence();
-          if (p < 2) rd1(sa1, sb1, 0, 0, 2 * p), rd1(sa1, sb1, 0, 0, 2 * p + 1);
-          if (p >= 2 && p < 6) rd1(sa1, sb1, 0, 0, p + 2), issue(8 + p - 2, sb2);
-          sched_fence();
-        }
+        kstep(1, sa1, sb1, 0, 8, sb2);  // k-step 1 | first-half fragments of stage s+1 | B_{s+2} into the slot A_s vacated
       }
     }
   }
@@ -655,20 +708,18 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   wait_lgkmcnt0();
   raw_barrier();
   TAMD_CLOCK_END
-  if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per register quad
+  if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per accumulator block
     float* ws = g.ws + (int64_t)split * g.M * g.N;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int64_t m = m0 + wm * 128 + mi * 32 + l31;
+    for (int mb = 0; mb < 8; ++mb) {
+      const int64_t m = m0 + wm * 128 + mb * 16 + l15;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int64_t n = n0 + wn * 128 + ni * 32 + 8 * qd + 4 * hi;
-          if (m < g.M && n < g.N)
-            st16(ws + m * g.N + n, u32x4{f32_as_u32(acc[ni][mi][qd * 4 + 0]), f32_as_u32(acc[ni][mi][qd * 4 + 1]),
-                                         f32_as_u32(acc[ni][mi][qd * 4 + 2]), f32_as_u32(acc[ni][mi][qd * 4 + 3])});
-        }
+      for (int nb = 0; nb < 8; ++nb) {
+        const int64_t n = n0 + wn * 128 + nb * 16 + 4 * g4;
+        if (m < g.M && n < g.N)
+          st16(ws + m * g.N + n, u32x4{f32_as_u32(acc[nb][mb][0]), f32_as_u32(acc[nb][mb][1]), f32_as_u32(acc[nb][mb][2]),
+                                       f32_as_u32(acc[nb][mb][3])});
+      }
     }
     return;
   }
@@ -677,7 +728,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
                             (n0 >> 1) + wn * 64, lane);
     return;
   }
-  gemm_epilogue<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT, 4, 4>(
+  gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(
       g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, lane);
 }
 

@@ -114,6 +114,57 @@ __global__ __launch_bounds__(512) void bw_probe_kernel(const char* __restrict__ 
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+
+// MFMA power probe: every wave (one per SIMD: 512 registers) runs `iters` rounds of 256 accumulator registers' worth of
+// independent MFMAs on operands read once from `in` (random bits -> realistic toggling), rotating through 8 A and 8 B
+// operand registers the way a 128x128 wave tile does.  MODE 0: 16 x v_mfma_f32_32x32x16_bf16 per round (4 A x 4 B);
+// MODE 1: 64 x v_mfma_f32_16x16x32_bf16 per round (8 A x 8 B): the same flops per round.  Stores {shader ticks,
+// real-time ticks} per workgroup: which shape does more work inside the power budget?  tools/mfma_power.py
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void mfma_power_kernel(const unsigned int* __restrict__ in, int iters,
+                                                             unsigned long long* clk, float* sink) {
+  const int lane = threadIdx.x & 63;
+  u32x4 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] = ld16(in + ((size_t)(blockIdx.x * 7 + i) % 61) * 256 + lane * 4);
+    b[i] = ld16(in + ((size_t)(blockIdx.x * 5 + i + 8) % 61) * 256 + lane * 4);
+  }
+  const unsigned long long t0 = device_clock(), r0 = device_realtime();
+  float out = 0.f;
+  if (MODE == 0) {
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          acc[i] = mfma32<bf16_t>(a[ks * 4 + (i >> 2)], b[ks * 4 + (i & 3)], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out += acc[i][lane & 15];
+  } else {
+    f32x4 acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) acc[i] = mfma16<bf16_t>(a[i >> 3], b[i & 7], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) out += acc[i][lane & 3];
+  }
+  if (threadIdx.x == 0) {
+    clk[2 * blockIdx.x] = device_clock() - t0;
+    clk[2 * blockIdx.x + 1] = device_realtime() - r0;
+  }
+  if (out == 12345.678f) sink[0] = out;
+}
+
 }  // namespace tamd
 
 using namespace tamd;
@@ -131,6 +182,18 @@ extern "C" int tamd_bw_probe(const void* buf, size_t bytes, int seg, size_t row_
   return launch_status();
 }
 
+
+// in: 61 x 256 u32 of operand bits; clk: uint64[2 * blocks]; flops per workgroup = iters * 4 waves * 2 * 32 * 32 * 16 * 32
+extern "C" int tamd_mfma_power(const void* in, int iters, int mode, int blocks, void* clk, void* sink, tamd_stream_t stream) {
+  if (!in || !clk || !sink) return TAMD_E_NULL;
+  if (mode == 0)
+    hipLaunchKernelGGL((mfma_power_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, TAMD_STREAM(stream),
+                       (const unsigned int*)in, iters, (unsigned long long*)clk, (float*)sink);
+  else
+    hipLaunchKernelGGL((mfma_power_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, TAMD_STREAM(stream),
+                       (const unsigned int*)in, iters, (unsigned long long*)clk, (float*)sink);
+  return launch_status();
+}
 
 // in: 4096 u32 (16 KiB), in2: 64 u32, out: 4096 u32.  One wave.
 extern "C" int tamd_probe(const void* in, const void* in2, void* out, int which, int dtype, tamd_stream_t stream) {
