@@ -20,6 +20,11 @@ int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N,
  * NULL switches it off.  tools/gemm_clock.py */
 int tamd_gemm_set_clock_buffer(void* buf);
 
+/* Ablation selector for the full-line GEMM kernel (row-major operands, plain epilogue; WRONG RESULTS by design):
+ * bit mask 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier;
+ * supported values 0, 1, 2, 4, 8, 12, 15.  tools/gemm_fl_dbg.py */
+int tamd_gemm_set_dbg(int dbg);
+
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
  * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
  * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */

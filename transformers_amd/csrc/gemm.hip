@@ -658,6 +658,8 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   // ra / rb, k-step rq, into the other buffer), behind the odd pairs 17..31 the LDS-DMA pieces pb .. pb+7 into half-slot
   // ps -- one small group of feed instructions per gap, pinned with sched_barrier(0) so the matrix pipe (one wave per
   // SIMD: nobody else fills it) never waits behind a clump of LDS / LDS-DMA issues.
+  // (placing the pieces behind every fourth pair instead, and staggering the four waves' piece gaps one pair apart, both
+  // measured +-1 %: profiles/r02i_gemm_piece_placement.jsonl)
   auto kstep = [&](int buf, int ra, int rb, int rq, int pb, int ps) __attribute__((always_inline)) {
     kstep_open();
 #pragma unroll
@@ -762,6 +764,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
 
 // ============================================================================================ host dispatch
 #ifndef TAMD_GEMM_KERNELS_ONLY  // (tools/gemm_isa.sh instantiates single kernels for a look at their ISA)
+#ifdef TAMD_DIAG
+// ablation selector of the diagnostic build (tamd_gemm_set_dbg, include/tamd_diag.h; TAMD_GEMM_DBG in the environment
+// sets the initial value): see the DBG template parameter of gemm_fl_kernel
+static int g_gemm_dbg = -1;
+static int gemm_diag_dbg() {
+  if (g_gemm_dbg < 0) {
+    const char* e = getenv("TAMD_GEMM_DBG");
+    g_gemm_dbg = e ? atoi(e) : 0;
+  }
+  return g_gemm_dbg;
+}
+#endif
 #define TAMD_EPI_SWITCH(LAUNCH)                                           \
   switch (epilogue) {                                                     \
     case TAMD_EPI_NONE: LAUNCH(TAMD_EPI_NONE, TAMD_ACT_NONE)              \
@@ -802,10 +816,7 @@ template <typename T, bool A_KM, bool B_KN>
 static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
 #ifdef TAMD_DIAG  // ablation instantiations (wrong results by design): libtamd_diag.so only, never the product library
-  static const int dbg = [] {
-    const char* e = getenv("TAMD_GEMM_DBG");
-    return e ? atoi(e) : 0;
-  }();
+  const int dbg = gemm_diag_dbg();
   if (dbg && epilogue == TAMD_EPI_NONE && !A_KM && !B_KN) {
 #define TAMD_GD(N_)                                                                                             \
   hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, N_>), grid, block, (size_t)kXSmem, \
@@ -814,6 +825,8 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
     switch (dbg) {
       case 1: TAMD_GD(1)
       case 2: TAMD_GD(2)
+      case 4: TAMD_GD(4)
+      case 8: TAMD_GD(8)
       case 12: TAMD_GD(12)
       case 15: TAMD_GD(15)
       default: break;
@@ -868,6 +881,10 @@ static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, h
 using namespace tamd;
 
 #ifdef TAMD_DIAG
+extern "C" int tamd_gemm_set_dbg(int dbg) {
+  g_gemm_dbg = dbg;
+  return TAMD_OK;
+}
 static unsigned long long* g_gemm_clock = nullptr;
 extern "C" int tamd_gemm_set_clock_buffer(void* buf) {
   g_gemm_clock = reinterpret_cast<unsigned long long*>(buf);
