@@ -138,6 +138,32 @@ class GemmTimer:
 
         # every caller (the torch.ops implementations in ops.py / layer_ops.py) looks `raw_gemm` up at call time
         ops.raw_gemm = timed_gemm
+        # the two GEMMs with the SwiGLU product / its backward in the epilogue (same kernel, own entry points)
+        inner_sw, inner_swb = ops.raw_gemm_swiglu, ops.raw_gemm_swiglu_bwd
+
+        def timed_swiglu(x2, wgu, need_gu=True):
+            if not timer.enabled:
+                return inner_sw(x2, wgu, need_gu)
+            (m, k), n = x2.shape, wgu.shape[0]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = inner_sw(x2, wgu, need_gu)
+            e.record()
+            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n * (1.5 if need_gu else 0.5))))
+            return out
+
+        def timed_swiglu_bwd(dy2, wd, gu):
+            if not timer.enabled:
+                return inner_swb(dy2, wd, gu)
+            (m, k), n = dy2.shape, wd.shape[1]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = inner_swb(dy2, wd, gu)
+            e.record()
+            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + 5 * m * n)))  # reads gate|up, writes d_gate|d_up, act
+            return out
+
+        ops.raw_gemm_swiglu, ops.raw_gemm_swiglu_bwd = timed_swiglu, timed_swiglu_bwd
 
     def summary(self):
         if not self.records:
@@ -145,6 +171,46 @@ class GemmTimer:
         fl = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         return dict(launches=len(self.records), flops=fl, ms=ms, bytes=sum(r[3] for r in self.records))
+
+
+def clock_probe(dev, m=32768, n=28672, k=4096):
+    """The clock the GEMM runs at and how busy its matrix pipe is: the gate|up forward GEMM of the workload under the
+    diagnostic build's probe (libtamd_diag.so, include/tamd_diag.h: every workgroup stamps s_memtime and the 100 MHz
+    s_memrealtime around its K loop).  MI355X lowers its clock to stay inside the power budget: 2.5 PFLOP/s is the
+    2.4 GHz figure; `peak_at_clock` is the same arithmetic at the clock measured here."""
+    import ctypes
+
+    import torch
+
+    sys.path.insert(0, str(ROOT / "tools"))
+    import _diag
+    from transformers_amd import ops
+
+    prev = ops.backend()
+    lib = _diag.use_diag()
+    try:
+        x = torch.randn(m, k, device=dev).bfloat16()
+        w = (torch.randn(n, k, device=dev) * 0.02).bfloat16()
+        wgs = (m // 256) * (n // 256)
+        for _ in range(4):
+            ops.raw_gemm(x, w)
+        buf = torch.zeros(2 * wgs, dtype=torch.int64, device=dev)
+        lib.tamd_gemm_set_clock_buffer(ctypes.c_void_p(buf.data_ptr()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.raw_gemm(x, w)
+        e1.record()
+        torch.cuda.synchronize()
+        lib.tamd_gemm_set_clock_buffer(ctypes.c_void_p(0))
+        t = buf.cpu().view(wgs, 2).double()
+        ghz = (t[:, 0] / t[:, 1]).mean().item() * 0.1
+        return {"kernel": f"gemm_fl_kernel {m}x{n}x{k} (gate|up forward), diagnostic build", "clock_GHz": ghz,
+                "mfma_busy_in_k_loop": ((k // 64) * 2048 / t[:, 0]).mean().item(),
+                "k_loop_share_of_kernel": (t[:, 1].sum() * 1e-8 / 256 / (e0.elapsed_time(e1) * 1e-3)).item(),
+                "TFLOPs": 2.0 * m * n * k / (e0.elapsed_time(e1) * 1e-3) / 1e12,
+                "peak_at_clock_TFLOPs": PEAK_BF16_TFLOPS * ghz / 2.4}
+    finally:
+        ops._set_backend(prev)
 
 
 def cpu_baseline(model_cfg, seq, layers, threads=None, iters=3):
@@ -379,6 +445,11 @@ def main():
             "max_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
             "roofline": roofline,
         }
+        if roofline is not None and world == 1 and args.config == "llama3-8b":
+            try:
+                roofline["clock_probe"] = clock_probe(dev)
+            except Exception as e:  # diagnostics only
+                roofline["clock_probe"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.config == "llama3-8b":
             try:
                 line["cpu_baseline"] = cpu_baseline(c["model"], seq, c["model"]["num_hidden_layers"])

@@ -939,17 +939,29 @@ extern "C" int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M,
 }
 #endif  // TAMD_DIAG
 
-// Split-K policy: a 256x256 tile grid that cannot fill the 256 CUs (weight gradients of narrow layers: dW of a
+// Split-K policy.  (1) A 256x256 tile grid that cannot fill the 256 CUs (weight gradients of narrow layers: dW of a
 // 768x3072 BERT projection is 36 tiles over K = tokens) is cut along K so that tiles x splits ~ one workgroup per CU,
-// at least 8 stages (512 k) per split.
+// at least 8 stages (512 k) per split.  (2) A grid of a few rounds whose last round is mostly empty (dW of the Llama-3-8B
+// q|k|v projection: 384 tiles = 1.5 rounds of 256 CUs, 25 % of the machine idle) is cut in 2..4 when the rounds saved
+// outweigh writing and re-reading the fp32 partial tiles:
+//     cost(s) = ceil(tiles * s / 256) / s * stages * 1.4 us  +  (s > 1) * s * M * N * 8 B / 4 TB/s   (s = 1..4)
 static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int epilogue, int* stages_per_split) {
   *stages_per_split = 0;
   if (K % kXK != 0 || (N % 4) != 0 || (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM)) return 1;
   const int64_t tiles = ceil_div(M, kBM) * ceil_div(N, kBN), nst = K / kXK;
-  if (tiles > 128 || nst < 32) return 1;
-  int64_t s = 256 / tiles;
-  if (s > nst / 8) s = nst / 8;
-  if (s > 16) s = 16;
+  if (nst < 32) return 1;
+  int64_t s = 1;
+  if (tiles <= 128) {
+    s = 256 / tiles;
+    if (s > nst / 8) s = nst / 8;
+    if (s > 16) s = 16;
+  } else if (tiles < 2048 && nst >= 128) {  // integer nanoseconds (ops.gemm_workspace_bytes mirrors this exactly)
+    int64_t best = 0;
+    for (int64_t c = 1; c <= 4; ++c) {
+      const int64_t cost = ceil_div(tiles * c, 256) * nst * 1400 / c + (c > 1 ? c * M * N / 500 : 0);
+      if (c == 1 || cost * 100 < best * 97) best = cost, s = c;  // a split has to win by 3 %
+    }
+  }
   if (s < 2) return 1;
   const int64_t sps = ceil_div(nst, s);
   *stages_per_split = (int)sps;

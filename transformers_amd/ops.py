@@ -441,9 +441,17 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int) -> int:
     if k % 64 or n % 4 or epilogue not in (EPI_NONE, EPI_ACCUM):
         return 0
     tiles, nst = -(-m // 256) * -(-n // 256), k // 64
-    if tiles > 128 or nst < 32:
+    if nst < 32:
         return 0
-    s = min(256 // tiles, nst // 8, 16)
+    s = 1
+    if tiles <= 128:
+        s = min(256 // tiles, nst // 8, 16)
+    elif tiles < 2048 and nst >= 128:  # a few rounds with a mostly empty last one: see gemm_choose_splits
+        best = 0
+        for c in range(1, 5):
+            cost = -(-tiles * c // 256) * nst * 1400 // c + (c * m * n // 500 if c > 1 else 0)
+            if c == 1 or cost * 100 < best * 97:
+                best, s = cost, c
     if s < 2:
         return 0
     sps = -(-nst // s)
