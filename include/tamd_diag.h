@@ -25,6 +25,11 @@ int tamd_gemm_set_clock_buffer(void* buf);
  * supported values 0, 1, 2, 4, 8, 12, 15.  tools/gemm_fl_dbg.py */
 int tamd_gemm_set_dbg(int dbg);
 
+/* Phase trace of the attention forward kernel: while `buf` (uint64[32], device memory) is set, workgroup 0 of every
+ * tamd_attn_fwd launch stores per-wave shader-clock sums of its tile-loop phases at buf[wave * 8 + phase]
+ * (0 tile-load issue, 1 K.Q^T, 2 mask + softmax, 3 P.V, 4 vmcnt wait, 5 barrier).  NULL switches it off. */
+int tamd_attn_set_trace(void* buf);
+
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
  * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
  * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */

@@ -84,6 +84,7 @@ def lint_kernel(name, lines):
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("src,flags", [("attention_bwd_dkdv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]),
+                                       ("attention.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
                                        ("gemm.hip", [])])
 def test_untracked_lds_reads_are_not_touched_before_their_wait(src, flags, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

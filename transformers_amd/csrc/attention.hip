@@ -27,14 +27,16 @@
 namespace tamd {
 
 template <typename T, int D, bool CAUSAL, bool HAS_MASK, bool DROP>
-__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
+// (two workgroups per CU where the registers allow it: the dropout variants at D = 128 need more than 256)
+__global__ __launch_bounds__(kAttnThreads, (DROP && D > 64) ? 1 : 2) void attn_fwd_kernel(AttnArgs a) {
   constexpr int ROWB = D * 2;
   constexpr int TILEB = kKB * ROWB;       // one K or V tile
   constexpr int KS = D / 16;              // QK^T k-steps
   constexpr int DT = D / 32;              // output d-tiles
   constexpr int OROWB = ROWB + 16;        // padded staging row
   TAMD_DYN_SMEM(smem);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = wave_id_uniform();
   const int hi = lane >> 5, l31 = lane & 31;
 
   // ---- work decode: (b, h, query tile); heavy (late) causal tiles first, K/V-sharing blocks on one XCD
@@ -93,15 +95,37 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
 
   TileOffsets<D> toff;
   toff.init(lane);
+  const unsigned lds0 = lds_base_u32(smem);
   const DropCtx drop = {a.drop_thr, a.seed_lo, a.seed_hi, a.drop_scale};
   const unsigned long long drop_base = (((unsigned long long)b * a.heads_q + h) * a.seq_q + (qrow < a.seq_q ? qrow : 0)) *
                                        (unsigned long long)a.seq_k;
   constexpr float kDeferThr = 6.f;  // skip the O rescale while the row max grows by < 2^6 (cdna guide T13)
 
+  TileFeed<D> feed_k, feed_v;
+  feed_k.init(a.kss, wave, lane);
+  feed_v.init(a.vss, wave, lane);
+  const bool fast_feed = TileFeed<D>::usable(a.kss) && TileFeed<D>::usable(a.vss);
+  // tile t -> LDS buffer buf.  A full tile goes by buffer-addressed LDS-DMA (TileFeed), and inside the tile loop its
+  // pieces are issued one by one behind the K.Q^T MFMAs (an LDS-DMA instruction holds its wave for ~90 cycles: 720 per
+  // tile when the eight were issued in a row; behind an MFMA the matrix pipe works through that time)
+  auto tile_is_fast = [&](int t) { return fast_feed && (t + 1) * kKB <= a.seq_k; };  // (wave-uniform)
+  auto issue_piece = [&](int t, int buf, int n) {  // piece n < 2 * NI of a fast tile: K pieces, then V pieces
+    constexpr int NI = TileFeed<D>::NI;
+    const unsigned k_off = (unsigned)buf * 2u * TILEB, v_off = k_off + TILEB;
+    if (n < NI)
+      feed_k.issue_one(K + (int64_t)t * kKB * a.kss, smem, k_off, wave, n);
+    else
+      feed_v.issue_one(V + (int64_t)t * kKB * a.vss, smem, v_off, wave, n - NI);
+  };
   auto issue = [&](int t, int buf) {
     const unsigned k_off = (unsigned)buf * 2u * TILEB, v_off = k_off + TILEB;
-    issue_kv_tile<T, D>(K, a.kss, t * kKB, a.seq_k, smem, k_off, wave, lane);
-    issue_kv_tile<T, D>(V, a.vss, t * kKB, a.seq_k, smem, v_off, wave, lane);
+    if (tile_is_fast(t)) {
+#pragma unroll
+      for (int n = 0; n < 2 * TileFeed<D>::NI; ++n) issue_piece(t, buf, n);
+    } else {
+      issue_kv_tile<T, D>(K, a.kss, t * kKB, a.seq_k, smem, k_off, wave, lane);
+      issue_kv_tile<T, D>(V, a.vss, t * kKB, a.seq_k, smem, v_off, wave, lane);
+    }
   };
   // packed sequences: q_start is non-decreasing along a row, so no row of this block sees a key before the first
   // visible key of its first row: whole K/V tiles below it are neither loaded nor visited (buffers alternate from t0)
@@ -110,25 +134,61 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
   wait_vmcnt0();
   block_sync();
 
+#ifdef TAMD_DIAG
+  const bool tr = a.trace != nullptr && blockIdx.x == 0;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = tr ? device_clock() : 0ull;
+#endif
   for (int t = t0; t < nkt; ++t) {
     const int cur = t & 1;
-    if (t + 1 < nkt) issue(t + 1, cur ^ 1);
+    // the next tile: a ragged one (the last) is issued here in one go, a full one behind this tile's K.Q^T MFMAs
+    const bool next_fast = t + 1 < nkt && tile_is_fast(t + 1);
+    if (t + 1 < nkt && !next_fast) issue(t + 1, cur ^ 1);
+    TAMD_ATTN_PHASE(0)
     const unsigned k_off = (unsigned)cur * 2u * TILEB, v_off = k_off + TILEB;
     const int kt0 = t * kKB;
     // wave-uniform skip: every key of the tile is above the diagonal for all 32 rows of this wave
     // (packed: ... or below the first visible key of all 32 rows)
     const bool wave_active = (!CAUSAL || (kt0 <= qw0 + 31 + off)) && (kt0 + kKB > klo_min);
     if (wave_active) {
-      // ---- S^T tile [64 keys][32 q] = K . Q^T   (two 32-key sub-tiles)
+      // ---- S^T tile [64 keys][32 q] = K . Q^T   (two 32-key sub-tiles, MFMAs alternate between them)
+      // K fragments through a 5-deep register ring, requested four MFMAs ahead: every read of the loop is issued
+      // untracked (the compiler would put vmcnt(0) -- the next tile's LDS-DMA -- in front of the transposing V reads and
+      // serialise each K read with its MFMA) and waited for with a counted lgkmcnt tied to the fragment register.
+      const unsigned kb = lds0 + k_off, vb = lds0 + v_off;
       f32x16 s[2];
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
+      for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+      {
+        constexpr int NM = 2 * KS;                 // MFMAs
+        constexpr int KA = (DROP || (HAS_MASK && D > 64)) ? 2 : (NM < 8 ? NM : 8);  // K fragments requested ahead (LDS latency under load: several MFMAs)
+        u32x4 kr[KA + 1];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          s[sub] = mfma32<T>(toff.read_row(smem, k_off, sub, ks), qf[ks], s[sub]);
+        for (int i = 0; i < KA; ++i) kr[i] = lds_read16_abs(kb + toff.row[i >> 1], (i & 1) * 32 * ROWB);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          if (i + KA < NM) kr[(i + KA) % (KA + 1)] = lds_read16_abs(kb + toff.row[(i + KA) >> 1], ((i + KA) & 1) * 32 * ROWB);
+          constexpr_wait_frag<KA>(NM - 1 - i, kr[i % (KA + 1)]);
+          s[i & 1] = mfma32<T>(kr[i % (KA + 1)], qf[i >> 1], s[i & 1]);
+          if ((i & 1) && (i >> 1) < 2 * TileFeed<D>::NI && next_fast) issue_piece(t + 1, cur ^ 1, i >> 1);
+        }
       }
+      TAMD_ATTN_PHASE(1)
+      // the first VA V fragments are requested now and land under the softmax arithmetic; P.V requests the others VA
+      // steps ahead (LDS latency under load -- two workgroups' reads and the tile loads -- is several MFMAs)
+      constexpr int NV = DT * 4;
+      constexpr int VA = (DROP || (HAS_MASK && D > 64)) ? 2 : (NV < 7 ? NV : 7);  // (no registers to spare in the dropout / padding-mask variants)
+      u32x4 vr[VA + 1];
+      auto vreq = [&](int i) -> u32x4 {  // step i = (key block i / DT, d-tile i % DT): two transposing reads
+        const int dt = i % DT, j = i / DT;
+        const int rb = ((j >> 1) * 32 + (j & 1) * 16) * ROWB;
+        const u32x2 lo = lds_read8_tr16_abs(vb + toff.tr[dt][0], rb);
+        const u32x2 h2 = lds_read8_tr16_abs(vb + toff.tr[dt][1], rb);
+        return u32x4{lo[0], lo[1], h2[0], h2[1]};
+      };
+#pragma unroll
+      for (int i = 0; i < VA; ++i) vr[i] = vreq(i);
       // ---- mask (diagonal / ragged / padded tiles only: wave-uniform branch, the common tile has no mask code)
       const bool need_mask = HAS_MASK || (kt0 + kKB > a.seq_k) || (CAUSAL && (kt0 + kKB - 1 > qw0 + off)) ||
                              (kt0 < klo_max);
@@ -190,17 +250,31 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
                                    pack2<T>(p[8 * st + 4], p[8 * st + 5]), pack2<T>(p[8 * st + 6], p[8 * st + 7])};
       }
       l_run += psum;
+      TAMD_ATTN_PHASE(2)
       // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]
       // step (sub, st): P registers r = 8*st + j  <->  key = sub*32 + 16*st + 8*(j>>2) + 4*hi + (j&3)
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) oacc[dt] = mfma32<T>(toff.read_tr(smem, v_off, dt, j), pf[j], oacc[dt]);
+      for (int i = 0; i < NV; ++i) {
+        if (i + VA < NV) vr[(i + VA) % (VA + 1)] = vreq(i + VA);
+        constexpr_wait_frag<2 * VA>(2 * (NV - 1 - i), vr[i % (VA + 1)]);
+        oacc[i % DT] = mfma32<T>(vr[i % (VA + 1)], pf[i / DT], oacc[i % DT]);  // consecutive MFMAs: different accumulators
       }
+      TAMD_ATTN_PHASE(3)
+    } else if (next_fast) {  // this wave skips the tile (all its rows are above the diagonal): its share of the loads still goes out
+#pragma unroll
+      for (int n = 0; n < 2 * TileFeed<D>::NI; ++n) issue_piece(t + 1, cur ^ 1, n);
     }
     wait_vmcnt0();
+    TAMD_ATTN_PHASE(4)
     block_sync();
+    TAMD_ATTN_PHASE(5)
   }
+#ifdef TAMD_DIAG
+  if (tr && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.trace[wave * 8 + i] = ph[i];
+  }
+#endif
 
   // ---- finalise: l over both half-waves, normalise, LSE, stage O through LDS, row-wise stores
   l_run += swap32_f32(l_run);
@@ -239,6 +313,10 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(AttnArgs a) {
 using namespace tamd;
 
 namespace {
+
+#ifdef TAMD_DIAG
+unsigned long long* g_attn_trace = nullptr;
+#endif
 
 template <typename T, int D>
 int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
@@ -317,10 +395,24 @@ AttnArgs make_args(const tamd_attn_params* p) {
   a.seed_hi = (unsigned)(p->dropout_seed >> 32);
   a.nqt = (int)ceil_div(p->seq_q, kQB);
   a.xcd_map = ((p->batch * p->heads_kv) % 8 == 0) ? 1 : 0;
+#ifdef TAMD_DIAG
+  a.trace = g_attn_trace;
+#else
+  a.trace = nullptr;
+#endif
   return a;
 }
 
 }  // namespace
+
+#ifdef TAMD_DIAG
+// per-phase shader-clock sums of workgroup 0 of the next tamd_attn_fwd launches: trace[wave * 8 + phase] (uint64[32]),
+// phases: 0 tile-load issue, 1 K.Q^T, 2 mask + softmax, 3 P.V, 4 vmcnt wait, 5 barrier.  tools/attn_phases.py
+extern "C" int tamd_attn_set_trace(void* buf) {
+  g_attn_trace = reinterpret_cast<unsigned long long*>(buf);
+  return TAMD_OK;
+}
+#endif
 
 extern "C" uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index) {
   return dropout_hash((unsigned)seed, (unsigned)(seed >> 32), (unsigned)index, (unsigned)(index >> 32));

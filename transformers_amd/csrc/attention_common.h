@@ -31,7 +31,22 @@ struct AttnArgs {
   unsigned seed_lo, seed_hi;
   int nqt;           // query tiles per (b, h)
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
+  unsigned long long* trace;  // diagnostic build: per-phase shader-clock sums of workgroup 0 (tamd_attn_set_trace), else null
 };
+
+// Diagnostic build only: phase i of the forward tile loop ends here (s_memtime stamps of workgroup 0, summed per wave)
+#ifdef TAMD_DIAG
+#define TAMD_ATTN_PHASE(i_)                              \
+  if (tr) {                                              \
+    asm volatile("" ::: "memory");                       \
+    const unsigned long long now_ = device_clock();      \
+    asm volatile("" ::: "memory");                       \
+    ph[i_] += now_ - tlast;                              \
+    tlast = now_;                                        \
+  }
+#else
+#define TAMD_ATTN_PHASE(i_)
+#endif
 
 // One swizzle serves both read patterns of a [rows][D] tile (rows = keys or queries):
 //   ds_read_b128 of 16 distinct rows at one logical slot  -> needs a bijection of the row bits onto slots,
@@ -60,6 +75,38 @@ __device__ __forceinline__ void issue_kv_tile(const T* __restrict__ base, int64_
     glds16(src, smem, tile_off + (unsigned)inst * 1024u);
   }
 }
+
+// The same tile through buffer-addressed LDS-DMA with loop-invariant lane offsets: the tile's first row goes into the
+// wave-uniform base (one 64-bit scalar add per tile), nothing per-lane is recomputed -- issue_kv_tile spends ~14 VALU /
+// SALU instructions per piece on 64-bit addresses, the bounds test and the zero page (110 per tile and wave, half of
+// what the softmax costs).  Full tiles only (every row < nkeys) and 32-bit offsets (64 rows x stride x 2 B < 2^31); the
+// callers take issue_kv_tile for the ragged last tile.
+template <int D>
+struct TileFeed {
+  static constexpr int NI = (kKB * D * 2) / 1024 / 4;  // pieces per wave
+  unsigned voff[NI];
+  __device__ __forceinline__ void init(int64_t stride, int wave, int lane) {
+    constexpr int ROWB = D * 2, SLOTS = ROWB / 16, RPI = 1024 / ROWB;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int inst = wave * NI + i;
+      const int r = inst * RPI + lane / SLOTS;
+      const int s = (lane % SLOTS) ^ row_swz<D>(r);
+      voff[i] = (unsigned)(((int64_t)r * stride + s * 8) * 2);
+    }
+  }
+  static __device__ __forceinline__ bool usable(int64_t stride) { return stride > 0 && stride * (kKB * 2) < ((int64_t)1 << 31); }
+  template <typename T>
+  __device__ __forceinline__ void issue_one(const T* __restrict__ first_row, char* smem, unsigned tile_off, int wave,
+                                            int i) const {  // piece i < NI of this wave
+    glds16_buf<0>(first_row, voff[i], smem, tile_off + (unsigned)(wave * NI + i) * 1024u);
+  }
+  template <typename T>
+  __device__ __forceinline__ void issue(const T* __restrict__ first_row, char* smem, unsigned tile_off, int wave) const {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue_one(first_row, smem, tile_off, wave, i);
+  }
+};
 
 // Loop-invariant LDS byte offsets of one lane inside a swizzled [64][D] tile (the swizzle terms depend on the
 // lane only), so every tile read in the attention loops is `tile base + offset register + immediate`:
@@ -98,6 +145,31 @@ struct TileOffsets {
     return lds_read16(smem, tile_off + row[ks] + (unsigned)(sub * 32 * D * 2));
   }
 };
+
+// s_waitcnt lgkmcnt(N) that fragment `f` depends on: the MFMA consuming it cannot be scheduled above the wait, and the
+// request of a later fragment (volatile asm too) cannot sink below it.  For LDS reads issued untracked (tamd_device.h)
+// N = the number of reads issued after the one that fills `f` (LDS reads of a wave return in order).
+template <int N>
+__device__ __forceinline__ void wait_frag(u32x4& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+#else
+  (void)f;
+#endif
+}
+
+// wait_frag<min(n, CAP)> for a compile-time-foldable n (unrolled loop index arithmetic)
+template <int CAP>
+__device__ __forceinline__ void constexpr_wait_frag(int n, u32x4& f) {
+  static_assert(CAP <= 15, "lgkmcnt is a 4-bit counter");
+  if (n >= CAP) return wait_frag<CAP>(f);
+#define TAMD_WF(N_) \
+  if (N_ < CAP && n == N_) return wait_frag<(N_ < CAP ? N_ : 0)>(f);
+  TAMD_WF(14) TAMD_WF(13) TAMD_WF(12) TAMD_WF(11) TAMD_WF(10) TAMD_WF(9) TAMD_WF(8) TAMD_WF(7) TAMD_WF(6) TAMD_WF(5) TAMD_WF(4)
+  TAMD_WF(3) TAMD_WF(2) TAMD_WF(1)
+#undef TAMD_WF
+  wait_frag<0>(f);
+}
 
 struct AttnBwdArgs {
   AttnArgs f;
