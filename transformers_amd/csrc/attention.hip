@@ -101,10 +101,9 @@ __global__ __launch_bounds__(kAttnThreads, (DROP && D > 64) ? 1 : 2) void attn_f
                                        (unsigned long long)a.seq_k;
   constexpr float kDeferThr = 6.f;  // skip the O rescale while the row max grows by < 2^6 (cdna guide T13)
 
-  TileFeed<D> feed_k, feed_v;
-  feed_k.init(a.kss, wave, lane);
-  feed_v.init(a.vss, wave, lane);
-  const bool fast_feed = TileFeed<D>::usable(a.kss) && TileFeed<D>::usable(a.vss);
+  TileFeed<D> feed;  // (one set of lane offsets: the fast path wants K and V rows the same distance apart)
+  feed.init(a.kss, wave, lane);
+  const bool fast_feed = TileFeed<D>::usable(a.kss) && a.kss == a.vss;
   // tile t -> LDS buffer buf.  A full tile goes by buffer-addressed LDS-DMA (TileFeed), and inside the tile loop its
   // pieces are issued one by one behind the K.Q^T MFMAs (an LDS-DMA instruction holds its wave for ~90 cycles: 720 per
   // tile when the eight were issued in a row; behind an MFMA the matrix pipe works through that time)
@@ -113,9 +112,9 @@ __global__ __launch_bounds__(kAttnThreads, (DROP && D > 64) ? 1 : 2) void attn_f
     constexpr int NI = TileFeed<D>::NI;
     const unsigned k_off = (unsigned)buf * 2u * TILEB, v_off = k_off + TILEB;
     if (n < NI)
-      feed_k.issue_one(K + (int64_t)t * kKB * a.kss, smem, k_off, wave, n);
+      feed.issue_one(K + (int64_t)t * kKB * a.kss, smem, k_off, wave, n);
     else
-      feed_v.issue_one(V + (int64_t)t * kKB * a.vss, smem, v_off, wave, n - NI);
+      feed.issue_one(V + (int64_t)t * kKB * a.vss, smem, v_off, wave, n - NI);
   };
   auto issue = [&](int t, int buf) {
     const unsigned k_off = (unsigned)buf * 2u * TILEB, v_off = k_off + TILEB;
