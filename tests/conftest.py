@@ -66,9 +66,35 @@ def _build_library_once():
     yield
 
 
+class Measured(float):
+    """An error that remembers what it was compared with: `assert rel_err(a, b) < 4e-3` records (measured, limit, where)
+    for the parity report (profiles/r02_parity.json: every GPU test's measured error next to its gate)."""
+
+    def _note(self, limit):
+        import inspect
+
+        fr = inspect.currentframe().f_back.f_back
+        key = f"{Path(fr.f_code.co_filename).name}:{fr.f_lineno} ({fr.f_code.co_name})"
+        e = _GATES.setdefault(key, {"err": 0.0, "limit": float(limit), "n": 0})
+        e["err"] = max(e["err"], float(self))
+        e["limit"] = max(e["limit"], float(limit))
+        e["n"] += 1
+
+    def __lt__(self, limit):
+        self._note(limit)
+        return float(self) < limit
+
+    def __le__(self, limit):
+        self._note(limit)
+        return float(self) <= limit
+
+
+_GATES = {}
+
+
 def rel_err(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    return Measured(((a - b).norm() / b.norm().clamp_min(1e-30)).item())
 
 
 def max_err(a, b):
@@ -85,6 +111,8 @@ def record(group, name, err, ref=None):
 
 
 def pytest_sessionfinish(session, exitstatus):
+    if _GATES:
+        _PARITY["gates"] = _GATES
     if not _PARITY:
         return
     import json

@@ -109,7 +109,7 @@ def test_generate_with_cache_uses_reference_modules(env):
     with torch.no_grad():
         want = ref(input_ids=ids, use_cache=True)
         got = fast(input_ids=ids.to(env.device), use_cache=True)
-    assert rel_err(got.logits, want.logits) < 2e-2
+    assert rel_err(got.logits, want.logits) < 0.014
     assert got.past_key_values is not None
 
 
@@ -152,7 +152,7 @@ def test_static_cache_prefill_and_decode_match_sdpa(env, padding_side):
 
     want, got = run(ref, "cpu"), run(fast, dev)
     assert got.shape == want.shape == (b, p + steps, cfg.vocab_size)
-    assert rel_err(got[valid], want[valid]) < 2e-2
+    assert rel_err(got[valid], want[valid]) < 0.0099
     # the static path agrees with the dynamic-cache path of the same model (same kernels, sliced K/V)
     with torch.no_grad():
         dyn = fast(input_ids=ids.to(dev), attention_mask=am.to(dev), use_cache=False).logits.float().cpu()
@@ -192,7 +192,7 @@ def test_autocast_with_fp32_master_weights(env):
         assert o.dtype == torch.bfloat16 and o.shape == (1, 24, 4, 64)
         want = torch.nn.functional.scaled_dot_product_attention(q, k.repeat_interleave(2, 1), k.repeat_interleave(2, 1),
                                                                 is_causal=True, scale=0.125).transpose(1, 2)
-        assert rel_err(o, want) < 1e-2
+        assert rel_err(o, want) < 0.0058
 
 
 def test_state_dict_keys_and_fused_views_roundtrip(env):
@@ -408,7 +408,7 @@ def test_packed_sequences_match_reference_and_separate_runs(env):
     g32 = dict(ref32.named_parameters())
     for n, p in fast.named_parameters():
         if "layers.0.self_attn.k_proj" in n or "layers.1.mlp.down_proj" in n:
-            assert rel_err(p.grad, g32[n].grad) < 3e-2, n
+            assert rel_err(p.grad, g32[n].grad) < 0.026, n
     # every sequence alone (its own forward, positions from 0) reproduces its slice of the packed logits
     fast.eval()
     st = 0
@@ -465,13 +465,13 @@ def test_bert_post_ln_block_with_hidden_dropout_matches_reference(env):
         assert 0.8 < keep.float().mean().item() < 0.98
         d = ref.dense(hr)
         yr = ref.LayerNorm((d * keep / (1 - cfg.hidden_dropout_prob)).to(d.dtype) + rr)
-        assert rel_err(yf, yr) < 1e-2
+        assert rel_err(yf, yr) < 0.0002
         g = torch.randn_like(yr)
         yr.backward(g)
         yf.backward(g.to(dev))
-        assert rel_err(hf.grad, hr.grad) < 2e-2 and rel_err(rf.grad, rr.grad) < 2e-2
-        assert rel_err(fast.dense.weight.grad, ref.dense.weight.grad) < 2e-2
-        assert rel_err(fast.LayerNorm.weight.grad, ref.LayerNorm.weight.grad) < 3e-2
+        assert rel_err(hf.grad, hr.grad) < 7.5e-3 and rel_err(rf.grad, rr.grad) < 7.5e-3
+        assert rel_err(fast.dense.weight.grad, ref.dense.weight.grad) < 0.0073
+        assert rel_err(fast.LayerNorm.weight.grad, ref.LayerNorm.weight.grad) < 0.0072
         fast.eval(), ref.eval()
         assert rel_err(fast(hf, rf), ref(hr, rr)) < 1e-2
 
@@ -636,7 +636,7 @@ def test_fused_lm_head_loss(env):
     assert abs(loss.item() - ref.item()) <= 2e-3 * abs(ref.item())
     loss.backward()
     ref.backward()
-    assert rel_err(h.grad, hr.grad) < 1e-2 and rel_err(w.grad, wr.grad) < 1.5e-2
+    assert rel_err(h.grad, hr.grad) < 1e-2 and rel_err(w.grad, wr.grad) < 0.0065
     # eval / no labels: the reference forward, logits present; revert removes the instance-level forward
     fused.eval()
     with torch.no_grad():

@@ -114,11 +114,11 @@ def test_torch_ops_gradients_match_fp32_autograd(env):
     y.backward(g.to(y.dtype))
     yr.backward(g.to(y.dtype).float())
     for a, r in ((x, xr), (w, wr), (b, br), (res, rr)):
-        assert rel_err(a.grad, r.grad) < 6e-3
+        assert rel_err(a.grad, r.grad) < 0.0034
     # gemm with the k-major operand modes is its own transpose
     a2, b2 = _bf(t, n, dev=dev), _bf(t, h, dev=dev)
     dw = T.gemm(a2, b2, True, True)                                      # [n, h] = a2^T . b2
-    assert rel_err(dw, a2.float().t() @ b2.float()) < 4e-3
+    assert rel_err(dw, a2.float().t() @ b2.float()) < 0.0034
     # attention: GQA, causal, fp32 softmax
     bsz, s, hq, hkv, d = (2, 512, 8, 2, 128) if env.big else (2, 48, 4, 2, 64)
     q, k, v = _bf(bsz, s, hq, d, dev=dev, grad=True), _bf(bsz, s, hkv, d, dev=dev, grad=True), _bf(bsz, s, hkv, d,
@@ -130,12 +130,12 @@ def test_torch_ops_gradients_match_fp32_autograd(env):
     sc = sc.masked_fill(torch.ones(s, s, dtype=torch.bool, device=sc.device).triu(1), float("-inf"))
     of = torch.einsum("bhqk,bkhd->bqhd", sc.softmax(-1), vv)
     assert rel_err(o, of) < 4e-3
-    assert rel_err(lse, sc.logsumexp(-1)) < 1e-4
+    assert rel_err(lse, sc.logsumexp(-1)) < 1e-05
     go = torch.randn_like(of)
     o.backward(go.to(o.dtype))
     of.backward(go.to(o.dtype).float())
     for a, r in ((q, qf), (k, kf), (v, vf)):
-        assert rel_err(a.grad, r.grad) < 8e-3
+        assert rel_err(a.grad, r.grad) < 0.0054
     # rmsnorm + swiglu chain through the ops
     gu = _bf(t, 2 * h, dev=dev, grad=True)
     wn = (torch.rand(h) + 0.5).bfloat16().to(dev).requires_grad_(True)
@@ -143,10 +143,10 @@ def test_torch_ops_gradients_match_fp32_autograd(env):
     guf, wnf = gu.detach().float().requires_grad_(True), wn.detach().float().requires_grad_(True)
     a_ = torch.nn.functional.silu(guf[:, :h]) * guf[:, h:]
     outf = wnf * (a_ * torch.rsqrt(a_.pow(2).mean(-1, keepdim=True) + 1e-5))
-    assert rel_err(out, outf) < 8e-3
+    assert rel_err(out, outf) < 0.0068
     out.backward(torch.ones_like(out))
     outf.backward(torch.ones_like(outf))
-    assert rel_err(gu.grad, guf.grad) < 1.5e-2 and rel_err(wn.grad, wnf.grad) < 1.5e-2
+    assert rel_err(gu.grad, guf.grad) < 7e-3 and rel_err(wn.grad, wnf.grad) < 7e-3
 
 
 def test_llama_layer_op_twice_differentiable_graph(env):
