@@ -160,17 +160,37 @@ class GemmTimer:
             s.record()
             out = inner_swb(dy2, wd, gu)
             e.record()
-            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + 5 * m * n)))  # reads gate|up, writes d_gate|d_up, act
+            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + 5 * m * n), "swiglu_bwd"))  # reads gate|up, writes d_gate|d_up, act
             return out
 
         ops.raw_gemm_swiglu, ops.raw_gemm_swiglu_bwd = timed_swiglu, timed_swiglu_bwd
+        inner_rope = getattr(ops, "raw_gemm_rope", None)
+
+        def timed_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim):
+            if not timer.enabled:
+                return inner_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim)
+            (m, k), n = x2.shape, wqkv.shape[0]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = inner_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim)
+            e.record()
+            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n)))
+            return out
+
+        if inner_rope is not None:
+            ops.raw_gemm_rope = timed_rope
 
     def summary(self):
         if not self.records:
             return None
         fl = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return dict(launches=len(self.records), flops=fl, ms=ms, bytes=sum(r[3] for r in self.records))
+        kinds = {}
+        for r in self.records:
+            if len(r) > 4:
+                kinds.setdefault(r[4], []).append(r[1].elapsed_time(r[2]))
+        return dict(launches=len(self.records), flops=fl, ms=ms, bytes=sum(r[3] for r in self.records),
+                    kinds={k: sum(v) / len(v) for k, v in kinds.items()})
 
 
 def clock_probe(dev, m=32768, n=28672, k=4096):
@@ -430,7 +450,7 @@ def main():
                             avg_launch_ms=gs["ms"] / gs["launches"],
                             avg_launch_tflop=gs["flops"] / gs["launches"] / 1e12,
                             avg_launch_algorithmic_bytes=gs["bytes"] / gs["launches"],
-                            gemm_share_of_step_time=gs["ms"] * 1e-3 / dt)
+                            gemm_share_of_step_time=gs["ms"] * 1e-3 / dt, avg_ms_by_kind=gs.get("kinds"))
         line = {
             "metric": metric,
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 4
+#define TAMD_ABI_VERSION 5
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -246,6 +246,14 @@ int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* D
                          int64_t K, int64_t lddy, int64_t ldw, int64_t ldgu, int64_t lddgu, int64_t ldact, int dtype,
                          tamd_stream_t stream);
 
+/* q|k|v projection with apply_rotary_pos_emb in the GEMM epilogue (models/llama/modeling_llama.py:254-262):
+ *   QKV[M, N] = X[M,K] . Wqkv[N,K]^T, rotary embedding on the first rope_cols columns (query + key heads of 128),
+ * cos / sin [cos_batch, seq, 128] (cos_batch 1 = shared by the batch rows).  Bit-identical to tamd_gemm followed by
+ * tamd_rope_inplace.  K % 64 == 0, N and rope_cols multiples of 128. */
+int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const void* cos, const void* sin, int64_t M, int64_t N,
+                   int64_t K, int64_t ldx, int64_t ldw, int64_t ldqkv, int64_t seq, int64_t cos_batch, int64_t rope_cols,
+                   int dtype, tamd_stream_t stream);
+
 /* ------------------------------------------------------------------ attention (MFMA, flash-style) */
 
 /* Scaled-dot-product attention replacing eager_attention_forward / repeat_kv
@@ -300,6 +308,13 @@ struct tamd_attn_bwd_params {
   void* dk;                    /* strides = k strides */
   void* dv;                    /* strides = v strides */
   float* delta;                /* workspace, 2 x [batch, heads_q, seq_q] fp32: rowsum(dO*O), then lse*log2(e) */
+  /* optional (ABI 5): q and k were rotated by apply_rotary_pos_emb before the attention -- dq and dk leave through the
+   * transposed rotation (bit-identical to tamd_rope_inplace(conj) on the stored gradients).  cos / sin
+   * [rope_cos_batch, seq, 128] in the storage dtype, rope_cos_batch 1 or batch; head_dim 128, seq_q == seq_k;
+   * NULL, NULL, 0 = gradients of q, k as given. */
+  const void* rope_cos;
+  const void* rope_sin;
+  int64_t rope_cos_batch;
 };
 int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream);
 

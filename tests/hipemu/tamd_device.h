@@ -384,6 +384,7 @@ inline void wait_vmcnt() {  // oldest-first completion until at most N remain in
   for (size_t i = 0; i < done; ++i) memcpy(q[i].dst, q[i].data, (size_t)q[i].size);
   q.erase(q.begin(), q.begin() + done);
 }
+inline int lane_id_mbcnt() { return hipemu::cur_lane(); }
 inline void wait_lgkmcnt0() {}
 inline void raw_barrier() { __syncthreads(); }
 inline void sched_fence() {}

@@ -673,3 +673,61 @@ def test_dropout_add_layernorm(env, cols):
     # p = 0 is the plain fused add + LayerNorm
     y0 = ops.dropout_add_layernorm(x.detach(), r.detach(), w.detach(), b.detach(), 1e-12, 0.0, seed)
     assert torch.equal(y0, ops.layernorm(x.detach(), w.detach(), b.detach(), 1e-12, residual=r.detach())[0])
+
+
+def test_gemm_rope_epilogue_is_bit_identical_to_unfused(env):
+    """apply_rotary_pos_emb in the q|k|v GEMM epilogue (tamd_gemm_rope, models/llama/modeling_llama.py:254-262): the
+    same bits as the projection followed by the in-place rotary kernel -- batch-shared and per-batch cos / sin, ragged
+    token counts, value heads untouched."""
+    torch.manual_seed(41)
+    dev = env.device
+    for (b, s, hq, hkv, k) in ([(2, 1024, 32, 8, 4096), (3, 100, 4, 2, 256)] if env.big else [(2, 72, 2, 1, 128), (1, 130, 1, 1, 64)]):
+        d, t = 128, b * s
+        n = (hq + 2 * hkv) * d
+        x = torch.randn(t, k).bfloat16().to(dev)
+        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+        for cb in (1, b):
+            ang = torch.rand(cb, s, d // 2) * 6.28
+            cos = torch.cat([ang.cos(), ang.cos()], -1).bfloat16().to(dev)
+            sin = torch.cat([ang.sin(), ang.sin()], -1).bfloat16().to(dev)
+            if cb == 1:
+                cos, sin = cos[0], sin[0]
+            assert ops.gemm_rope_supported(x, w, cos, d)
+            ref = ops.raw_gemm(x, w)
+            ops.raw_rope_(ref, cos, sin, s, hq + hkv, d)
+            got = ops.raw_gemm_rope(x, w, cos, sin, s, hq + hkv, d)
+            assert torch.equal(got, ref), (b, s, hq, hkv, k, cb)
+
+
+def test_attention_backward_rope_epilogue_is_bit_identical_to_unfused(env):
+    """The transposed rotary embedding on dq / dk inside the attention backward kernels (tamd_attn_bwd rope_cos /
+    rope_sin) gives the bits of the stored gradients followed by tamd_rope_inplace(conj): shared and per-batch cos / sin,
+    GQA, ragged sequence length; dv untouched."""
+    import math
+
+    torch.manual_seed(43)
+    dev = env.device
+    for (b, s, hq, hkv) in ([(2, 1000, 8, 2), (1, 4096, 4, 4)] if env.big else [(2, 72, 2, 1), (1, 130, 2, 2)]):
+        d = 128
+        qkv = torch.randn(b * s, (hq + 2 * hkv) * d).bfloat16().to(dev)
+        q = qkv[:, : hq * d].view(b, s, hq, d)
+        k = qkv[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d)
+        v = qkv[:, (hq + hkv) * d:].view(b, s, hkv, d)
+        scale = 1 / math.sqrt(d)
+        o, lse = ops.raw_attn_fwd(q, k, v, scale, True)
+        do = torch.randn(b, s, hq, d).bfloat16().to(dev)
+        for cb in (1, b):
+            ang = torch.rand(cb, s, d // 2) * 6.28
+            cos = torch.cat([ang.cos(), ang.cos()], -1).bfloat16().to(dev)
+            sin = torch.cat([ang.sin(), ang.sin()], -1).bfloat16().to(dev)
+            if cb == 1:
+                cos, sin = cos[0], sin[0]
+            ref = torch.zeros_like(qkv)
+            rq, rk, rv = ref[:, : hq * d].view(b, s, hq, d), ref[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d), ref[:, (hq + hkv) * d:].view(b, s, hkv, d)
+            ops.raw_attn_bwd(q, k, v, o, lse, do, scale, True, dq=rq, dk=rk, dv=rv)
+            ops.raw_rope_(ref, cos, sin, s, hq + hkv, d, conj=True)
+            got = torch.zeros_like(qkv)
+            gq, gk, gv = got[:, : hq * d].view(b, s, hq, d), got[:, hq * d: (hq + hkv) * d].view(b, s, hkv, d), got[:, (hq + hkv) * d:].view(b, s, hkv, d)
+            assert ops.attn_bwd_rope_supported(q, k, cos, d)
+            ops.raw_attn_bwd(q, k, v, o, lse, do, scale, True, dq=gq, dk=gk, dv=gv, rope=(cos, sin))
+            assert torch.equal(got, ref), (b, s, hq, hkv, cb)

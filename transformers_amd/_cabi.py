@@ -14,7 +14,7 @@ TAMD_BF16, TAMD_F16, TAMD_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 GEMM_A_KM, GEMM_B_KN = 1, 2
 EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_BIAS_ACT, EPI_ACCUM = 0, 1, 2, 3, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 P = c_void_p
 I64 = c_int64
@@ -34,7 +34,8 @@ class AttnParams(Structure):
 
 
 class AttnBwdParams(Structure):
-    _fields_ = [("fwd", AttnParams), ("dout", P), ("dq", P), ("dk", P), ("dv", P), ("delta", P)]
+    _fields_ = [("fwd", AttnParams), ("dout", P), ("dq", P), ("dk", P), ("dv", P), ("delta", P), ("rope_cos", P),
+                ("rope_sin", P), ("rope_cos_batch", I64)]
 
 
 # name -> (restype, argtypes); order and types mirror include/tamd.h
@@ -73,6 +74,7 @@ SIGNATURES = {
                              P]),
     "tamd_gemm_swiglu": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_gemm_swiglu_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
+    "tamd_gemm_rope": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),
     "tamd_attn_bwd": (c_int, [POINTER(AttnBwdParams), P]),

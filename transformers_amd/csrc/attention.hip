@@ -435,6 +435,12 @@ extern "C" int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t
   const int chk = attn_check(&p->fwd);
   if (chk != TAMD_OK) return chk;
   if (!p->dout || !p->dq || !p->dk || !p->dv || !p->delta || !p->fwd.lse) return TAMD_E_NULL;
+  if ((p->rope_cos != nullptr) != (p->rope_sin != nullptr)) return TAMD_E_NULL;
+  if (p->rope_cos != nullptr) {  // rotary on the way out: heads of 128, positions = row indices (no KV offset)
+    if (p->fwd.head_dim != 128 || p->fwd.seq_q != p->fwd.seq_k || (p->rope_cos_batch != 1 && p->rope_cos_batch != p->fwd.batch))
+      return TAMD_E_ARG;
+    if (!aligned16(p->rope_cos) || !aligned16(p->rope_sin)) return TAMD_E_ALIGN;
+  }
   if (!aligned16(p->dout) || !aligned16(p->dq) || !aligned16(p->dk) || !aligned16(p->dv)) return TAMD_E_ALIGN;
   const AttnArgs a = make_args(&p->fwd);
   hipStream_t s = TAMD_STREAM(stream);

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   T* dK = reinterpret_cast<T*>(g.dk) + (int64_t)b * a.ksb + (int64_t)hkv * a.ksh;
   T* dV = reinterpret_cast<T*>(g.dv) + (int64_t)b * a.vsb + (int64_t)hkv * a.vsh;
   const unsigned st = (unsigned)wave * (32u * OROWB);
-  store_rows_via_lds<T, D>(dkacc, g.scale, smem, st, dK, a.kss, kw0, a.seq_k, lane);
+  store_rows_via_lds<T, D>(dkacc, g.scale, smem, st, dK, a.kss, kw0, a.seq_k, lane, reinterpret_cast<const T*>(g.rope_cos),
+                           reinterpret_cast<const T*>(g.rope_sin),
+                           (g.rope_cos_batch == 1 ? 0 : (int64_t)b * a.seq_k) + kw0);  // (rotary: key position = row index)
   wave_lockstep_point();
   store_rows_via_lds<T, D>(dvacc, 1.f, smem, st, dV, a.vss, kw0, a.seq_k, lane);
 }

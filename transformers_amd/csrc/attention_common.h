@@ -179,14 +179,24 @@ struct AttnBwdArgs {
   void* dv;
   float* delta;
   float scale;
+  // optional: the transposed rotary embedding applied to dq / dk on their way out (head_dim 128); null = none
+  const void* rope_cos;
+  const void* rope_sin;
+  int rope_cos_batch;
 };
 
 
 // stage a wave's [32 rows][D] fp32-accumulator tile (C layout: lane column = row, registers = d) through LDS
-// and write it as full rows:  dst[(row0 + r) * stride + d]
+// and write it as full rows:  dst[(row0 + r) * stride + d].
+// cosp != null (D = 128): the rows are gradients of rotated query / key heads and leave through the transposed rotary
+// embedding (the backward of apply_rotary_pos_emb, models/llama/modeling_llama.py:130-160):
+//     dx[d] = round(round(dy[d]*cos[d]) + round(dy[d+64]*sin[d])),  dx[d+64] = round(round(dy[d+64]*cos[d]) - round(dy[d]*sin[d]))
+// on the rounded staged values, with rope_kernel's roundings (elementwise.hip, conj): bit-identical to storing dy and
+// running tamd_rope_inplace(conj) afterwards.  cos / sin rows: crow0 + r.
 template <typename T, int D>
 __device__ __forceinline__ void store_rows_via_lds(const f32x16* acc, float mul, char* smem, unsigned st_off, T* dst,
-                                                   int64_t stride, int row0, int nrows, int lane) {
+                                                   int64_t stride, int row0, int nrows, int lane,
+                                                   const T* cosp = nullptr, const T* sinp = nullptr, int64_t crow0 = 0) {
   constexpr int ROWB = D * 2, OROWB = ROWB + 16, DT = D / 32;
   const int hi = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -203,7 +213,21 @@ __device__ __forceinline__ void store_rows_via_lds(const f32x16* acc, float mul,
 #pragma unroll
   for (int it = 0; it < 32 / RPI; ++it) {
     const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
-    const u32x4 v = lds_read16(smem, st_off + (unsigned)row * OROWB + (unsigned)slot * 16u);
+    u32x4 v = lds_read16(smem, st_off + (unsigned)row * OROWB + (unsigned)slot * 16u);
+    if (D == 128 && cosp != nullptr) {  // (wave-uniform)
+      const u32x4 vp = lds_read16(smem, st_off + (unsigned)row * OROWB + (unsigned)(slot ^ (SLOTS / 2)) * 16u);
+      if (row0 + row < nrows) {
+        float x[8], xp[8], cs[8], sn[8], o[8];
+        unpack16<T>(v, x);
+        unpack16<T>(vp, xp);
+        unpack16<T>(ld16(cosp + (crow0 + row) * D + slot * 8), cs);
+        unpack16<T>(ld16(sinp + (crow0 + row) * D + slot * 8), sn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o[e] = round_through<T>(x[e] * cs[e]) + round_through<T>((slot < SLOTS / 2 ? xp[e] : -xp[e]) * sn[e]);
+        v = pack16<T>(o);
+      }
+    }
     if (row0 + row < nrows) st16(dst + (int64_t)(row0 + row) * stride + slot * 8, v);
   }
 }

@@ -83,10 +83,14 @@ struct GemmArgs {
   // [M, 2*n_half] gate|up output or nullptr when nothing will be differentiated
   void* C2;
   int64_t ldc2, n_half;
+  // rotary epilogue (kEpiRope): R = cos, C2 = sin ([cos_batch, seq, 128] in the storage dtype), n_half = the leading
+  // columns to rotate (query + key heads, a multiple of 128), seq / cos_batch below
+  int64_t seq, cos_batch;
 };
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
 constexpr int kEpiSwiGLUBwd = 102;
+constexpr int kEpiRope = 103;
 
 // the LlamaMLP inner product (models/llama/modeling_llama.py:174-176; same expression as swiglu_fwd_kernel in
 // elementwise.hip, so the fused epilogue and the stand-alone kernel agree bit for bit)
@@ -191,29 +195,36 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
   // flight instead of 4 (the way out was latency-bound at ~2.7 TB/s: 1.05 ms of the 3.8 ms SwiGLU-backward GEMM)
   constexpr int NR = (EPI == kEpiSwiGLUBwd) ? 2 : ((EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0);
   constexpr int NIT = 64 / RPI;
+  // (the SwiGLU backward carries two loads per row segment: in two chunks of 8 iterations -- 64 registers of loads in
+  // flight -- so that nothing spills; a kernel with scratch also throttles how many of its waves the CU runs)
+  constexpr int CH = (NR == 2 && NIT > 8) ? 8 : NIT;
 #pragma unroll
   for (int half = 0; half < HALVES; ++half) {
-    u32x4 pre[NR > 0 ? NIT * NR : 1];
-    if (NR > 0) {
+    u32x4 pre[NR > 0 ? CH * NR : 1];
+    auto preload = [&](int it0) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
+      for (int i = 0; i < CH; ++i) {
+        const int it = it0 + i;
         const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
         const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
         const bool ok = gm_ < g.M && gn < g.N;
         if (EPI == kEpiSwiGLUBwd) {
-          pre[2 * it] = ok ? ld16(R + gm_ * g.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
-          pre[2 * it + 1] = ok ? ld16(R + gm_ * g.ldr + g.n_half + gn) : u32x4{0u, 0u, 0u, 0u};
+          pre[2 * i] = ok ? ld16(R + gm_ * g.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
+          pre[2 * i + 1] = ok ? ld16(R + gm_ * g.ldr + g.n_half + gn) : u32x4{0u, 0u, 0u, 0u};
         } else {
           const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
-          pre[it] = ok ? ld16(rp) : u32x4{0u, 0u, 0u, 0u};
+          pre[i] = ok ? ld16(rp) : u32x4{0u, 0u, 0u, 0u};
         }
       }
       sched_fence();
-    }
+    };
+    if (NR > 0) preload(0);
     stage(half);
     wave_lockstep_point();  // wave-private region: this wave's writes are ordered before its reads
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
+      if (NR > 0 && it > 0 && it % CH == 0) preload(it);
+      const int pi = it % CH;  // index of this iteration's preloaded operands
       const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
       const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
       u32x4 v = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)slot * 16u);
@@ -223,8 +234,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
         if (gm_ < g.M && gn < g.N) {
           float d[8], gt[8], up[8], dg[8], du[8], ac[8];
           unpack16<T>(v, d);
-          unpack16<T>(pre[NR == 2 ? 2 * it : 0], gt);
-          unpack16<T>(pre[NR == 2 ? 2 * it + 1 : 0], up);
+          unpack16<T>(pre[NR == 2 ? 2 * pi : 0], gt);
+          unpack16<T>(pre[NR == 2 ? 2 * pi + 1 : 0], up);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float sl = round_through<T>(gemm_silu(gt[e]));
@@ -238,11 +249,31 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
         }
         continue;
       }
+      if (EPI == kEpiRope && NCOLS == 128 && col0 < g.n_half) {
+        // apply_rotary_pos_emb on a query / key head (this wave's 128 columns are exactly one head of 128):
+        //   out = round(round(x * cos) + round(rotate_half(x) * sin)),  rotate_half(x)[d] = -x[d+64] (d < 64), x[d-64]
+        // with the roundings of rope_kernel (elementwise.hip), on the rounded projection staged in LDS: bit-identical
+        // to tamd_gemm followed by tamd_rope_inplace
+        if (gm_ < g.M && gn < g.N) {
+          const u32x4 vp = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)(slot ^ 8) * 16u);
+          const int64_t crow = (g.cos_batch == 1) ? (gm_ % g.seq) : gm_;
+          float x[8], xp[8], cs[8], sn[8], o[8];
+          unpack16<T>(v, x);
+          unpack16<T>(vp, xp);
+          unpack16<T>(ld16(R + crow * 128 + slot * 8), cs);
+          unpack16<T>(ld16(reinterpret_cast<const T*>(g.C2) + crow * 128 + slot * 8), sn);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o[e] = round_through<T>(x[e] * cs[e]) + round_through<T>((slot < 8 ? -xp[e] : xp[e]) * sn[e]);
+          st16(C + gm_ * g.ldc + gn, pack16<T>(o));
+        }
+        continue;
+      }
       if (gm_ < g.M && gn < g.N) {
         if (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) {
           float a[8], b[8];
           unpack16<T>(v, a);
-          unpack16<T>(pre[NR == 1 ? it : 0], b);
+          unpack16<T>(pre[NR == 1 ? pi : 0], b);
 #pragma unroll
           for (int e = 0; e < 8; ++e) a[e] += b[e];
           v = pack16<T>(a);
@@ -710,8 +741,12 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   wait_lgkmcnt0();
   raw_barrier();
   TAMD_CLOCK_END
+  // (the epilogue takes its lane index from v_mbcnt: kept from the kernel entry it is spilled around the K loop in the
+  // k-major variants, and a kernel with scratch is throttled in how many of its waves a CU runs)
+  const int elane = (A_KM && B_KN) ? lane_id_mbcnt() : lane;
   if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per accumulator block
     float* ws = g.ws + (int64_t)split * g.M * g.N;
+    const int l15 = elane & 15, g4 = elane >> 4;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
       const int64_t m = m0 + wm * 128 + mb * 16 + l15;
@@ -727,11 +762,11 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   }
   if (EPI == kEpiSwiGLU) {
     gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), m0 + wm * 128,
-                            (n0 >> 1) + wn * 64, lane);
+                            (n0 >> 1) + wn * 64, elane);
     return;
   }
-  gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(
-      g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, lane);
+  gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
+      g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
 }
 
 // out[m][n] = round(sum_s ws[s][m][n] (+ out[m][n] if ACCUM)): 4 columns per thread (16-byte reads, 8-byte stores)
@@ -919,6 +954,8 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->C2 = nullptr;
   g->ldc2 = 0;
   g->n_half = 0;
+  g->seq = 1;
+  g->cos_batch = 1;
   return TAMD_OK;
 }
 
@@ -1044,6 +1081,33 @@ extern "C" int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* 
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
   TAMD_DISPATCH_HALF(dtype, {
     hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, kEpiSwiGLU, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
+                       TAMD_STREAM(stream), g);
+    return launch_status();
+  });
+  return TAMD_E_DTYPE;
+}
+
+// q|k|v projection of LlamaAttention with apply_rotary_pos_emb in the GEMM epilogue (models/llama/modeling_llama.py:254-262):
+//   QKV[M, N] = X[M,K] . Wqkv[N,K]^T, then the rotary embedding on the first rope_cols columns (query and key heads of
+// 128; the value heads pass through), cos / sin [cos_batch, seq, 128] indexed by token m (m % seq when cos_batch == 1).
+// Results are bit-identical to tamd_gemm followed by tamd_rope_inplace.
+extern "C" int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const void* cosp, const void* sinp, int64_t M,
+                              int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldqkv, int64_t seq,
+                              int64_t cos_batch, int64_t rope_cols, int dtype, tamd_stream_t stream) {
+  if (!X || !Wqkv || !QKV || !cosp || !sinp) return TAMD_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || seq <= 0 || cos_batch <= 0) return TAMD_E_SHAPE;
+  if ((K % kXK) || (N % 128) || (rope_cols % 128) || rope_cols > N || (ldx % 8) || (ldw % 8) || (ldqkv % 8)) return TAMD_E_SHAPE;
+  if (cos_batch != 1 && cos_batch * seq != M) return TAMD_E_SHAPE;
+  if (!aligned16(X) || !aligned16(Wqkv) || !aligned16(QKV) || !aligned16(cosp) || !aligned16(sinp)) return TAMD_E_ALIGN;
+  GemmArgs g;
+  gemm_fill_args(&g, X, Wqkv, QKV, nullptr, cosp, M, N, K, ldx, ldw, ldqkv, 128);
+  g.C2 = const_cast<void*>(sinp);
+  g.n_half = rope_cols;
+  g.seq = seq;
+  g.cos_batch = cos_batch;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
+  TAMD_DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, kEpiRope, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
                        TAMD_STREAM(stream), g);
     return launch_status();
   });

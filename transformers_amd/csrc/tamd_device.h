@@ -60,6 +60,14 @@ __device__ __forceinline__ void permlane32_swap(unsigned int& a, unsigned int& b
 // wave index inside the workgroup as a provably wave-uniform (SGPR) value
 __device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
+// lane index recomputed from the execution mask (v_mbcnt; all 64 lanes must be active): nothing has to stay in a
+// register -- or get spilled -- for it across a long loop (volatile: a plain builtin would be hoisted back above the loop)
+__device__ __forceinline__ int lane_id_mbcnt() {
+  int x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  return x;
+}
+
 // 64-bit mask of the lanes whose predicate is true
 __device__ __forceinline__ unsigned long long ballot64(bool pred) { return __ballot(pred); }
 

@@ -7,12 +7,15 @@ model classes in `transformers_amd/models/` only call `torch.ops.tamd.llama_laye
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
 from .ops import EPI_RESIDUAL, define_op
 
 T = torch.ops.tamd
+_FUSE_ROPE = os.environ.get("TAMD_FUSE_ROPE", "1") != "0"  # (A/B switch for measurements: rotary in the GEMM / attention epilogues)
 
 
 def _split_qkv(qkv, b, s, hq, hkv, d):
@@ -22,7 +25,7 @@ def _split_qkv(qkv, b, s, hq, hkv, d):
     return q, k, v
 
 
-# forward : rmsnorm -> QKV GEMM -> rope(in place) -> attention -> o_proj GEMM(+residual)
+# forward : rmsnorm -> QKV GEMM with the rotary epilogue -> attention -> o_proj GEMM(+residual)
 #           -> rmsnorm -> gate|up GEMM with the SwiGLU epilogue -> down GEMM(+residual)
 def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, eps,
                       hq, hkv, d, scale, causal, train):
@@ -30,8 +33,11 @@ def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, w
     t = b * s
     x = ops._c(h_in).view(t, hd)
     xn, _, rstd1 = ops.raw_rmsnorm_fwd(x, w_ln1, eps)
-    qkv = ops.raw_gemm(xn, wqkv)
-    ops.raw_rope_(qkv, cos, sin, s, hq + hkv, d)
+    if _FUSE_ROPE and ops.gemm_rope_supported(xn, wqkv, cos, d):  # apply_rotary_pos_emb in the q|k|v GEMM epilogue
+        qkv = ops.raw_gemm_rope(xn, wqkv, cos, sin, s, hq + hkv, d)
+    else:
+        qkv = ops.raw_gemm(xn, wqkv)
+        ops.raw_rope_(qkv, cos, sin, s, hq + hkv, d)
     q, k, v = _split_qkv(qkv, b, s, hq, hkv, d)
     o, lse = ops.raw_attn_fwd(q, k, v, scale, causal, key_valid, need_lse=train, q_start=q_start)
     h_mid = ops.raw_gemm(o.view(t, hq * d), wo, residual=x, epilogue=EPI_RESIDUAL)
@@ -91,10 +97,12 @@ def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
     d_qkv = torch.empty_like(qkv)
     q, k, v = _split_qkv(qkv, b, s, hq, hkv, d)
     dq, dk, dv = _split_qkv(d_qkv, b, s, hq, hkv, d)
+    fused_rope = _FUSE_ROPE and ops.attn_bwd_rope_supported(q, k, cos, d)  # the transposed rotary on dq / dk inside the kernels
     ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, hq, d), scale, causal, key_valid, dq=dq, dk=dk, dv=dv,
-                     q_start=q_start)
+                     q_start=q_start, rope=(cos, sin) if fused_rope else None)
     del d_o
-    ops.raw_rope_(d_qkv, cos, sin, s, hq + hkv, d, conj=True)
+    if not fused_rope:
+        ops.raw_rope_(d_qkv, cos, sin, s, hq + hkv, d, conj=True)
     d_xn = ops.raw_gemm(d_qkv, wqkv, b_kn=True)
     dwqkv = ops.raw_gemm(d_qkv, xn, a_km=True, b_kn=True)                    # [(Hq+2Hkv)D, hd]
     d_hin, dw_ln1 = ops.raw_rmsnorm_bwd(d_xn, x, w_ln1, rstd1, dres=d_hmid)

@@ -489,6 +489,37 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
     return out
 
 
+def attn_bwd_rope_supported(q, k, cos, head_dim) -> bool:
+    """The attention backward can apply the transposed rotary embedding to dq / dk on their way out."""
+    return head_dim == 128 and q.shape[1] == k.shape[1] and cos.shape[-1] == 128 and cos.dim() in (2, 3)
+
+
+def gemm_rope_supported(x2, wqkv, cos, head_dim) -> bool:
+    """Shapes the q|k|v GEMM with the rotary epilogue takes (csrc/gemm.hip tamd_gemm_rope): heads of 128."""
+    n, k = wqkv.shape
+    return (head_dim == 128 and x2.dtype in (torch.bfloat16, torch.float16) and wqkv.dtype == x2.dtype and k % 64 == 0
+            and n % 128 == 0 and x2.stride(1) == 1 and wqkv.stride(1) == 1 and x2.stride(0) % 8 == 0
+            and wqkv.stride(0) % 8 == 0 and cos.shape[-1] == 128)
+
+
+@_device_guard
+def raw_gemm_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim):
+    """qkv [T, N] = x2 [T, K] . wqkv [N, K]^T with apply_rotary_pos_emb on the first rope_heads heads (query + key) in
+    the GEMM epilogue; bit-identical to raw_gemm followed by raw_rope_."""
+    be = _prep(x2, wqkv, cos, sin)
+    cos, sin = _c(cos), _c(sin)
+    if cos.dtype != x2.dtype:
+        cos, sin = cos.to(x2.dtype), sin.to(x2.dtype)
+    cos_batch = cos.shape[0] if cos.dim() == 3 else 1
+    t, k = x2.shape
+    n = wqkv.shape[0]
+    out = torch.empty(t, n, dtype=x2.dtype, device=x2.device)
+    be.lib.check(be.lib.tamd_gemm_rope(_p(x2), _p(wqkv), _p(out), _p(cos), _p(sin), t, n, k, x2.stride(0), wqkv.stride(0),
+                                       out.stride(0), seq, cos_batch, rope_heads * head_dim, _code(x2), be.stream(x2)),
+                 "tamd_gemm_rope")
+    return out
+
+
 def gemm_swiglu_supported(x2, wgu) -> bool:
     """Shapes the fused gate|up GEMM + SiLU*up epilogue takes (csrc/gemm.hip tamd_gemm_swiglu)."""
     two_i, k = wgu.shape
@@ -593,8 +624,10 @@ def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, out=None
 
 @_device_guard
 def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, dk=None, dv=None,
-                 dropout_p=0.0, seed=0, q_start=None):
-    """Gradients written into dq/dk/dv (views with the strides of q/k/v) or freshly allocated."""
+                 dropout_p=0.0, seed=0, q_start=None, rope=None):
+    """Gradients written into dq/dk/dv (views with the strides of q/k/v) or freshly allocated.  rope = (cos, sin)
+    ([seq, 128] or [batch, seq, 128], the storage dtype): q and k had been rotated before the attention, dq and dk leave
+    through the transposed rotation (the same bits as raw_rope_(conj=True) on the stored gradients)."""
     be = _prep(q, k, v, o, lse, dout, key_valid)
     if dout.stride() != o.stride():
         dout = dout.contiguous() if o.is_contiguous() else dout.clone(memory_format=torch.preserve_format)
@@ -612,6 +645,11 @@ def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, 
     bp.fwd = _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start)
     bp.dout, bp.dq, bp.dk, bp.dv, bp.delta = (dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                               delta.data_ptr())
+    if rope is not None:
+        cos, sin = (_c(t) if t.dtype == q.dtype else t.to(q.dtype).contiguous() for t in rope)
+        be.check_tensor(cos), be.check_tensor(sin)
+        bp.rope_cos, bp.rope_sin = cos.data_ptr(), sin.data_ptr()
+        bp.rope_cos_batch = cos.shape[0] if cos.dim() == 3 else 1
     be.lib.check(be.lib.tamd_attn_bwd(ctypes.byref(bp), be.stream(q)), "tamd_attn_bwd")
     return dq, dk, dv
 
