@@ -1,5 +1,5 @@
 """Per-kernel HBM traffic from rocprofv3 PMC passes of bench.py (FETCH_SIZE and WRITE_SIZE collected in separate
-runs, as gpurun requires).  Writes a per-kernel table and profiles/r01_gemm_traffic.json (read by bench.py).
+runs, as gpurun requires).  Writes a per-kernel table and profiles/r02_gemm_traffic.json (read by bench.py).
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 (MI355X_MICROARCH.md
 section HBM), so read bytes = 2 x FETCH_SIZE x 1024.
@@ -36,9 +36,10 @@ open(prefix + "_pmc_per_kernel.txt", "w").write("\n".join(lines[:40]) + "\n")
 if gemm["fetch"][1] and gemm["write"][1]:
     fb = 2 * gemm["fetch"][0] * 1024 / gemm["fetch"][1]
     wb = gemm["write"][0] * 1024 / gemm["write"][1]
-    json.dump({"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+    summary = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
                "gemm_launches_profiled": gemm["fetch"][1],
                "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1`; "
-                      "all tamd::gemm_* dispatches; read bytes = 2 x FETCH_SIZE KiB (gfx950 correction)"},
-              open("profiles/r01_gemm_traffic.json", "w"), indent=1)
+                      "all tamd::gemm_* dispatches; read bytes = 2 x FETCH_SIZE KiB (gfx950 correction)"}
+    for path in ("profiles/r02_gemm_traffic.json", prefix + "_gemm_traffic.json"):  # (gpurun merges gpurun_out/ back, not profiles/)
+        json.dump(summary, open(path, "w"), indent=1)
 print("\n".join(lines[:25]))
