@@ -16,6 +16,11 @@ from .ops import EPI_RESIDUAL, define_op
 
 T = torch.ops.tamd
 _FUSE_ROPE = os.environ.get("TAMD_FUSE_ROPE", "1") != "0"  # (A/B switch for measurements: rotary in the GEMM / attention epilogues)
+# SwiGLU backward in the d_act GEMM epilogue (tamd_gemm_swiglu_bwd): OFF by default.  The fused kernel is 0.2 ms per
+# layer faster than GEMM + swiglu_bwd on some runs (3.65 vs 3.87 ms) and 1.9 ms slower on others (5.7 ms; same binary,
+# same data -- the epilogue streams five large arrays in lockstep and its speed depends on where the run's buffers land
+# physically): 1292 vs 1359 ms per step measured back to back on one box.  profiles/r02_regression_note.md
+_FUSE_SWIGLU_BWD = os.environ.get("TAMD_FUSE_SWIGLU_BWD", "0") == "1"
 
 
 def _split_qkv(qkv, b, s, hq, hkv, d):
@@ -78,7 +83,7 @@ def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
     x = ops._c(h_in).view(t, hd)
     dh = ops._c(d_hout).view(t, hd)
     # ---- MLP
-    if ops.gemm_swiglu_bwd_supported(dh, wd, gu):  # d_act = dh . Wd with the SwiGLU backward in its epilogue
+    if _FUSE_SWIGLU_BWD and ops.gemm_swiglu_bwd_supported(dh, wd, gu):  # d_act = dh . Wd with the SwiGLU backward in its epilogue
         d_gu, act = ops.raw_gemm_swiglu_bwd(dh, wd, gu)
     else:
         d_act = ops.raw_gemm(dh, wd, b_kn=True)                              # [T, I]
