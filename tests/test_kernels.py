@@ -731,3 +731,21 @@ def test_attention_backward_rope_epilogue_is_bit_identical_to_unfused(env):
             assert ops.attn_bwd_rope_supported(q, k, cos, d)
             ops.raw_attn_bwd(q, k, v, o, lse, do, scale, True, dq=gq, dk=gk, dv=gv, rope=(cos, sin))
             assert torch.equal(got, ref), (b, s, hq, hkv, cb)
+
+
+def test_residual_epilogue_on_a_small_grid_goes_through_split_k(env):
+    """o_proj / down_proj of a short prompt (80 tiles of 256 x 256 on 256 CUs): ops.raw_gemm turns the residual epilogue
+    into copy + accumulate so that split-K applies: the roundings of the one-kernel residual epilogue (the fp32 partial
+    sums of the K ranges are added in a different order)."""
+    torch.manual_seed(47)
+    dev = env.device
+    for (m, n, k) in ([(1088, 4096, 11008), (577, 1024, 4096)] if env.big else [(200, 264, 2048)]):
+        x = torch.randn(m, k).bfloat16().to(dev)
+        w = (torch.randn(n, k) * 0.05).bfloat16().to(dev)
+        r = torch.randn(m, n).bfloat16().to(dev)
+        assert ops.gemm_workspace_bytes(m, n, k, ops.EPI_ACCUM) > 0
+        ref = ops.raw_gemm(x, w, residual=r, epilogue=ops.EPI_RESIDUAL, sched="fl")  # a schedule hint turns split-K off
+        got = ops.raw_gemm(x, w, residual=r, epilogue=ops.EPI_RESIDUAL)
+        # split-K sums the fp32 partials of the K ranges: not the bits of the unsplit order, but the same roundings
+        assert rel_err(got, ref) < 2e-3 and (got != ref).float().mean() < 0.2
+        assert rel_err(got, (x.float() @ w.float().t()).bfloat16().float() + r.float()) < 4e-3

@@ -474,6 +474,13 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
     if out is None:
         out = torch.empty(m, n, dtype=a.dtype, device=a.device)
     flags = (GEMM_A_KM if a_km else 0) | (GEMM_B_KN if b_kn else 0) | GEMM_SCHED[sched]
+    # a residual epilogue on a tile grid that cannot fill the GPU (o_proj / down_proj of a short prompt: 80 tiles on 256
+    # CUs): the residual goes into C first and the product is accumulated onto it, which split-K can do -- the same
+    # roundings, round(round(acc) + R), for the price of copying a small C
+    if (epilogue == EPI_RESIDUAL and bias is None and sched is None and residual is not None
+            and residual.shape == out.shape and gemm_workspace_bytes(m, n, k_a, EPI_ACCUM)):
+        out.copy_(residual)
+        residual, epilogue = None, EPI_ACCUM
     ldr = residual.stride(0) if residual is not None else 0
     # split-K for tile grids that cannot fill the GPU (weight gradients of narrow layers): needs an fp32 workspace
     ws_bytes = gemm_workspace_bytes(m, n, k_a, epilogue) if sched is None else 0
@@ -499,7 +506,9 @@ def gemm_rope_supported(x2, wqkv, cos, head_dim) -> bool:
     n, k = wqkv.shape
     return (head_dim == 128 and x2.dtype in (torch.bfloat16, torch.float16) and wqkv.dtype == x2.dtype and k % 64 == 0
             and n % 128 == 0 and x2.stride(1) == 1 and wqkv.stride(1) == 1 and x2.stride(0) % 8 == 0
-            and wqkv.stride(0) % 8 == 0 and cos.shape[-1] == 128)
+            and wqkv.stride(0) % 8 == 0 and cos.shape[-1] == 128
+            # a tile grid that cannot fill the GPU (a short prompt) is better off with split-K and the rotary kernel
+            and gemm_workspace_bytes(x2.shape[0], n, k, EPI_NONE) == 0)
 
 
 @_device_guard
@@ -525,7 +534,8 @@ def gemm_swiglu_supported(x2, wgu) -> bool:
     two_i, k = wgu.shape
     return (x2.dtype in (torch.bfloat16, torch.float16) and wgu.dtype == x2.dtype and k % 64 == 0 and two_i % 16 == 0
             and x2.stride(1) == 1 and wgu.stride(1) == 1 and x2.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0
-            and two_i * wgu.stride(0) * 2 < 2 ** 31)
+            and two_i * wgu.stride(0) * 2 < 2 ** 31
+            and gemm_workspace_bytes(x2.shape[0], two_i, k, EPI_NONE) == 0)  # (small grids: split-K + swiglu kernel)
 
 
 @_device_guard
