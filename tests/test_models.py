@@ -636,7 +636,7 @@ def test_fused_lm_head_loss(env):
     assert abs(loss.item() - ref.item()) <= 2e-3 * abs(ref.item())
     loss.backward()
     ref.backward()
-    assert rel_err(h.grad, hr.grad) < 1e-2 and rel_err(w.grad, wr.grad) < 0.0065
+    assert rel_err(h.grad, hr.grad) < 0.0065 and rel_err(w.grad, wr.grad) < 0.0065
     # eval / no labels: the reference forward, logits present; revert removes the instance-level forward
     fused.eval()
     with torch.no_grad():

@@ -66,15 +66,6 @@ __device__ __forceinline__ void after_wait(u32x4& x0, u32x4& x1) {
 // PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
 // a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
 // the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
-// PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
-// a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
-// the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
-// PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
-// a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
-// the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
-// PACKED (include/tamd.h q_start plane 1): key k is seen by queries up to k_end[k], the last token of its sequence --
-// a per-lane scalar here (a lane owns a key), so the packed mask is one more compare per element and q-tiles past
-// the block's last sequence are never visited.  A separate instantiation keeps it out of the common path.
 __device__ __forceinline__ void after_wait1(u32x4& x0) {
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(x0)::"memory");
