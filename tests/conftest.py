@@ -120,5 +120,14 @@ def pytest_sessionfinish(session, exitstatus):
     backend = "hip" if torch.cuda.is_available() else "emu"
     out = ROOT / "gpurun_out" if backend == "hip" else ROOT / ".pytest_cache"
     out.mkdir(exist_ok=True)
-    with open(out / f"parity_{backend}.json", "w") as f:
-        json.dump(_PARITY, f, indent=1, sort_keys=True)
+    path = out / f"parity_{backend}.json"
+    merged = {}
+    if path.exists():  # a partial session (-k ...) must not drop what a full one measured
+        try:
+            merged = json.loads(path.read_text())
+        except ValueError:
+            merged = {}
+    for grp, entries in _PARITY.items():
+        merged.setdefault(grp, {}).update(entries)  # the latest measurement (and gate) of an entry wins
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)

@@ -17,7 +17,7 @@ for be, d in data.items():
     for key, g in d.get("gates", {}).items():
         e = gates.setdefault(key, {"limit": g["limit"]})
         e[be] = g["err"]
-        e["limit"] = max(e["limit"], g["limit"])
+        e["limit"] = min(e["limit"], g["limit"])  # (gates only ever got tighter: the smaller one is the current one)
 
 
 def round_up(x):
