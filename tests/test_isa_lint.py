@@ -83,16 +83,18 @@ def lint_kernel(name, lines):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("src,flags", [("attention_bwd_dkdv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]),
-                                       ("attention.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]),
-                                       ("gemm.hip", [])])
-def test_untracked_lds_reads_are_not_touched_before_their_wait(src, flags, tmp_path):
+@pytest.mark.parametrize("src,flags,defines", [
+    ("attention_bwd_dkdv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"], []),
+    ("attention.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], []),
+    ("attention.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], ["-DTAMD_DIAG"]),  # + the experimental attn_fwd64_kernel
+    ("gemm.hip", [], [])])
+def test_untracked_lds_reads_are_not_touched_before_their_wait(src, flags, defines, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     from transformers_amd import build as tb
 
     assert flags == tb.PER_SOURCE_FLAGS.get(src, []), "keep this test's flags in step with build.py"
     out = tmp_path / "k.s"
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", *flags, "-I", str(CSRC), "-I",
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", *flags, *defines, "-I", str(CSRC), "-I",
            str(ROOT / "include"), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", str(CSRC / src),
            "-o", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True)

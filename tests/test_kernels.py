@@ -749,3 +749,32 @@ def test_residual_epilogue_on_a_small_grid_goes_through_split_k(env):
         # split-K sums the fp32 partials of the K ranges: not the bits of the unsplit order, but the same roundings
         assert rel_err(got, ref) < 0.00011 and (got != ref).float().mean() < 0.2
         assert rel_err(got, (x.float() @ w.float().t()).bfloat16().float() + r.float()) < 0.0036
+
+
+def test_attention_fwd64_matches_fwd(env):
+    """The experimental forward kernel with 64 query rows per wave (csrc/attention_fwd64.inc, diagnostic library only) is
+    bit-identical to the product kernel: causal and bidirectional, GQA, query counts that are not multiples of 256,
+    more keys than queries (KV offset), outputs and LSE."""
+    import math
+
+    lib = ops.backend().lib
+    if not hasattr(lib, "tamd_attn_set_fwd64"):
+        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
+    torch.manual_seed(53)
+    dev = env.device
+    cases = ([(2, 1024, 1024, 8, 2), (1, 700, 704, 4, 4), (1, 4096, 4096, 2, 1)] if env.big else
+             [(1, 320, 320, 2, 1), (1, 100, 192, 2, 2), (2, 256, 256, 1, 1)])
+    for (b, sq, sk, hq, hkv) in cases:
+        d = 128
+        q = torch.randn(b, sq, hq, d).bfloat16().to(dev)
+        k = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
+        v = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
+        for causal in (True, False):
+            o_ref, lse_ref = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal)
+            before = lib.tamd_attn_set_fwd64(1)
+            try:
+                o, lse = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal)
+            finally:
+                after = lib.tamd_attn_set_fwd64(0)
+            assert after == before + 1, "the experimental kernel was not taken"
+            assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, causal)

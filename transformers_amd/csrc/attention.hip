@@ -307,6 +307,9 @@ __global__ __launch_bounds__(kAttnThreads, (DROP && D > 64) ? 1 : 2) void attn_f
 
 }  // namespace tamd
 
+#ifdef TAMD_DIAG
+#include "attention_fwd64.inc"  // experimental 64-rows-per-wave forward: diagnostic library only
+#endif
 #include "attention_bwd.inc"
 
 using namespace tamd;
@@ -315,6 +318,8 @@ namespace {
 
 #ifdef TAMD_DIAG
 unsigned long long* g_attn_trace = nullptr;
+int g_attn_fwd64 = 0;  // tamd_attn_set_fwd64: route eligible forwards to attn_fwd64_kernel
+int g_attn_fwd64_launches = 0;
 #endif
 
 template <typename T, int D>
@@ -323,6 +328,20 @@ int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
   dim3 grid((unsigned)(a.nqt * a.heads_q * a.batch)), block(kAttnThreads);
   const bool mask = a.key_valid != nullptr;
   const bool drop = a.drop_thr != 0;
+#ifdef TAMD_DIAG
+  if (g_attn_fwd64 && D == 128 && !mask && !drop && a.q_start == nullptr && a.seq_k % kKB == 0 && a.kss == a.vss &&
+      TileFeed<128>::usable(a.kss)) {
+    const int nqt64 = (a.seq_q + kQB64 - 1) / kQB64;
+    dim3 grid64((unsigned)(nqt64 * a.heads_q * a.batch));
+    ++g_attn_fwd64_launches;
+    const size_t smem64 = (size_t)3 * 2 * kKB * 128 * 2;  // 3 x (K + V) = 96 KiB (covers the O staging: 8 x 32 x 272 B)
+    if (causal)
+      hipLaunchKernelGGL((attn_fwd64_kernel<T, true>), grid64, block, smem64, s, a);
+    else
+      hipLaunchKernelGGL((attn_fwd64_kernel<T, false>), grid64, block, smem64, s, a);
+    return launch_status();
+  }
+#endif
 #define TAMD_AF(C_, M_, D_) hipLaunchKernelGGL((attn_fwd_kernel<T, D, C_, M_, D_>), grid, block, smem, s, a)
   if (drop) {  // the dropout variants always carry the padding-mask code (rare path: keep the instantiation count down)
     if (causal)
@@ -410,6 +429,11 @@ AttnArgs make_args(const tamd_attn_params* p) {
 extern "C" int tamd_attn_set_trace(void* buf) {
   g_attn_trace = reinterpret_cast<unsigned long long*>(buf);
   return TAMD_OK;
+}
+// 1: tamd_attn_fwd takes the experimental 64-rows-per-wave kernel (attention_fwd64.inc) wherever it applies
+extern "C" int tamd_attn_set_fwd64(int on) {
+  g_attn_fwd64 = on;
+  return g_attn_fwd64_launches;  // (how many forwards have taken the experimental kernel so far)
 }
 #endif
 

@@ -95,7 +95,7 @@ struct TileFeed {
       voff[i] = (unsigned)(((int64_t)r * stride + s * 8) * 2);
     }
   }
-  static __device__ __forceinline__ bool usable(int64_t stride) { return stride > 0 && stride * (kKB * 2) < ((int64_t)1 << 31); }
+  static __host__ __device__ __forceinline__ bool usable(int64_t stride) { return stride > 0 && stride * (kKB * 2) < ((int64_t)1 << 31); }
   template <typename T>
   __device__ __forceinline__ void issue_one(const T* __restrict__ first_row, char* smem, unsigned tile_off, int wave,
                                             int i) const {  // piece i < NI of this wave
