@@ -25,6 +25,12 @@ int tamd_gemm_set_clock_buffer(void* buf);
  * supported values 0, 1, 2, 4, 8, 12, 15.  tools/gemm_fl_dbg.py */
 int tamd_gemm_set_dbg(int dbg);
 
+/* Staggered K start for plain-epilogue GEMMs of every layout (CORRECT results; the fp32 summation order of a tile
+ * rotates): a workgroup starts its K loop (key % units) * stride_stages stages in (stride 0 = K / units apart) and wraps
+ * around.  mode: key = 1 XCD of the workgroup, 2 tile row, 3 tile column, 4 tile row + column; mode 0 or units < 2 =
+ * off.  tools/gemm_stagger_ab.py */
+int tamd_gemm_set_stagger(int mode, int units, int stride_stages);
+
 /* Phase trace of the attention forward kernel: while `buf` (uint64[32], device memory) is set, workgroup 0 of every
  * tamd_attn_fwd launch stores per-wave shader-clock sums of its tile-loop phases at buf[wave * 8 + phase]
  * (0 tile-load issue, 1 K.Q^T, 2 mask + softmax, 3 P.V, 4 vmcnt wait, 5 barrier).  NULL switches it off. */

@@ -778,3 +778,43 @@ def test_attention_fwd64_matches_fwd(env):
                 after = lib.tamd_attn_set_fwd64(0)
             assert after == before + 1, "the experimental kernel was not taken"
             assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, causal)
+
+
+def test_gemm_staggered_k_start(env):
+    """Diagnostic variant of the GEMM (tamd_gemm_set_stagger, include/tamd_diag.h): a workgroup starts its K loop a few
+    stages in and wraps around.  Same products, rotated fp32 summation order: results agree with the product kernel to
+    rounding in every layout, and a cancellation pattern that is sensitive to the order shows which tiles rotated."""
+    lib = ops.backend().lib
+    if not hasattr(lib, "tamd_gemm_set_stagger"):
+        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
+    torch.manual_seed(61)
+    dev = env.device
+    m, n, k = (1024, 768, 1280) if env.big else (512, 512, 640)
+    x = torch.randn(m, k).bfloat16().to(dev)
+    w = (torch.randn(n, k) * k ** -0.5).bfloat16().to(dev)
+    layouts = [((x, w), {}), ((x, w.t().contiguous()), {"b_kn": True}),
+               ((x.t().contiguous(), w.t().contiguous()), {"a_km": True, "b_kn": True})]
+    ref = x.float() @ w.float().t()
+    try:
+        for args, kw in layouts:
+            plain = ops.raw_gemm(*args, **kw)
+            for mode, units, stride in ((1, 8, 0), (2, 3, 1), (3, 2, 3), (4, 5, 0), (2, 255, 7)):
+                assert lib.tamd_gemm_set_stagger(mode, units, stride) == 0
+                got = ops.raw_gemm(*args, **kw)
+                assert rel_err(got, plain) < 2e-3 and rel_err(got, ref) < 0.0036, (kw, mode, units, stride)
+        # order-sensitive operands: +2^30 in the first stage, -2^30 in the last, ones in between: the product kernel adds
+        # the ones to 2^30 (lost, 64 at a time) and ends at 0; a tile that starts one stage in keeps them
+        xs = torch.ones(m, k)
+        xs[:, 0], xs[:, -1] = 2.0 ** 15, -(2.0 ** 15)
+        ws = torch.ones(n, k)
+        ws[:, 0] = ws[:, -1] = 2.0 ** 15
+        xs, ws = xs.bfloat16().to(dev), ws.bfloat16().to(dev)
+        lib.tamd_gemm_set_stagger(0, 0, 0)
+        plain = ops.raw_gemm(xs, ws).float()
+        lib.tamd_gemm_set_stagger(2, 2, 1)                               # odd tile rows start at stage 1
+        got = ops.raw_gemm(xs, ws).float()
+        assert torch.equal(got[:256], plain[:256]) and torch.equal(got[512:768], plain[512:768])
+        assert (got[256:512] != plain[256:512]).all()
+        assert lib.tamd_gemm_set_stagger(7, 2, 1) != 0                   # unknown mode is refused
+    finally:
+        lib.tamd_gemm_set_stagger(0, 0, 0)

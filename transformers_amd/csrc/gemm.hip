@@ -86,6 +86,9 @@ struct GemmArgs {
   // rotary epilogue (kEpiRope): R = cos, C2 = sin ([cos_batch, seq, 128] in the storage dtype), n_half = the leading
   // columns to rotate (query + key heads, a multiple of 128), seq / cos_batch below
   int64_t seq, cos_batch;
+#ifdef TAMD_DIAG
+  int stagger;  // staggered K start of the DBG=16 instantiations: mode | units << 4 | stride_stages << 12
+#endif
 };
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
@@ -555,7 +558,10 @@ __device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
 }
 
 // DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_GEMM_DBG=n, wrong results): 1 no LDS-DMA after the prologue, 2 no LDS
-// fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier
+// fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier.  16 (CORRECT results, tamd_gemm_set_stagger): the K loop
+// of a workgroup starts `soff` stages in and wraps around -- workgroups that run side by side then ask the memory
+// system for different k ranges at the same moment instead of sweeping the same address bits in lockstep (what
+// hipBLASLt's gfx950 kernels call StaggerU); the fp32 summation order of a tile rotates with it.
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
@@ -595,6 +601,24 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096 + (int64_t)st0 * kinc_a;
   const int64_t nb0 = (EPI == kEpiSwiGLU) ? 0 : n0;  // SwiGLU: per-lane offsets address the whole fused weight
   const char* base_b = (const char*)(B_KN ? B + n0 : B + nb0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
+  // staggered K start (DBG & 16): stage issues left until the operand base wraps back to k = 0, and the wrap distance
+  int wrap_a = 0x7fffffff, wrap_b = 0x7fffffff;
+  int64_t wrap_bytes_a = 0, wrap_bytes_b = 0;
+#ifdef TAMD_DIAG
+  if (DBG & 16) {
+    const int mode = g.stagger & 15, units = (g.stagger >> 4) & 255, stride = g.stagger >> 12;
+    const int key = mode == 1 ? (int)(blockIdx.x & 7u) : mode == 2 ? tile_m : mode == 3 ? tile_n : tile_m + tile_n;
+    const int step = stride ? stride : (nst / (units > 0 ? units : 1) > 0 ? nst / (units > 0 ? units : 1) : 1);
+    const int soff = units > 0 ? (int)(((int64_t)(key % units) * step) % nst) : 0;
+    if (soff) {
+      base_a += soff * kinc_a;
+      base_b += soff * kinc_b;
+      wrap_a = wrap_b = nst - soff;
+      wrap_bytes_a = nst * kinc_a;
+      wrap_bytes_b = nst * kinc_b;
+    }
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (wave * 8 + i) * 8 + (lane >> 3);
@@ -621,6 +645,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     base_b -= kinc_b;
     kinc_a = 0;
     kinc_b = 0;
+    wrap_a = wrap_b = 0x7fffffff;
   };
   const unsigned piece0 = (unsigned)wave * 8192u;  // this wave's first piece inside an operand stage
   bool dma_on = true;
@@ -634,8 +659,14 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
       case 2: glds16_buf<2048>(base, voff[p], smem, dst); break;
       default: glds16_buf<3072>(base, voff[p], smem, dst); break;
     }
-    if (p == 7) base_a += kinc_a;  // every piece of the operand stage is out: step to the next stage
-    if (p == 15) base_b += kinc_b;
+    if (p == 7) {  // every piece of the operand stage is out: step to the next stage
+      base_a += kinc_a;
+      if ((DBG & 16) && --wrap_a == 0) base_a -= wrap_bytes_a;
+    }
+    if (p == 15) {
+      base_b += kinc_b;
+      if ((DBG & 16) && --wrap_b == 0) base_b -= wrap_bytes_b;
+    }
   };
   // fragment offsets inside a half-slot (block t = 16 rows / columns of this wave's 128, k-step q = 32 of the stage's 64)
   //   row-major: one register per k-step, the block is the immediate t*2048;
@@ -811,6 +842,9 @@ static int gemm_diag_dbg() {
   return g_gemm_dbg;
 }
 #endif
+#ifdef TAMD_DIAG
+static int g_gemm_stagger = 0;  // tamd_gemm_set_stagger: packed like GemmArgs::stagger, 0 = off
+#endif
 #define TAMD_EPI_SWITCH(LAUNCH)                                           \
   switch (epilogue) {                                                     \
     case TAMD_EPI_NONE: LAUNCH(TAMD_EPI_NONE, TAMD_ACT_NONE)              \
@@ -851,6 +885,12 @@ template <typename T, bool A_KM, bool B_KN>
 static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
 #ifdef TAMD_DIAG  // ablation instantiations (wrong results by design): libtamd_diag.so only, never the product library
+  if (g_gemm_stagger && epilogue == TAMD_EPI_NONE) {  // staggered K start: every layout, plain epilogue, correct results
+    GemmArgs gs = g;
+    gs.stagger = g_gemm_stagger;
+    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 16>), grid, block, (size_t)kXSmem, s, gs);
+    return launch_status();
+  }
   const int dbg = gemm_diag_dbg();
   if (dbg && epilogue == TAMD_EPI_NONE && !A_KM && !B_KN) {
 #define TAMD_GD(N_)                                                                                             \
@@ -920,6 +960,11 @@ extern "C" int tamd_gemm_set_dbg(int dbg) {
   g_gemm_dbg = dbg;
   return TAMD_OK;
 }
+extern "C" int tamd_gemm_set_stagger(int mode, int units, int stride_stages) {
+  if (mode < 0 || mode > 4 || units < 0 || units > 255 || stride_stages < 0 || stride_stages > 4095) return TAMD_E_ARG;
+  g_gemm_stagger = (mode && units > 1) ? (mode | units << 4 | stride_stages << 12) : 0;
+  return TAMD_OK;
+}
 static unsigned long long* g_gemm_clock = nullptr;
 extern "C" int tamd_gemm_set_clock_buffer(void* buf) {
   g_gemm_clock = reinterpret_cast<unsigned long long*>(buf);
@@ -956,6 +1001,9 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->n_half = 0;
   g->seq = 1;
   g->cos_batch = 1;
+#ifdef TAMD_DIAG
+  g->stagger = 0;
+#endif
   return TAMD_OK;
 }
 
