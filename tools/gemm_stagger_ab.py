@@ -24,7 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--iters", type=int, default=6)
 ap.add_argument("--shapes", default="o_proj,gate_up,down,qkv")
-ap.add_argument("--configs", default="1/8/0,1/8/1,1/8/4,2/8/1,2/8/2,2/32/1,2/16/0,3/4/2,3/16/1,4/8/1,4/32/2")
+ap.add_argument("--configs", default="2/32/2,3/32/2,1/8/0,1/8/1,1/8/4,2/8/1,2/8/2,2/32/1,2/16/0,3/4/2,3/16/1,4/8/1,4/32/2")
 args = ap.parse_args()
 lib = _diag.use_diag()
 dev = torch.device("cuda:0")
