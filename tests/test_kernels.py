@@ -816,5 +816,17 @@ def test_gemm_staggered_k_start(env):
         assert torch.equal(got[:256], plain[:256]) and torch.equal(got[512:768], plain[512:768])
         assert (got[256:512] != plain[256:512]).all()
         assert lib.tamd_gemm_set_stagger(7, 2, 1) != 0                   # unknown mode is refused
+        # early LDS-DMA pieces (tamd_gemm_set_dbg(32), row-major operands): same summation order, identical bits --
+        # alone and on top of a stagger
+        lib.tamd_gemm_set_stagger(0, 0, 0)
+        plain = ops.raw_gemm(x, w)
+        lib.tamd_gemm_set_dbg(32)
+        assert torch.equal(ops.raw_gemm(x, w), plain)
+        lib.tamd_gemm_set_dbg(0)
+        lib.tamd_gemm_set_stagger(4, 5, 2)
+        staggered = ops.raw_gemm(x, w)
+        lib.tamd_gemm_set_dbg(32)
+        assert torch.equal(ops.raw_gemm(x, w), staggered)
     finally:
         lib.tamd_gemm_set_stagger(0, 0, 0)
+        lib.tamd_gemm_set_dbg(0)

@@ -7,7 +7,9 @@ different offset and wraps (its StaggerU code is visible at the top of its main 
 
     python tools/gemm_stagger_ab.py [--rounds 3] [--iters 6] [--shapes o_proj,gate_up,down,qkv]
 
-One JSON line per (shape, layout): TFLOP/s per round for every configuration "mode/units/stride" ("off" = product)."""
+One JSON line per (shape, layout): TFLOP/s per round for every configuration "mode/units/stride" ("off" = product);
+a trailing "e" = with the LDS-DMA pieces issued early in every k-step (tamd_gemm_set_dbg(32), row-major layout only:
+the other difference to hipBLASLt's loop, see profiles/r02_gemm_variants.md section 5).  Every arm gives correct results."""
 import argparse
 import json
 import sys
@@ -31,6 +33,18 @@ dev = torch.device("cuda:0")
 T = 32768
 SHAPES = {"qkv": (T, 6144, 4096), "o_proj": (T, 4096, 4096), "gate_up": (T, 28672, 4096), "down": (T, 4096, 14336)}
 configs = [None] + [tuple(int(v) for v in c.split("/")) for c in args.configs.split(",")]
+EARLY = ["e", "2/32/2e", "3/32/2e", "1/8/1e"]                              # forward layout only
+
+
+def key_of(c):
+    return "off" if c is None else c if isinstance(c, str) else "/".join(map(str, c))
+
+
+def select(c):
+    early = isinstance(c, str)
+    st = tuple(int(v) for v in c[:-1].split("/")) if early and len(c) > 1 else (c if not early and c else (0, 0, 0))
+    lib.tamd_gemm_set_stagger(*st)
+    lib.tamd_gemm_set_dbg(32 if early else 0)
 
 
 def time_ms(fn):
@@ -54,12 +68,13 @@ for name in args.shapes.split(","):
     legs = {"fwd": lambda: ops.raw_gemm(x, w), "dX": lambda: ops.raw_gemm(dy, w, b_kn=True),
             "dW": lambda: ops.raw_gemm(dy, x, a_km=True, b_kn=True)}
     for leg, fn in legs.items():
-        res = {("off" if c is None else "/".join(map(str, c))): [] for c in configs}
+        arms = configs + (EARLY if leg == "fwd" else [])
+        res = {key_of(c): [] for c in arms}
         for _ in range(args.rounds):
-            for c in configs:
-                lib.tamd_gemm_set_stagger(*(c or (0, 0, 0)))
-                res["off" if c is None else "/".join(map(str, c))].append(round(2.0 * m * n * k / time_ms(fn) / 1e9))
-        lib.tamd_gemm_set_stagger(0, 0, 0)
+            for c in arms:
+                select(c)
+                res[key_of(c)].append(round(2.0 * m * n * k / time_ms(fn) / 1e9))
+        select(None)
         best = max(res, key=lambda c: sorted(res[c])[len(res[c]) // 2])
         print(json.dumps({"shape": name, "layout": leg, "tflops": res, "best_median": best}), flush=True)
     del x, w, dy

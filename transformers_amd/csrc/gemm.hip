@@ -561,7 +561,11 @@ __device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
 // fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier.  16 (CORRECT results, tamd_gemm_set_stagger): the K loop
 // of a workgroup starts `soff` stages in and wraps around -- workgroups that run side by side then ask the memory
 // system for different k ranges at the same moment instead of sweeping the same address bits in lockstep (what
-// hipBLASLt's gfx950 kernels call StaggerU); the fp32 summation order of a tile rotates with it.
+// hipBLASLt's gfx950 kernels call StaggerU); the fp32 summation order of a tile rotates with it.  32 (correct,
+// bit-identical results; row-major operands): the LDS-DMA pieces of a k-step go out behind its MFMA pairs 2, 5, .. 23
+// instead of 17, 19, .. 31 -- 23 MFMAs (~400 cycles) more on average for a piece to land before the hand-off waits for
+// it (hipBLASLt's kernel gives its operands 84-182 MFMAs, ours 64-94 for B) -- with the fragment reads of the next
+// k-step on the pairs between them.
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
@@ -730,8 +734,13 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
       acc[nb][mb] = mfma16<T>(fw[buf][nb], fx[buf][mb], acc[nb][mb]);
       acc[nb][mb + 1] = mfma16<T>(fw[buf][nb], fx[buf][mb + 1], acc[nb][mb + 1]);
       sched_fence();
-      if (p < 16) rd1(ra, rb, rq, buf ^ 1, p);
-      if (p >= 16 && (p & 1)) issue(pb + ((p - 17) >> 1), ps);
+      if ((DBG & 32) && !A_KM && !B_KN) {  // early pieces: of the pairs 0..23 every third carries an LDS-DMA piece, the
+        if (p < 24 && p % 3 != 2) rd1(ra, rb, rq, buf ^ 1, p - p / 3);  // other two a fragment read (the last one 9 pairs
+        if (p < 24 && p % 3 == 2) issue(pb + p / 3, ps);                 // ahead of the hand-off's lgkmcnt(0))
+      } else {
+        if (p < 16) rd1(ra, rb, rq, buf ^ 1, p);
+        if (p >= 16 && (p & 1)) issue(pb + ((p - 17) >> 1), ps);
+      }
       sched_fence();
     }
   };
@@ -885,13 +894,16 @@ template <typename T, bool A_KM, bool B_KN>
 static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
 #ifdef TAMD_DIAG  // ablation instantiations (wrong results by design): libtamd_diag.so only, never the product library
+  const int dbg = gemm_diag_dbg();
   if (g_gemm_stagger && epilogue == TAMD_EPI_NONE) {  // staggered K start: every layout, plain epilogue, correct results
     GemmArgs gs = g;
     gs.stagger = g_gemm_stagger;
-    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 16>), grid, block, (size_t)kXSmem, s, gs);
+    if (dbg == 32 && !A_KM && !B_KN)
+      hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, 48>), grid, block, (size_t)kXSmem, s, gs);
+    else
+      hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 16>), grid, block, (size_t)kXSmem, s, gs);
     return launch_status();
   }
-  const int dbg = gemm_diag_dbg();
   if (dbg && epilogue == TAMD_EPI_NONE && !A_KM && !B_KN) {
 #define TAMD_GD(N_)                                                                                             \
   hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, N_>), grid, block, (size_t)kXSmem, \
@@ -904,6 +916,7 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       case 8: TAMD_GD(8)
       case 12: TAMD_GD(12)
       case 15: TAMD_GD(15)
+      case 32: TAMD_GD(32)
       default: break;
     }
 #undef TAMD_GD
