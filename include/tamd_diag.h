@@ -23,7 +23,8 @@ int tamd_gemm_set_clock_buffer(void* buf);
 /* Ablation selector for the full-line GEMM kernel (row-major operands, plain epilogue; WRONG RESULTS by design):
  * bit mask 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier;
  * supported values 0, 1, 2, 4, 8, 12, 15 (tools/gemm_fl_dbg.py), and 32 = LDS-DMA pieces issued in the first half of
- * every k-step instead of the second (CORRECT, bit-identical results; combines with tamd_gemm_set_stagger). */
+ * every k-step instead of the second, 64 = a second barrier per k-step between its fragment-read half and its LDS-DMA
+ * half (both CORRECT, bit-identical results; each combines with tamd_gemm_set_stagger). */
 int tamd_gemm_set_dbg(int dbg);
 
 /* Staggered K start for plain-epilogue GEMMs of every layout (CORRECT results; the fp32 summation order of a tile

@@ -820,13 +820,15 @@ def test_gemm_staggered_k_start(env):
         # alone and on top of a stagger
         lib.tamd_gemm_set_stagger(0, 0, 0)
         plain = ops.raw_gemm(x, w)
-        lib.tamd_gemm_set_dbg(32)
-        assert torch.equal(ops.raw_gemm(x, w), plain)
+        for dbg in (32, 64):                                             # 64: a second barrier per k-step
+            lib.tamd_gemm_set_dbg(dbg)
+            assert torch.equal(ops.raw_gemm(x, w), plain), dbg
         lib.tamd_gemm_set_dbg(0)
         lib.tamd_gemm_set_stagger(4, 5, 2)
         staggered = ops.raw_gemm(x, w)
-        lib.tamd_gemm_set_dbg(32)
-        assert torch.equal(ops.raw_gemm(x, w), staggered)
+        for dbg in (32, 64):
+            lib.tamd_gemm_set_dbg(dbg)
+            assert torch.equal(ops.raw_gemm(x, w), staggered), dbg
     finally:
         lib.tamd_gemm_set_stagger(0, 0, 0)
         lib.tamd_gemm_set_dbg(0)

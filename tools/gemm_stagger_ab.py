@@ -8,8 +8,9 @@ different offset and wraps (its StaggerU code is visible at the top of its main 
     python tools/gemm_stagger_ab.py [--rounds 3] [--iters 6] [--shapes o_proj,gate_up,down,qkv]
 
 One JSON line per (shape, layout): TFLOP/s per round for every configuration "mode/units/stride" ("off" = product);
-a trailing "e" = with the LDS-DMA pieces issued early in every k-step (tamd_gemm_set_dbg(32), row-major layout only:
-the other difference to hipBLASLt's loop, see profiles/r02_gemm_variants.md section 5).  Every arm gives correct results."""
+a trailing "e" = with the LDS-DMA pieces issued early in every k-step (tamd_gemm_set_dbg(32)), a trailing "b" = with a
+second barrier per k-step (tamd_gemm_set_dbg(64)); row-major layout only: the other differences to hipBLASLt's loop, see
+profiles/r02_gemm_variants.md section 5.  Every arm gives correct results."""
 import argparse
 import json
 import sys
@@ -33,7 +34,7 @@ dev = torch.device("cuda:0")
 T = 32768
 SHAPES = {"qkv": (T, 6144, 4096), "o_proj": (T, 4096, 4096), "gate_up": (T, 28672, 4096), "down": (T, 4096, 14336)}
 configs = [None] + [tuple(int(v) for v in c.split("/")) for c in args.configs.split(",")]
-EARLY = ["e", "2/32/2e", "3/32/2e", "1/8/1e"]                              # forward layout only
+EARLY = ["e", "2/32/2e", "3/32/2e", "1/8/1e", "b", "2/32/2b"]              # forward layout only ("b": second barrier)
 
 
 def key_of(c):
@@ -44,7 +45,7 @@ def select(c):
     early = isinstance(c, str)
     st = tuple(int(v) for v in c[:-1].split("/")) if early and len(c) > 1 else (c if not early and c else (0, 0, 0))
     lib.tamd_gemm_set_stagger(*st)
-    lib.tamd_gemm_set_dbg(32 if early else 0)
+    lib.tamd_gemm_set_dbg((64 if c.endswith("b") else 32) if early else 0)
 
 
 def time_ms(fn):

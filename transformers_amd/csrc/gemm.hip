@@ -565,7 +565,8 @@ __device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
 // bit-identical results; row-major operands): the LDS-DMA pieces of a k-step go out behind its MFMA pairs 2, 5, .. 23
 // instead of 17, 19, .. 31 -- 23 MFMAs (~400 cycles) more on average for a piece to land before the hand-off waits for
 // it (hipBLASLt's kernel gives its operands 84-182 MFMAs, ours 64-94 for B) -- with the fragment reads of the next
-// k-step on the pairs between them.
+// k-step on the pairs between them.  64 (correct, bit-identical; row-major operands): a second barrier per k-step between
+// its fragment-read half and its LDS-DMA half (hipBLASLt's loop has three barriers per stage, ours one).
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
@@ -733,6 +734,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
       const int nb = p >> 2, mb = (p & 3) * 2;
       acc[nb][mb] = mfma16<T>(fw[buf][nb], fx[buf][mb], acc[nb][mb]);
       acc[nb][mb + 1] = mfma16<T>(fw[buf][nb], fx[buf][mb + 1], acc[nb][mb + 1]);
+      if ((DBG & 64) && p == 16) raw_barrier();  // (diagnostic) the four waves enter the LDS-DMA half of the k-step together
       sched_fence();
       if ((DBG & 32) && !A_KM && !B_KN) {  // early pieces: of the pairs 0..23 every third carries an LDS-DMA piece, the
         if (p < 24 && p % 3 != 2) rd1(ra, rb, rq, buf ^ 1, p - p / 3);  // other two a fragment read (the last one 9 pairs
@@ -900,6 +902,8 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
     gs.stagger = g_gemm_stagger;
     if (dbg == 32 && !A_KM && !B_KN)
       hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, 48>), grid, block, (size_t)kXSmem, s, gs);
+    else if (dbg == 64 && !A_KM && !B_KN)
+      hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, 80>), grid, block, (size_t)kXSmem, s, gs);
     else
       hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 16>), grid, block, (size_t)kXSmem, s, gs);
     return launch_status();
@@ -917,6 +921,7 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       case 12: TAMD_GD(12)
       case 15: TAMD_GD(15)
       case 32: TAMD_GD(32)
+      case 64: TAMD_GD(64)
       default: break;
     }
 #undef TAMD_GD
