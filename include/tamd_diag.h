@@ -40,9 +40,15 @@ int tamd_attn_set_trace(void* buf);
 
 /* Experimental forward attention kernel with 64 query rows per wave (csrc/attention_fwd64.inc): while on, tamd_attn_fwd
  * uses it for head_dim 128 without padding mask / dropout / packed sequences and seq_k % 64 == 0; results are
- * bit-identical to the product kernel.  Not measured on hardware yet (tools/attn_fwd64_ab.py).  Returns the number of
+ * bit-identical to the product kernel (tools/attn_fwd64_ab.py; 954 vs 1008 TFLOP/s bidirectional in round 2).  Returns the number of
  * forwards that have taken the experimental kernel so far. */
 int tamd_attn_set_fwd64(int on);
+
+/* Causal forward attention with two query tiles per workgroup (the heaviest remaining tile, then the lightest: equal
+ * work per workgroup, half as many workgroups to dispatch): while on, tamd_attn_fwd uses it for causal calls without
+ * padding mask / dropout / packed sequences; results are bit-identical to the product kernel.  Returns the number of
+ * forwards that have taken the variant so far.  tools/attn_fwd64_ab.py */
+int tamd_attn_set_pair(int on);
 
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
  * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to

@@ -780,6 +780,33 @@ def test_attention_fwd64_matches_fwd(env):
             assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, causal)
 
 
+def test_attention_fwd_paired_tiles_matches_fwd(env):
+    """Diagnostic variant of the causal forward with two query tiles per workgroup (heaviest + lightest,
+    tamd_attn_set_pair): bit-identical to the product kernel, odd and even tile counts, GQA, a KV offset, ragged ends."""
+    import math
+
+    lib = ops.backend().lib
+    if not hasattr(lib, "tamd_attn_set_pair"):
+        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
+    torch.manual_seed(67)
+    dev = env.device
+    cases = ([(2, 1024, 1024, 8, 2, 128), (1, 700, 704, 4, 4, 128), (1, 4096, 4096, 2, 1, 128), (2, 640, 640, 4, 2, 64)]
+             if env.big else [(1, 384, 384, 2, 1, 128), (1, 100, 192, 2, 2, 128), (2, 256, 256, 2, 1, 64), (1, 128, 128, 1, 1, 64)])
+    for (b, sq, sk, hq, hkv, d) in cases:
+        q = torch.randn(b, sq, hq, d).bfloat16().to(dev)
+        k = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
+        v = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
+        o_ref, lse_ref = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), True)
+        before = lib.tamd_attn_set_pair(1)
+        try:
+            o, lse = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), True)
+            ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), False)            # bidirectional calls keep the product kernel
+        finally:
+            after = lib.tamd_attn_set_pair(0)
+        assert after == before + 1, "the paired variant was not taken exactly once"
+        assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, d)
+
+
 def test_gemm_staggered_k_start(env):
     """Diagnostic variant of the GEMM (tamd_gemm_set_stagger, include/tamd_diag.h): a workgroup starts its K loop a few
     stages in and wraps around.  Same products, rotated fp32 summation order: results agree with the product kernel to

@@ -1,5 +1,7 @@
-"""A/B of the experimental 64-rows-per-wave forward attention kernel (csrc/attention_fwd64.inc, diagnostic library)
-against the product kernel at the Llama-3-8B shape: interleaved rounds, ms and TFLOP/s, bit-identity check."""
+"""A/B of the experimental forward attention kernels of the diagnostic library against the product kernel at the
+Llama-3-8B shape: interleaved rounds, ms and TFLOP/s, bit-identity check.
+  fwd64  64 query rows per wave (csrc/attention_fwd64.inc, tamd_attn_set_fwd64)
+  pair   causal only: two query tiles per workgroup, heaviest + lightest (attn_fwd_pair_kernel, tamd_attn_set_pair)"""
 import json
 import math
 import sys
@@ -21,14 +23,23 @@ for name, b, s, hq, hkv, causal in [("llama3-8b causal", 8, 4096, 32, 8, True), 
     v = torch.randn(b, s, hkv, d, device=dev).bfloat16()
     scale = 1 / math.sqrt(d)
     fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
+    arms = ["fwd32", "fwd64"] + (["pair"] if causal else [])
+
+    def select(key):
+        lib.tamd_attn_set_fwd64(int(key == "fwd64"))
+        lib.tamd_attn_set_pair(int(key == "pair"))
+
     o0, l0 = ops.raw_attn_fwd(q, k, v, scale, causal)
-    lib.tamd_attn_set_fwd64(1)
-    o1, l1 = ops.raw_attn_fwd(q, k, v, scale, causal)
-    lib.tamd_attn_set_fwd64(0)
-    res = {"shape": name, "bit_identical": bool(torch.equal(o0, o1) and torch.equal(l0, l1)), "ms": {"fwd32": [], "fwd64": []}}
+    same = {}
+    for key in arms[1:]:
+        select(key)
+        o1, l1 = ops.raw_attn_fwd(q, k, v, scale, causal)
+        same[key] = bool(torch.equal(o0, o1) and torch.equal(l0, l1))
+    select("fwd32")
+    res = {"shape": name, "bit_identical": same, "ms": {key: [] for key in arms}}
     for rnd in range(3):
-        for on, key in ((0, "fwd32"), (1, "fwd64")):
-            lib.tamd_attn_set_fwd64(on)
+        for key in arms:
+            select(key)
             ops.raw_attn_fwd(q, k, v, scale, causal)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -38,6 +49,6 @@ for name, b, s, hq, hkv, causal in [("llama3-8b causal", 8, 4096, 32, 8, True), 
             e1.record()
             torch.cuda.synchronize()
             res["ms"][key].append(round(e0.elapsed_time(e1) / 5, 4))
-    lib.tamd_attn_set_fwd64(0)
+    select("fwd32")
     res["TFLOPs"] = {kk: round(fl / (min(vv) * 1e-3) / 1e12) for kk, vv in res["ms"].items()}
     print(json.dumps(res), flush=True)
