@@ -21,3 +21,4 @@ PY
 timeout 200 python tools/attn_fwd64_ab.py > gpurun_out/${tag}_attn_fwd_ab.jsonl 2> gpurun_out/${tag}_attn_fwd_ab.err
 cat gpurun_out/${tag}_attn_fwd_ab.jsonl
 bash tools/gpu_r03_tlb.sh ${tag}_tlb
+bash tools/gpu_l2.sh
