@@ -248,7 +248,7 @@ int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* D
 
 /* q|k|v projection with apply_rotary_pos_emb in the GEMM epilogue (models/llama/modeling_llama.py:254-262):
  *   QKV[M, N] = X[M,K] . Wqkv[N,K]^T, rotary embedding on the first rope_cols columns (query + key heads of 128),
- * cos / sin [cos_batch, seq, 128] (cos_batch 1 = shared by the batch rows).  Bit-identical to tamd_gemm followed by
+ * cos / sin [cos_batch, seq, 128] (cos_batch 1 = shared by the batch rows; then seq >= 128).  Bit-identical to tamd_gemm followed by
  * tamd_rope_inplace.  K % 64 == 0, N and rope_cols multiples of 128. */
 int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const void* cos, const void* sin, int64_t M, int64_t N,
                    int64_t K, int64_t ldx, int64_t ldw, int64_t ldqkv, int64_t seq, int64_t cos_batch, int64_t rope_cols,

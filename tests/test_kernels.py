@@ -681,7 +681,10 @@ def test_gemm_rope_epilogue_is_bit_identical_to_unfused(env):
     token counts, value heads untouched."""
     torch.manual_seed(41)
     dev = env.device
-    for (b, s, hq, hkv, k) in ([(2, 1024, 32, 8, 4096), (3, 100, 4, 2, 256)] if env.big else [(2, 72, 2, 1, 128), (1, 130, 1, 1, 64)]):
+    # (a table shared by the batch is indexed by the token's position in its sequence: one wrap per 128-row piece, so
+    # shared tables need seq >= 128 -- shorter ones are refused and take the two-kernel path)
+    for (b, s, hq, hkv, k) in ([(2, 1024, 32, 8, 4096), (3, 200, 4, 2, 256), (9, 40, 2, 1, 128)] if env.big
+                               else [(2, 136, 2, 1, 128), (1, 130, 1, 1, 64), (5, 24, 1, 1, 64)]):
         d, t = 128, b * s
         n = (hq + 2 * hkv) * d
         x = torch.randn(t, k).bfloat16().to(dev)
@@ -692,6 +695,11 @@ def test_gemm_rope_epilogue_is_bit_identical_to_unfused(env):
             sin = torch.cat([ang.sin(), ang.sin()], -1).bfloat16().to(dev)
             if cb == 1:
                 cos, sin = cos[0], sin[0]
+            if cos.dim() == 2 and s < 128:
+                assert not ops.gemm_rope_supported(x, w, cos, d)
+                with pytest.raises(ops.TamdError):
+                    ops.raw_gemm_rope(x, w, cos, sin, s, hq + hkv, d)
+                continue
             assert ops.gemm_rope_supported(x, w, cos, d)
             ref = ops.raw_gemm(x, w)
             ops.raw_rope_(ref, cos, sin, s, hq + hkv, d)

@@ -196,8 +196,19 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
   // operands the way out reads from memory (residual / previous C / the saved gate|up): all of a half's loads are issued
   // BEFORE the accumulators are rounded and staged, so their latency overlaps that work and 16-32 KiB per wave are in
   // flight instead of 4 (the way out was latency-bound at ~2.7 TB/s: 1.05 ms of the 3.8 ms SwiGLU-backward GEMM)
-  constexpr int NR = (EPI == kEpiSwiGLUBwd) ? 2 : ((EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0);
+  constexpr bool ROPE = (EPI == kEpiRope && NCOLS == 128);  // (cos / sin rows of the rotary epilogue are such operands too)
+  constexpr int NR = (EPI == kEpiSwiGLUBwd || ROPE) ? 2 : ((EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0);
   constexpr int NIT = 64 / RPI;
+  // rotary epilogue: this wave's 128 columns are one head; value heads (col0 >= n_half) pass through.  The cos / sin row
+  // of a token is its position in its sequence: ONE 64-bit modulo per wave, the rows of the piece count up from there
+  // (the first version took gm_ % seq per row segment -- 32 software divisions per lane -- and loaded cos / sin inside
+  // the row loop: the fused GEMM was 150 us slower than GEMM + rope_kernel, profiles/r02_gemm_variants.md section 7)
+  const bool rope_here = ROPE && col0 < g.n_half;
+  const int64_t crow_base = !ROPE ? 0 : ((g.cos_batch == 1) ? row0 % g.seq : row0);
+  auto rope_row = [&](int r) -> int64_t {  // r = row inside this wave's piece
+    const int64_t crow = crow_base + r;  // r < 128 <= seq (tamd_gemm_rope refuses shorter shared-table sequences): one wrap
+    return (g.cos_batch == 1 && crow >= g.seq) ? crow - g.seq : crow;
+  };
   // (the SwiGLU backward carries two loads per row segment: in two chunks of 8 iterations -- 64 registers of loads in
   // flight -- so that nothing spills; a kernel with scratch also throttles how many of its waves the CU runs)
   constexpr int CH = (NR == 2 && NIT > 8) ? 8 : NIT;
@@ -214,6 +225,12 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
         if (EPI == kEpiSwiGLUBwd) {
           pre[2 * i] = ok ? ld16(R + gm_ * g.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
           pre[2 * i + 1] = ok ? ld16(R + gm_ * g.ldr + g.n_half + gn) : u32x4{0u, 0u, 0u, 0u};
+        } else if (ROPE) {
+          if (rope_here) {
+            const int64_t crow = rope_row(half * 64 + row);
+            pre[2 * i] = ok ? ld16(R + crow * 128 + slot * 8) : u32x4{0u, 0u, 0u, 0u};
+            pre[2 * i + 1] = ok ? ld16(reinterpret_cast<const T*>(g.C2) + crow * 128 + slot * 8) : u32x4{0u, 0u, 0u, 0u};
+          }
         } else {
           const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
           pre[i] = ok ? ld16(rp) : u32x4{0u, 0u, 0u, 0u};
@@ -252,19 +269,18 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
         }
         continue;
       }
-      if (EPI == kEpiRope && NCOLS == 128 && col0 < g.n_half) {
+      if (ROPE && rope_here) {
         // apply_rotary_pos_emb on a query / key head (this wave's 128 columns are exactly one head of 128):
         //   out = round(round(x * cos) + round(rotate_half(x) * sin)),  rotate_half(x)[d] = -x[d+64] (d < 64), x[d-64]
         // with the roundings of rope_kernel (elementwise.hip), on the rounded projection staged in LDS: bit-identical
         // to tamd_gemm followed by tamd_rope_inplace
         if (gm_ < g.M && gn < g.N) {
           const u32x4 vp = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)(slot ^ 8) * 16u);
-          const int64_t crow = (g.cos_batch == 1) ? (gm_ % g.seq) : gm_;
           float x[8], xp[8], cs[8], sn[8], o[8];
           unpack16<T>(v, x);
           unpack16<T>(vp, xp);
-          unpack16<T>(ld16(R + crow * 128 + slot * 8), cs);
-          unpack16<T>(ld16(reinterpret_cast<const T*>(g.C2) + crow * 128 + slot * 8), sn);
+          unpack16<T>(pre[NR == 2 ? 2 * pi : 0], cs);
+          unpack16<T>(pre[NR == 2 ? 2 * pi + 1 : 0], sn);
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             o[e] = round_through<T>(x[e] * cs[e]) + round_through<T>((slot < 8 ? -xp[e] : xp[e]) * sn[e]);
@@ -1164,6 +1180,7 @@ extern "C" int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const 
   if (M <= 0 || N <= 0 || K <= 0 || seq <= 0 || cos_batch <= 0) return TAMD_E_SHAPE;
   if ((K % kXK) || (N % 128) || (rope_cols % 128) || rope_cols > N || (ldx % 8) || (ldw % 8) || (ldqkv % 8)) return TAMD_E_SHAPE;
   if (cos_batch != 1 && cos_batch * seq != M) return TAMD_E_SHAPE;
+  if (cos_batch == 1 && seq < 128) return TAMD_E_SHAPE;  // (the way out wraps the shared table's row index once per 128 rows)
   if (!aligned16(X) || !aligned16(Wqkv) || !aligned16(QKV) || !aligned16(cosp) || !aligned16(sinp)) return TAMD_E_ALIGN;
   GemmArgs g;
   gemm_fill_args(&g, X, Wqkv, QKV, nullptr, cosp, M, N, K, ldx, ldw, ldqkv, 128);

@@ -15,7 +15,15 @@ from . import ops
 from .ops import EPI_RESIDUAL, define_op
 
 T = torch.ops.tamd
-_FUSE_ROPE = os.environ.get("TAMD_FUSE_ROPE", "1") != "0"  # (A/B switch for measurements: rotary in the GEMM / attention epilogues)
+# Rotary embedding in the epilogues (both bit-identical to the two-kernel paths; A/B switches for measurements).
+# Backward (transposed rotary on dq / dk inside the attention backward): ON -- saves the 118-us rotary kernel for
+# ~50-70 us of epilogue.  Forward (tamd_gemm_rope): OFF until the rewritten way out is measured -- across eight profiled
+# runs of round 2 the fused q|k|v GEMM took 1377-1518 us where GEMM + rope_kernel took 1285-1372 us (normalised by the
+# gate|up GEMM of the same run: 0.245-0.267 against 0.225-0.234): its first way out divided a 64-bit index per row
+# segment and loaded cos / sin inside the row loop; the rewrite (csrc/gemm.hip gemm_epilogue_rows, a third fewer
+# instructions) is what TAMD_FUSE_ROPE_FWD=1 selects.  profiles/r02_gemm_variants.md section 7
+_FUSE_ROPE_FWD = os.environ.get("TAMD_FUSE_ROPE_FWD", "0") == "1"
+_FUSE_ROPE_BWD = os.environ.get("TAMD_FUSE_ROPE_BWD", "1") != "0"
 # SwiGLU backward in the d_act GEMM epilogue (tamd_gemm_swiglu_bwd): OFF by default.  The fused kernel is 0.2 ms per
 # layer faster than GEMM + swiglu_bwd on some runs (3.65 vs 3.87 ms) and 1.9 ms slower on others (5.7 ms; same binary,
 # same data -- the epilogue streams five large arrays in lockstep and its speed depends on where the run's buffers land
@@ -30,7 +38,7 @@ def _split_qkv(qkv, b, s, hq, hkv, d):
     return q, k, v
 
 
-# forward : rmsnorm -> QKV GEMM with the rotary epilogue -> attention -> o_proj GEMM(+residual)
+# forward : rmsnorm -> QKV GEMM, rotary (kernel, or the GEMM's epilogue) -> attention -> o_proj GEMM(+residual)
 #           -> rmsnorm -> gate|up GEMM with the SwiGLU epilogue -> down GEMM(+residual)
 def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, eps,
                       hq, hkv, d, scale, causal, train):
@@ -38,7 +46,7 @@ def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, w
     t = b * s
     x = ops._c(h_in).view(t, hd)
     xn, _, rstd1 = ops.raw_rmsnorm_fwd(x, w_ln1, eps)
-    if _FUSE_ROPE and ops.gemm_rope_supported(xn, wqkv, cos, d):  # apply_rotary_pos_emb in the q|k|v GEMM epilogue
+    if _FUSE_ROPE_FWD and ops.gemm_rope_supported(xn, wqkv, cos, d):  # apply_rotary_pos_emb in the q|k|v GEMM epilogue
         qkv = ops.raw_gemm_rope(xn, wqkv, cos, sin, s, hq + hkv, d)
     else:
         qkv = ops.raw_gemm(xn, wqkv)
@@ -102,7 +110,7 @@ def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
     d_qkv = torch.empty_like(qkv)
     q, k, v = _split_qkv(qkv, b, s, hq, hkv, d)
     dq, dk, dv = _split_qkv(d_qkv, b, s, hq, hkv, d)
-    fused_rope = _FUSE_ROPE and ops.attn_bwd_rope_supported(q, k, cos, d)  # the transposed rotary on dq / dk inside the kernels
+    fused_rope = _FUSE_ROPE_BWD and ops.attn_bwd_rope_supported(q, k, cos, d)  # the transposed rotary on dq / dk inside the kernels
     ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, hq, d), scale, causal, key_valid, dq=dq, dk=dk, dv=dv,
                      q_start=q_start, rope=(cos, sin) if fused_rope else None)
     del d_o

@@ -502,9 +502,10 @@ def attn_bwd_rope_supported(q, k, cos, head_dim) -> bool:
 
 
 def gemm_rope_supported(x2, wqkv, cos, head_dim) -> bool:
-    """Shapes the q|k|v GEMM with the rotary epilogue takes (csrc/gemm.hip tamd_gemm_rope): heads of 128."""
+    """Shapes the q|k|v GEMM with the rotary epilogue takes (csrc/gemm.hip tamd_gemm_rope): heads of 128; a cos / sin
+    table shared by the batch ([seq, 128]) needs seq >= 128."""
     n, k = wqkv.shape
-    return (head_dim == 128 and x2.dtype in (torch.bfloat16, torch.float16) and wqkv.dtype == x2.dtype and k % 64 == 0
+    return (head_dim == 128 and (cos.dim() == 3 and cos.shape[0] > 1 or cos.shape[-2] >= 128) and x2.dtype in (torch.bfloat16, torch.float16) and wqkv.dtype == x2.dtype and k % 64 == 0
             and n % 128 == 0 and x2.stride(1) == 1 and wqkv.stride(1) == 1 and x2.stride(0) % 8 == 0
             and wqkv.stride(0) % 8 == 0 and cos.shape[-1] == 128
             # a tile grid that cannot fill the GPU (a short prompt) is better off with split-K and the rotary kernel
