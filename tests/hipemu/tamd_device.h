@@ -347,6 +347,15 @@ inline u32x4 buf_load16(const void* base, unsigned voff) {
   memcpy(&v, reinterpret_cast<const char*>(base) + voff, 16);
   return v;
 }
+// range-checked variants: outside [0, bytes) a load returns zeros and a store is dropped
+inline u32x4 buf_load16_rng(const void* base, unsigned bytes, unsigned voff) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if ((unsigned long long)voff + 16ull <= (unsigned long long)bytes) memcpy(&v, reinterpret_cast<const char*>(base) + voff, 16);
+  return v;
+}
+inline void buf_store16_rng(void* base, unsigned bytes, unsigned voff, u32x4 v) {
+  if ((unsigned long long)voff + 16ull <= (unsigned long long)bytes) memcpy(reinterpret_cast<char*>(base) + voff, &v, 16);
+}
 // 4-byte variant (global_load_lds_dword): LDS destination = wave-uniform base + lane*4
 inline void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   const int lane = hipemu::cur_lane();

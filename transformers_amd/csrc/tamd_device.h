@@ -190,6 +190,18 @@ __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned voff) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
 }
+// Range-checked 16-byte buffer accesses: wave-uniform `base` and size in bytes; a lane whose 16 bytes are not inside
+// [0, bytes) reads zeros / stores nothing (the hardware's buffer range check; offsets and sizes here are multiples of 16,
+// so an access is either wholly inside or wholly outside).  Ragged rows and tails cost no branch -- and hipcc answers a
+// branch around a store with s_waitcnt vmcnt(0) at the join: gfx9-family loads and stores share one out-of-order counter.
+__device__ __forceinline__ u32x4 buf_load16_rng(const void* base, unsigned bytes, unsigned voff) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store16_rng(void* base, unsigned bytes, unsigned voff, u32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, (int)voff, 0, 0);
+}
 // 4-byte variant (global_load_lds_dword): the wave writes 64 x 4 B = 256 B contiguous at smem + wave_base_off
 __device__ __forceinline__ void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
