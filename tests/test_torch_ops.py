@@ -170,3 +170,25 @@ def test_llama_layer_op_twice_differentiable_graph(env):
     loss.backward()
     for n, p in m.named_parameters():
         assert torch.equal(p.grad, g1[n]), n
+
+
+def test_llama_layer_saved_swiglu_product_matches_rematerialised(env, monkeypatch):
+    """The SiLU*up product kept from the forward (layer_ops._SAVE_ACT, the default: memory for HBM traffic) and the one the
+    SwiGLU backward re-materialises are the same bits: every gradient of a two-layer model is identical either way."""
+    import transformers_amd
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(3)
+    cfg = LlamaConfig(vocab_size=128, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                      num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=64,
+                      attn_implementation="eager")
+    m = transformers_amd.accelerate(LlamaForCausalLM(cfg).bfloat16().to(env.device)).train()
+    ids = torch.randint(0, 128, (2, 24)).to(env.device)
+    grads = []
+    for save in (True, False):
+        monkeypatch.setattr(layer_ops, "_SAVE_ACT", save)
+        m.zero_grad(set_to_none=True)
+        m(input_ids=ids, labels=ids, use_cache=False).loss.backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n

@@ -29,6 +29,11 @@ _FUSE_ROPE_BWD = os.environ.get("TAMD_FUSE_ROPE_BWD", "1") != "0"
 # same data -- the epilogue streams five large arrays in lockstep and its speed depends on where the run's buffers land
 # physically): 1292 vs 1359 ms per step measured back to back on one box.  profiles/r02_regression_note.md
 _FUSE_SWIGLU_BWD = os.environ.get("TAMD_FUSE_SWIGLU_BWD", "0") == "1"
+# The SiLU*up product `act` [T, I] (the down projection's input, needed again for its weight gradient) is KEPT for the
+# backward instead of re-materialised there: the gate|up GEMM's epilogue writes it anyway, so keeping it costs no time
+# and T*I*2 bytes per layer (0.94 GB at the Llama-3-8B shape: 30 GB over 32 layers on a 288 GB part, peak 141 -> 171 GB),
+# and the HBM-bound SwiGLU backward kernel writes 4.70 instead of 5.64 GB.  TAMD_SAVE_SWIGLU_ACT=0 re-materialises.
+_SAVE_ACT = os.environ.get("TAMD_SAVE_SWIGLU_ACT", "1") != "0"
 
 
 def _split_qkv(qkv, b, s, hq, hkv, d):
@@ -63,8 +68,9 @@ def _llama_layer_impl(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, w
     h_out = ops.raw_gemm(act, wd, residual=h_mid, epilogue=EPI_RESIDUAL).view(b, s, hd)
     if not train:
         e = h_out.new_empty(0)
-        return h_out, e, e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone()
-    return h_out, xn, qkv, o, lse, h_mid, xn2, gu, rstd1, rstd2
+        return (h_out, e, e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone(), e.clone(),
+                e.clone())
+    return h_out, xn, qkv, o, lse, h_mid, xn2, gu, rstd1, rstd2, (act if _SAVE_ACT else h_out.new_empty(0))
 
 
 def _llama_layer_fake(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd, eps, hq,
@@ -73,19 +79,20 @@ def _llama_layer_fake(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, w
     t = b * s
     h_out = h_in.new_empty(b, s, hd)
     if not train:
-        return (h_out,) + tuple(h_in.new_empty(0) for _ in range(9))
+        return (h_out,) + tuple(h_in.new_empty(0) for _ in range(10))
     f32 = dict(dtype=torch.float32)
     return (h_out, h_in.new_empty(t, hd), h_in.new_empty(t, wqkv.shape[0]), h_in.new_empty(b, s, hq, d),
             h_in.new_empty(b, hq, s, **f32), h_in.new_empty(t, hd), h_in.new_empty(t, hd),
-            h_in.new_empty(t, wgu.shape[0]), h_in.new_empty(t, **f32), h_in.new_empty(t, **f32))
+            h_in.new_empty(t, wgu.shape[0]), h_in.new_empty(t, **f32), h_in.new_empty(t, **f32),
+            h_in.new_empty(t, wgu.shape[0] // 2) if _SAVE_ACT else h_in.new_empty(0))
 
 
 # backward: the derivatives of SURVEY.md section 8a in reverse; every weight gradient is a k-major GEMM on the saved
-# activations, the SiLU*up product is re-materialised instead of stored, and the residual-stream gradient is folded
-# into the RMSNorm backward kernels (`dres`).  Nothing saved by the forward is written (a retained graph can be
-# differentiated twice).
+# activations, the SiLU*up product comes from the forward (`act_saved`, _SAVE_ACT) or is re-materialised (an empty
+# `act_saved`), and the residual-stream gradient is folded into the RMSNorm backward kernels (`dres`).  Nothing saved
+# by the forward is written (a retained graph can be differentiated twice).
 def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o,
-                          lse, h_mid, rstd2, xn2, gu, hq, hkv, d, scale, causal):
+                          lse, h_mid, rstd2, xn2, gu, act_saved, hq, hkv, d, scale, causal):
     b, s, hd = h_in.shape
     t = b * s
     x = ops._c(h_in).view(t, hd)
@@ -95,7 +102,10 @@ def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
         d_gu, act = ops.raw_gemm_swiglu_bwd(dh, wd, gu)
     else:
         d_act = ops.raw_gemm(dh, wd, b_kn=True)                              # [T, I]
-        d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
+        if act_saved.numel():
+            d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=False)[0], act_saved
+        else:
+            d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
         del d_act
     dwd = ops.raw_gemm(dh, act, a_km=True, b_kn=True)                        # [hd, I]
     del act
@@ -123,7 +133,7 @@ def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
 
 
 def _llama_layer_bwd_fake(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv,
-                          o, lse, h_mid, rstd2, xn2, gu, hq, hkv, d, scale, causal):
+                          o, lse, h_mid, rstd2, xn2, gu, act_saved, hq, hkv, d, scale, causal):
     return (torch.empty_like(h_in, memory_format=torch.contiguous_format), torch.empty_like(w_ln1),
             torch.empty_like(wqkv), torch.empty_like(wo), torch.empty_like(w_ln2), torch.empty_like(wgu),
             torch.empty_like(wd))
@@ -132,9 +142,9 @@ def _llama_layer_bwd_fake(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
 def _llama_layer_setup(ctx, inputs, output):
     (h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, _wq, _wk, _wv, wo, w_ln2, wgu, _wg, _wu, wd, _eps, hq, hkv, d,
      scale, causal, train) = inputs
-    _h_out, xn, qkv, o, lse, h_mid, xn2, gu, rstd1, rstd2 = output
+    _h_out, xn, qkv, o, lse, h_mid, xn2, gu, rstd1, rstd2, act = output
     ctx.save_for_backward(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse,
-                          h_mid, rstd2, xn2, gu)
+                          h_mid, rstd2, xn2, gu, act)
     ctx.meta = (hq, hkv, d, scale, causal, train)
     ctx.set_materialize_grads(False)
 
@@ -158,12 +168,12 @@ def _llama_layer_backward(ctx, d_hout, *_aux):
 define_op("llama_layer(Tensor h_in, Tensor cos, Tensor sin, Tensor? key_valid, Tensor? q_start, Tensor w_ln1, "
           "Tensor wqkv, Tensor wq, Tensor wk, Tensor wv, Tensor wo, Tensor w_ln2, Tensor wgu, Tensor wg, Tensor wu, "
           "Tensor wd, float eps, int hq, int hkv, int d, float scale, bool causal, bool train) -> "
-          "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+          "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
           _llama_layer_impl, _llama_layer_fake, _llama_layer_backward, _llama_layer_setup)
 define_op("llama_layer_bwd(Tensor d_hout, Tensor h_in, Tensor cos, Tensor sin, Tensor? key_valid, Tensor? q_start, "
           "Tensor w_ln1, Tensor wqkv, Tensor wo, Tensor w_ln2, Tensor wgu, Tensor wd, Tensor rstd1, Tensor xn, "
-          "Tensor qkv, Tensor o, Tensor lse, Tensor h_mid, Tensor rstd2, Tensor xn2, Tensor gu, int hq, int hkv, int d, "
-          "float scale, bool causal) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+          "Tensor qkv, Tensor o, Tensor lse, Tensor h_mid, Tensor rstd2, Tensor xn2, Tensor gu, Tensor act_saved, int hq, "
+          "int hkv, int d, float scale, bool causal) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
           _llama_layer_bwd_impl, _llama_layer_bwd_fake)
 
 
