@@ -56,11 +56,21 @@ class HipBackend:
         # raw handle of torch's current stream on the tensor's device (no Stream object: this runs once per kernel)
         idx = t.device.index
         if _RAW_STREAM is not None:
-            return _RAW_STREAM(idx if idx is not None else torch.cuda.current_device())
+            return _RAW_STREAM(idx if idx is not None else _current_device())
         return torch.cuda.current_stream(t.device).cuda_stream
 
 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+_CUDA_OK = None  # torch.cuda.is_available(), asked once (it re-counts the devices on every call)
+
+
+def _current_device() -> int:
+    """torch.cuda.current_device() without its Python layers once CUDA is initialised (this runs several times per
+    kernel launch; a small-model step is hundreds of 10-us launches and its host side is what bounds it)."""
+    if _RAW_GET_DEVICE is not None and torch.cuda.is_initialized():
+        return _RAW_GET_DEVICE()
+    return torch.cuda.current_device()
 _backend = None
 _backend_lock = threading.Lock()
 
@@ -110,7 +120,7 @@ def _prep(*tensors):
                 dev = t.device
             elif t.device != dev:
                 raise TamdError(f"tamd op operands live on different devices: {dev} and {t.device}")
-    if dev is not None and dev.type == "cuda" and dev.index != torch.cuda.current_device():
+    if dev is not None and dev.type == "cuda" and dev.index != _current_device():
         torch.cuda.set_device(dev)  # restored by `_device_guard` around the raw_* call
     return be
 
@@ -121,13 +131,16 @@ def _device_guard(fn):
 
     @functools.wraps(fn)
     def guarded(*args, **kwargs):
-        if not torch.cuda.is_available():
+        global _CUDA_OK
+        if _CUDA_OK is None:
+            _CUDA_OK = torch.cuda.is_available()
+        if not _CUDA_OK:
             return fn(*args, **kwargs)
-        cur = torch.cuda.current_device()
+        cur = _current_device()
         try:
             return fn(*args, **kwargs)
         finally:
-            if torch.cuda.current_device() != cur:
+            if _current_device() != cur:
                 torch.cuda.set_device(cur)
 
     return guarded
