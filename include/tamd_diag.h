@@ -44,10 +44,10 @@ int tamd_attn_set_trace(void* buf);
  * forwards that have taken the experimental kernel so far. */
 int tamd_attn_set_fwd64(int on);
 
-/* Causal forward attention with two query tiles per workgroup (the heaviest remaining tile, then the lightest: equal
- * work per workgroup, half as many workgroups to dispatch): while on, tamd_attn_fwd uses it for causal calls without
- * padding mask / dropout / packed sequences; results are bit-identical to the product kernel.  Returns the number of
- * forwards that have taken the variant so far.  tools/attn_fwd64_ab.py */
+/* Causal attention with two query tiles per workgroup (the heaviest remaining tile, then the lightest: equal work per
+ * workgroup, half as many workgroups to dispatch).  `on` bit 0: tamd_attn_fwd, bit 1: the dQ kernel of tamd_attn_bwd, for
+ * causal calls without padding mask / dropout / packed sequences; results are bit-identical to the product kernels.
+ * Returns the number of launches that have taken a paired variant so far.  tools/attn_fwd64_ab.py */
 int tamd_attn_set_pair(int on);
 
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,

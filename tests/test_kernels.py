@@ -813,6 +813,17 @@ def test_attention_fwd_paired_tiles_matches_fwd(env):
             after = lib.tamd_attn_set_pair(0)
         assert after == before + 1, "the paired variant was not taken exactly once"
         assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, d)
+        # the dQ kernel of the backward, paired the same way (bit 1 of the switch)
+        do = torch.randn(b, sq, hq, d).bfloat16().to(dev)
+        ref = ops.raw_attn_bwd(q, k, v, o_ref, lse_ref, do, 1 / math.sqrt(d), True, None)
+        before = lib.tamd_attn_set_pair(2)
+        try:
+            got = ops.raw_attn_bwd(q, k, v, o_ref, lse_ref, do, 1 / math.sqrt(d), True, None)
+        finally:
+            after = lib.tamd_attn_set_pair(0)
+        assert after == before + 1
+        for x, y in zip(got, ref):
+            assert torch.equal(x, y), (b, sq, sk, hq, hkv, d)
 
 
 def test_gemm_staggered_k_start(env):

@@ -52,3 +52,33 @@ for name, b, s, hq, hkv, causal in [("llama3-8b causal", 8, 4096, 32, 8, True), 
     select("fwd32")
     res["TFLOPs"] = {kk: round(fl / (min(vv) * 1e-3) / 1e12) for kk, vv in res["ms"].items()}
     print(json.dumps(res), flush=True)
+
+# ---- backward: the dQ kernel with two query tiles per workgroup (tamd_attn_set_pair bit 1); whole-backward ms
+# (delta + dQ + dK/dV -- only dQ differs between the arms), causal Llama-3-8B shape, interleaved rounds
+b, s, hq, hkv, d = 8, 4096, 32, 8, 128
+q = torch.randn(b, s, hq, d, device=dev).bfloat16()
+k = torch.randn(b, s, hkv, d, device=dev).bfloat16()
+v = torch.randn(b, s, hkv, d, device=dev).bfloat16()
+do = torch.randn(b, s, hq, d, device=dev).bfloat16()
+scale = 1 / math.sqrt(d)
+o, lse = ops.raw_attn_fwd(q, k, v, scale, True)
+dq, dk, dv = (torch.empty_like(t) for t in (q, k, v))
+ref = [t.clone() for t in ops.raw_attn_bwd(q, k, v, o, lse, do, scale, True, None)]
+lib.tamd_attn_set_pair(2)
+got = ops.raw_attn_bwd(q, k, v, o, lse, do, scale, True, None)
+res = {"shape": "llama3-8b causal backward", "bit_identical": all(bool(torch.equal(x, y)) for x, y in zip(got, ref)),
+       "ms": {"bwd": [], "bwd_dq_pair": []}}
+for rnd in range(3):
+    for on, key in ((0, "bwd"), (2, "bwd_dq_pair")):
+        lib.tamd_attn_set_pair(on)
+        ops.raw_attn_bwd(q, k, v, o, lse, do, scale, True, None, dq=dq, dk=dk, dv=dv)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.raw_attn_bwd(q, k, v, o, lse, do, scale, True, None, dq=dq, dk=dk, dv=dv)
+        e1.record()
+        torch.cuda.synchronize()
+        res["ms"][key].append(round(e0.elapsed_time(e1) / 5, 4))
+lib.tamd_attn_set_pair(0)
+print(json.dumps(res), flush=True)

@@ -175,10 +175,12 @@ extern "C" int tamd_attn_set_trace(void* buf) {
   return TAMD_OK;
 }
 // 1: tamd_attn_fwd takes the experimental 64-rows-per-wave kernel (attention_fwd64.inc) wherever it applies
-// 1: causal forwards without mask / dropout take two query tiles per workgroup (heavy + light); returns the launch count
+// bit 0: causal forwards, bit 1: causal dQ launches without mask / dropout take two query tiles per workgroup (heavy +
+// light); returns how many launches have taken a paired variant so far
 extern "C" int tamd_attn_set_pair(int on) {
-  g_attn_pair = on;
-  return g_attn_pair_launches;
+  g_attn_pair = on & 1;
+  g_attn_pair_bwd = (on >> 1) & 1;
+  return g_attn_pair_launches + g_attn_pair_bwd_launches;
 }
 extern "C" int tamd_attn_set_fwd64(int on) {
   g_attn_fwd64 = on;
