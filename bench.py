@@ -308,6 +308,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="llama3-8b", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="forward-only configurations (llava): capture one step in a HIP graph after the warm-up and time "
+                         "replays -- the host side (10-20 us per op, ~3300 launches) is what bounds that regime")
     ap.add_argument("--fused-lm-head-loss", action="store_true")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in DDP over RCCL even with one rank (exercises init / bucket all-reduce / destroy)")
@@ -424,10 +427,29 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     barrier()
-    timer.enabled = rank == 0
+    run = step
+    if args.hip_graph:
+        if backward or world > 1:
+            raise SystemExit("--hip-graph: single-GPU forward-only configurations")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # (capture wants the allocator warmed on a side stream)
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def run():
+            graph.replay()
+            return static_loss
+
+        barrier()
+    timer.enabled = rank == 0 and not args.hip_graph  # (per-GEMM events cannot be read out of a replayed graph)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     barrier()
     dt = time.perf_counter() - t0
     timer.enabled = False
@@ -457,7 +479,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload, "model": args.config, "global_batch": batch * world, "seq_len": seq,
-                       "parallelism": f"dp{world}" + (" (DDP over RCCL)" if ddp else "")},
+                       "parallelism": f"dp{world}" + (" (DDP over RCCL)" if ddp else "")
+                       + (" (HIP graph replay)" if args.hip_graph else "")},
             "tokens_per_sec_per_gpu": value / world,
             "model_tflops_per_gpu": flops_step * args.steps / dt / 1e12,
             "mfu_vs_2500TF": flops_step * args.steps / dt / (PEAK_BF16_TFLOPS * 1e12),

@@ -28,3 +28,7 @@ timeout 200 python tools/attn_fwd64_ab.py > gpurun_out/${tag}_attn_fwd_ab.jsonl 
 cat gpurun_out/${tag}_attn_fwd_ab.jsonl
 bash tools/gpu_r03_tlb.sh ${tag}_tlb
 bash tools/gpu_l2.sh
+# LLaVA forward: host-bound?  the same step eagerly and as a replayed HIP graph
+for extra in "" "--hip-graph"; do
+  timeout 240 python bench.py --config llava --steps 20 --warmup 5 --no-cpu-baseline $extra 2> gpurun_out/${tag}_llava${extra}.err | tee -a gpurun_out/${tag}_llava_graph_ab.jsonl | cut -c1-300
+done
