@@ -114,3 +114,16 @@ def test_untracked_lds_reads_are_not_touched_before_their_wait(src, flags, defin
         bad += lint_kernel(m.group(1), body.splitlines())  # (a spill of a pending register is a read of it: caught)
     assert checked > 0
     assert not bad, "\n".join(bad[:10])
+    if src == "gemm.hip":
+        # a second thing only the generated code shows: per-lane software divisions in a GEMM kernel.  The tile decode
+        # divides on the scalar unit; a `%` or `/` on a per-lane 64-bit index inside a way-out row loop costs ~40 VALU
+        # instructions per row segment with nothing to overlap them (the first rotary epilogue did: 96 v_mul_hi_u32, 12.5 k
+        # instructions, 150 us per launch slower than GEMM + rotary kernel -- profiles/r02_gemm_variants.md section 7)
+        heavy = []
+        for k in kernels:
+            m = re.match(r"(_ZN4tamd\w*gemm_\w+):", k)
+            if m:
+                n = k.split("s_endpgm")[0].count("v_mul_hi_u32")
+                if n > 8:
+                    heavy.append(f"{m.group(1)}: {n} x v_mul_hi_u32")
+        assert not heavy, "per-lane divisions in GEMM kernels:\n" + "\n".join(heavy[:10])
