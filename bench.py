@@ -65,7 +65,7 @@ CONFIGS = {
 }
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-GEMM_TRAFFIC_FILES = ("r02_gemm_traffic.json", "r01_gemm_traffic.json")
+GEMM_TRAFFIC_FILES = ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
 
 
 def llama_flops_per_token(m, seq, backward=True) -> float:
@@ -270,6 +270,39 @@ def cpu_baseline(model_cfg, seq, layers, threads=None, iters=3):
                         f"{layers} layers extrapolated; embedding/lm_head/loss excluded"))
 
 
+def cpu_baseline_bert(batch, seq, sample_batch=8, threads=None, iters=2):
+    """Reference eager path on the host cores for BASELINE config 2: the reference's own BertForMaskedLM (bert-base-uncased
+    architecture, random init, bf16, train mode, eager attention) fwd+bwd on a `sample_batch` x seq slice of the workload
+    (every sequence is independent: tokens/s does not depend on the batch beyond cache effects)."""
+    import torch
+    from transformers import BertConfig, BertForMaskedLM
+
+    threads = threads or os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    cfg = BertConfig(attn_implementation="eager")
+    model = BertForMaskedLM(cfg).to(torch.bfloat16).train()
+    ids = torch.randint(1000, cfg.vocab_size, (sample_batch, seq))
+    labels = ids.clone()
+    labels[torch.rand(sample_batch, seq) < 0.85] = -100
+
+    def step():
+        model(input_ids=ids, labels=labels).loss.backward()
+        model.zero_grad(set_to_none=True)
+
+    step()  # warm-up (allocator, thread pool)
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    return dict(value=sample_batch * seq / dt, unit="tokens/s", cores=threads, kind="reference",
+                sample=(f"transformers eager BertForMaskedLM (bert-base-uncased dims, all 12 layers + MLM head + loss) fwd+bwd, "
+                        f"batch {sample_batch} x seq {seq} of the workload's {batch} x {seq}, bf16, train mode, mean of "
+                        f"{iters} iterations ({', '.join(f'{t:.2f}' for t in times)} s)"))
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     with socket.socket() as s:
@@ -312,8 +345,15 @@ def main():
                     help="forward-only configurations (llava): capture one step in a HIP graph after the warm-up and time "
                          "replays -- the host side (10-20 us per op, ~3300 launches) is what bounds that regime")
     ap.add_argument("--fused-lm-head-loss", action="store_true")
+    ap.add_argument("--gemm-timer", choices=("auto", "on", "off"), default="auto",
+                    help="HIP-event pair around every GEMM launch of the timed region (the `roofline` object).  auto = on for "
+                         "the Llama configurations, off for bert-base / llava: their steps are hundreds to thousands of "
+                         "10-50 us launches and two event records per GEMM add host time to a host-bound step")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in DDP over RCCL even with one rank (exercises init / bucket all-reduce / destroy)")
+    ap.add_argument("--ddp-grads", choices=("none", "zero", "keep"), default="none",
+                    help="between steps: none = zero_grad(set_to_none=True) (Trainer's default), zero = zero in place "
+                         "(gradients stay views of the DDP buckets), keep = no zero_grad (gradients accumulate)")
     ap.add_argument("--bucket-mb", type=int, default=int(os.environ.get("TAMD_DDP_BUCKET_MB", "256")))
     args = ap.parse_args()
 
@@ -402,7 +442,9 @@ def main():
         metric = "forward tokens/sec (whole job), LLaVA-1.5-7B 336px image + 512 text tokens"
 
     timer = GemmTimer()
-    timer.install()
+    use_timer = args.gemm_timer == "on" or (args.gemm_timer == "auto" and kind == "llama")
+    if use_timer:
+        timer.install()
     net = model
     if ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
@@ -416,7 +458,14 @@ def main():
                 return fwd(net).logits[0, -1, 0].float()
         out = fwd(net)
         out.loss.backward()
-        model.zero_grad(set_to_none=True)
+        # What Trainer does between steps (optimizer.zero_grad(), set_to_none=True).  Under DDP with
+        # gradient_as_bucket_view the next backward then hands DDP fresh gradient tensors, which it copies into the bucket
+        # views (read 16 + write 16 GB: ~6 ms of a 1.28 s step); zeroing in place instead costs a 16 GB memset plus
+        # autograd's in-place accumulate (read 32 + write 16 GB: ~13 ms) -- `--ddp-grads zero|keep` selects those for an A/B
+        if args.ddp_grads == "none":
+            model.zero_grad(set_to_none=True)
+        elif args.ddp_grads == "zero":
+            model.zero_grad(set_to_none=False)
         return out.loss.detach()
 
     def barrier():
@@ -446,7 +495,8 @@ def main():
             return static_loss
 
         barrier()
-    timer.enabled = rank == 0 and not args.hip_graph  # (per-GEMM events cannot be read out of a replayed graph)
+    transformers_amd.fallback_calls(reset=True)
+    timer.enabled = use_timer and rank == 0 and not args.hip_graph  # (per-GEMM events cannot be read out of a replayed graph)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run()
@@ -486,6 +536,9 @@ def main():
             "mfu_vs_2500TF": flops_step * args.steps / dt / (PEAK_BF16_TFLOPS * 1e12),
             "loss": float(loss),
             "max_memory_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+            # GPU tensors served by a reference module's own forward (ATen / vendor kernels) inside the timed region
+            "fallback_calls": sum(transformers_amd.fallback_calls().values()),
+            "fallbacks": transformers_amd.fallback_calls(),
             "roofline": roofline,
         }
         if roofline is not None and world == 1 and args.config == "llama3-8b":
@@ -493,9 +546,10 @@ def main():
                 roofline["clock_probe"] = clock_probe(dev)
             except Exception as e:  # diagnostics only
                 roofline["clock_probe"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and world == 1 and args.config == "llama3-8b":
+        if not args.no_cpu_baseline and world == 1 and args.config in ("llama3-8b", "bert-base"):
             try:
-                line["cpu_baseline"] = cpu_baseline(c["model"], seq, c["model"]["num_hidden_layers"])
+                line["cpu_baseline"] = (cpu_baseline(c["model"], seq, c["model"]["num_hidden_layers"])
+                                        if kind == "llama" else cpu_baseline_bert(batch, seq))
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)

@@ -73,3 +73,28 @@ def test_mask_function_decoder():
         tamd_mask(2, 12, 12, mask_function=lambda b, h, q, k: q >= k)
     with pytest.raises(ops.TamdError):
         tamd_mask(2, 4, 12, q_offset=8, mask_function=fn)
+
+
+def test_mask_for_cross_attention_is_the_padding_mask():
+    """create_bidirectional_mask with encoder_hidden_states calls the mask factory with q_offset = 0
+    and kv_length = encoder length != q_length (masking_utils.py: `create_bidirectional_mask`).  That is not a cache:
+    every query sees every valid encoder key -- for q_length < kv_length, q_length == 1 and q_length > kv_length alike."""
+    from transformers import masking_utils as mu
+
+    bi = getattr(mu, "bidirectional_mask_function", None)
+    if bi is None:
+        pytest.skip("reference without bidirectional_mask_function")
+    enc = torch.ones(2, 10, dtype=torch.long)
+    enc[1, 7:] = 0
+    for q_len in (4, 1, 16):
+        m = tamd_mask(2, q_len, 10, q_offset=0, mask_function=bi, attention_mask=enc)
+        assert torch.equal(m, enc) and m.shape == (2, 10)
+        assert tamd_mask(2, q_len, 10, q_offset=0, mask_function=bi) is None
+    # a causal prefill into a pre-allocated cache still yields the mask over the slots in use: its LENGTH carries kv_len
+    m = tamd_mask(2, 4, 32, q_offset=3, mask_function=mu.causal_mask_function, device=torch.device("cpu"))
+    assert m.shape == (2, 7) and bool(m.all())
+    from transformers_amd.attention import _mask_kv_len
+
+    assert _mask_kv_len(m) == 7 and _mask_kv_len(m.to(torch.int32)[:1]) == 7 and _mask_kv_len(None) is None
+    with pytest.raises(ops.TamdError):
+        tamd_mask(2, 4, 6, q_offset=3, mask_function=mu.causal_mask_function, device=torch.device("cpu"))

@@ -12,6 +12,7 @@ import json
 import sys
 
 root, prefix = sys.argv[1], sys.argv[2]
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
 agg = {"fetch": collections.defaultdict(lambda: [0.0, 0]), "write": collections.defaultdict(lambda: [0.0, 0])}
 for which in agg:
     for f in glob.glob(f"{root}/{which}/**/*counter_collection.csv", recursive=True):
@@ -40,6 +41,6 @@ if gemm["fetch"][1] and gemm["write"][1]:
                "gemm_launches_profiled": gemm["fetch"][1],
                "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1`; "
                       "all tamd::gemm_* dispatches; read bytes = 2 x FETCH_SIZE KiB (gfx950 correction)"}
-    for path in ("profiles/r02_gemm_traffic.json", prefix + "_gemm_traffic.json"):  # (gpurun merges gpurun_out/ back, not profiles/)
+    for path in (f"profiles/{rnd}_gemm_traffic.json", prefix + "_gemm_traffic.json"):  # (gpurun merges gpurun_out/ back, not profiles/)
         json.dump(summary, open(path, "w"), indent=1)
 print("\n".join(lines[:25]))

@@ -10,6 +10,7 @@ __version__ = "0.1.0"
 
 from . import attention as _attention
 from . import layer_ops as _layer_ops  # noqa: F401  (registers torch.ops.tamd.llama_layer)
+from .models.common import fallback_calls  # noqa: F401
 from .optim import TamdAdamW  # noqa: F401
 from .patch import accelerate, revert  # noqa: F401
 

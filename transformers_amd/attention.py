@@ -32,13 +32,18 @@ class TamdMask:
         self.key_valid, self.q_start = key_valid, q_start
 
 
-def _with_kv_len(key_valid: torch.Tensor, kv_len: int) -> torch.Tensor:
-    """Prefill into a pre-allocated (static) KV cache: the 2-D key-validity mask over the `kv_len` cache slots in use,
-    tagged with that length.  The attention function slices K/V to it, so the kernels' bottom-right causal alignment is
-    the reference's `kv_idx <= q_idx + q_offset`.  (A plain tensor, not a wrapper class: `generate` builds masks ahead
-    of the forward and feeds them back through `create_causal_mask`, masking_utils.py:812-823.)"""
-    key_valid._tamd_kv_len = kv_len
-    return key_valid
+def _mask_kv_len(attention_mask) -> Optional[int]:
+    """Number of key slots a mask produced by `tamd_mask` covers.  For a prefill into a pre-allocated (static) KV cache
+    `tamd_mask` returns a key-validity mask over the slots IN USE only -- shorter than the cache's key/value tensors --
+    and the attention function slices K/V to it, so the kernels' bottom-right causal alignment is the reference's
+    `kv_idx <= q_idx + q_offset`.  The length travels as the mask's own shape (it survives `.to(device)`, slicing of the
+    batch, fake tensors and graph capture; round 2 carried it as a Python attribute on the tensor, which none of those
+    keep)."""
+    if isinstance(attention_mask, TamdMask):
+        attention_mask = attention_mask.key_valid
+    if attention_mask is None or not torch.is_tensor(attention_mask):
+        return None
+    return int(attention_mask.shape[-1])
 
 
 def _closure_vars(fn):
@@ -78,6 +83,12 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
         if (short := kv_length + kv_offset - padding.shape[-1]) > 0:
             padding = torch.nn.functional.pad(padding, (0, short))
         padding = padding[:, kv_offset: kv_offset + kv_length] if padding.shape[-1] != kv_length else padding
+    bidirectional = getattr(mu, "bidirectional_mask_function", None)
+    if mask_function is not None and mask_function is bidirectional:
+        # encoder self-attention and CROSS-attention (create_bidirectional_mask with encoder_hidden_states: q_offset = 0,
+        # kv_length = encoder length != q_length, masking_utils.py:1000-1080): every query sees every valid key; there is
+        # no cache geometry to decode
+        return padding
     kv_len = None
     dynamic = not torch.is_tensor(q_offset) and kv_offset == 0 and kv_length == q_offset + q_length
     if not dynamic:
@@ -100,7 +111,7 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
                        else padding[:, :kv_len].to(torch.bool))
     plain = (None, mu.causal_mask_function, getattr(mu, "bidirectional_mask_function", None))
     if mask_function in plain:
-        return padding if kv_len is None else _with_kv_len(padding, kv_len)
+        return padding  # (a static-cache prefill mask is [B, kv_len]: shorter than the cache, see _mask_kv_len)
     packed_ids = None
     for leaf in _decompose_mask_function(mask_function):
         if leaf in plain:
@@ -113,7 +124,7 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
                         f"sequences; the mask function {getattr(leaf, '__qualname__', leaf)!r} is not one of them "
                         "(sliding-window / chunked / custom overlays need attn_implementation='sdpa' or 'eager')")
     if packed_ids is None:
-        return padding if kv_len is None else _with_kv_len(padding, kv_len)
+        return padding
     if not dynamic or q_offset != 0 or q_length != kv_length:
         raise TamdError("packed sequences with a KV cache are not supported by attn_implementation='tamd'")
     return TamdMask(padding, ops.packed_q_start(packed_ids[:, -q_length:]))
@@ -183,8 +194,8 @@ def tamd_attention_forward(module, query, key, value, attention_mask, dropout: f
     causal = bool(causal) and sq > 1
     # [B,H,S,D] -> [B,S,H,D] views (the projections produced [B,S,H,D]; this undoes the caller's transpose)
     q, k, v = query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2)
-    used = getattr(attention_mask, "_tamd_kv_len", None)
-    if used is not None and used != sk:
+    used = _mask_kv_len(attention_mask)
+    if used is not None and used < sk:
         sk = used  # pre-allocated cache: only the first kv_len key slots are in use (strided views of the cache)
         k, v = k[:, :sk], v[:, :sk]
     key_valid, q_start = split_mask(attention_mask, b, sk)

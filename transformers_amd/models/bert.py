@@ -11,7 +11,7 @@ from transformers.models.bert import modeling_bert as ref
 
 from .. import ops
 from ..fused_params import FusedWeights
-from .common import _gpu
+from .common import _gpu, note_fallback
 
 
 def _no_dropout(mod) -> bool:
@@ -33,6 +33,7 @@ class TamdBertSelfAttention(ref.BertSelfAttention):
         if not (_gpu(hidden_states) and past_key_values is None and d in (64, 128)
                 and hidden_states.dtype in (torch.bfloat16, torch.float16)
                 and self.config._attn_implementation == "tamd" and not kwargs.get("output_attentions", False)):
+            note_fallback(self, hidden_states, "kv_cache" if past_key_values is not None else "unsupported")
             return super().forward(hidden_states, attention_mask=attention_mask, past_key_values=past_key_values,
                                    **kwargs)
         b, s, h = hidden_states.shape
@@ -73,6 +74,7 @@ class TamdBertSelfOutput(_DenseResidualLN, ref.BertSelfOutput):
 
     def forward(self, hidden_states, input_tensor):
         if not self._ok(hidden_states):
+            note_fallback(self, hidden_states)
             return ref.BertSelfOutput.forward(self, hidden_states, input_tensor)
         return self._fast(hidden_states, input_tensor)
 
@@ -82,6 +84,7 @@ class TamdBertOutput(_DenseResidualLN, ref.BertOutput):
 
     def forward(self, hidden_states, input_tensor):
         if not self._ok(hidden_states):
+            note_fallback(self, hidden_states)
             return ref.BertOutput.forward(self, hidden_states, input_tensor)
         return self._fast(hidden_states, input_tensor)
 
@@ -99,6 +102,7 @@ class TamdBertIntermediate(ref.BertIntermediate):
             self._tamd_act = act
         if not (_gpu(hidden_states) and act in ops.ACT_CODES and ops.ACT_CODES[act] != ops.ACT_NONE
                 and hidden_states.dtype in (torch.bfloat16, torch.float16) and self.dense.bias is not None):
+            note_fallback(self, hidden_states)
             return super().forward(hidden_states)
         return ops.linear(hidden_states, self.dense.weight, self.dense.bias, act=ops.ACT_CODES[act])
 
@@ -110,6 +114,7 @@ class TamdBertEmbeddings(ref.BertEmbeddings):
         if not (input_ids is not None and inputs_embeds is None and _gpu(w)
                 and w.shape[1] % 8 == 0 and w.shape[1] <= 4096
                 and w.dtype in (torch.bfloat16, torch.float16, torch.float32)):
+            note_fallback(self, w)
             return super().forward(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
                                    inputs_embeds=inputs_embeds, past_key_values_length=past_key_values_length)
         b, s = input_ids.shape

@@ -10,7 +10,7 @@ from transformers.models.clip import modeling_clip as ref
 
 from .. import ops
 from ..fused_params import FusedWeights
-from .common import _gpu, _has_hooks
+from .common import _gpu, _has_hooks, note_fallback
 
 
 class TamdCLIPAttention(ref.CLIPAttention):
@@ -28,6 +28,7 @@ class TamdCLIPAttention(ref.CLIPAttention):
         if not (_gpu(hidden_states) and d in (64, 128) and hidden_states.dtype in (torch.bfloat16, torch.float16)
                 and self.config._attn_implementation == "tamd"
                 and not kwargs.get("output_attentions", False)):
+            note_fallback(self, hidden_states)
             return super().forward(hidden_states, attention_mask=attention_mask, **kwargs)
         b, s, h = hidden_states.shape
         nh = self.num_heads
@@ -52,6 +53,7 @@ class TamdCLIPMLP(ref.CLIPMLP):
         act = self.config.hidden_act
         if not (_gpu(hidden_states) and isinstance(act, str) and ops.ACT_CODES.get(act, 0) != ops.ACT_NONE
                 and hidden_states.dtype in (torch.bfloat16, torch.float16) and self.fc1.bias is not None):
+            note_fallback(self, hidden_states)
             return super().forward(hidden_states)
         hmid = ops.linear(hidden_states, self.fc1.weight, self.fc1.bias, act=ops.ACT_CODES[act])
         return ops.linear(hmid, self.fc2.weight, self.fc2.bias)
@@ -69,6 +71,9 @@ class TamdCLIPEncoderLayer(ref.CLIPEncoderLayer):
                 and attn.config._attn_implementation == "tamd" and not (self.training and attn.dropout > 0)
                 and isinstance(act, str) and ops.ACT_CODES.get(act, 0) != ops.ACT_NONE
                 and not (_has_hooks(attn, mlp) or kwargs.get("output_attentions", False))):
+            # (the children are replacement classes themselves: this level only loses the epilogue fusions, and a hooked
+            # layer -- LLaVA reads hidden states through hooks on the LAYER, which do not land here -- is by design)
+            note_fallback(self, x, "layer_unfused")
             return super().forward(hidden_states, attention_mask, **kwargs)
         b, s, h = x.shape
         nh, d = attn.num_heads, attn.head_dim

@@ -15,12 +15,37 @@ def _gpu(t: torch.Tensor) -> bool:
     return t.is_cuda or ops.backend_is_emulated()
 
 
+# ---- fallback accounting (VERDICT r2 "no silent fallbacks") ---------------------------------------------------------
+# Every replacement class keeps the reference's own forward for what it does not implement (odd shapes, fp32 modules,
+# cached decode, exotic options).  For CPU tensors that is the contract (BASELINE config 1 runs the reference unchanged);
+# for a GPU tensor it means ATen / vendor kernels are doing work this package claims -- so each such call is counted, by
+# class and reason.  `transformers_amd.fallback_calls()` reads the counters; bench.py prints their sum as
+# "fallback_calls" and the GPU model tests assert it is zero for the BASELINE configurations.
+_FALLBACKS: dict = {}
+
+
+def note_fallback(mod, x, reason: str = "unsupported") -> None:
+    """Record that `mod` is about to serve the GPU tensor `x` through the reference's forward."""
+    if x is not None and torch.is_tensor(x) and _gpu(x):
+        key = f"{type(mod).__name__}:{reason}"
+        _FALLBACKS[key] = _FALLBACKS.get(key, 0) + 1
+
+
+def fallback_calls(reset: bool = False) -> dict:
+    """{"Class:reason": calls} of GPU tensors served by a reference forward since the last reset."""
+    out = dict(_FALLBACKS)
+    if reset:
+        _FALLBACKS.clear()
+    return out
+
+
 class TamdLinear(nn.Linear):
     def forward(self, x):
         w = self.weight
         if (_gpu(x) and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and x.numel() > 0
                 and ops.gemm_supported(x.numel() // x.shape[-1], w.shape[0], w.shape[1], x.dtype)):
             return ops.linear(x, w, self.bias)
+        note_fallback(self, x)
         return super().forward(x)
 
 
@@ -31,6 +56,7 @@ class TamdEmbedding(nn.Embedding):
                 and not self.sparse and not self.scale_grad_by_freq and w.shape[1] % 8 == 0
                 and ids.dtype in (torch.int64, torch.int32)):
             return ops.embedding(ids, w, self.padding_idx)
+        note_fallback(self, w)
         return super().forward(ids)
 
 
@@ -40,6 +66,7 @@ class TamdLayerNorm(nn.LayerNorm):
                 and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and x.shape[-1] % 8 == 0
                 and x.shape[-1] <= 8192 and self.weight.dtype == x.dtype):
             return ops.layernorm(x, self.weight, self.bias, self.eps)
+        note_fallback(self, x)
         return super().forward(x)
 
 

@@ -9,7 +9,7 @@ import torch
 from transformers.pytorch_utils import Conv1D
 
 from .. import ops
-from .common import _gpu
+from .common import _gpu, note_fallback
 
 
 class TamdConv1D(Conv1D):
@@ -18,6 +18,7 @@ class TamdConv1D(Conv1D):
         if (_gpu(x) and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype
                 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0 and x.numel() > 0):
             return ops.conv1d(x, w, self.bias)  # torch.ops.tamd.conv1d
+        note_fallback(self, x)
         return super().forward(x)
 
 

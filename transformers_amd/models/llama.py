@@ -21,7 +21,7 @@ from .. import layer_ops, ops
 from ..fused_params import FusedWeights
 
 
-from .common import _has_hooks  # noqa: E402
+from .common import _has_hooks, note_fallback  # noqa: E402
 
 
 def _on_gpu(t: torch.Tensor) -> bool:
@@ -33,7 +33,7 @@ class TamdLlamaRMSNorm(ref.LlamaRMSNorm):
 
     def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
         if not _on_gpu(hidden_states):
-            return super().forward(hidden_states)
+            return super().forward(hidden_states)  # (CPU tensors: the reference's own path, by contract)
         return ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
 
 
@@ -52,6 +52,7 @@ class TamdLlamaMLP(ref.LlamaMLP):
         if (not _on_gpu(x) or self.config.hidden_act not in ("silu", "swish") or self.gate_proj.bias is not None
                 or self.down_proj.bias is not None or x.dtype not in (torch.bfloat16, torch.float16)
                 or w.dtype != x.dtype or w.shape[0] % 8 or w.shape[1] % 8):
+            note_fallback(self, x)
             return super().forward(x)
         gu = self._fused().linear(x)
         act = ops.swiglu(gu)
@@ -75,6 +76,9 @@ class TamdLlamaAttention(ref.LlamaAttention):
 
     def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
         if not self._fast_ok(hidden_states, past_key_values):
+            # cached decode: the reference module (projections through the TamdLinear children, cache update) around the
+            # registered attention function -- by design, counted under its own reason
+            note_fallback(self, hidden_states, "kv_cache" if past_key_values is not None else "unsupported")
             return super().forward(hidden_states, position_embeddings=position_embeddings,
                                    attention_mask=attention_mask, past_key_values=past_key_values, **kwargs)
         b, s, _ = hidden_states.shape
@@ -110,6 +114,8 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                 position_embeddings=None, **kwargs):
         if not self._fused_ok(hidden_states, past_key_values):
+            # (the children are replacement classes: this level only loses the epilogue fusions)
+            note_fallback(self, hidden_states, "kv_cache" if past_key_values is not None else "layer_unfused")
             return super().forward(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                    past_key_values=past_key_values, use_cache=use_cache,
                                    position_embeddings=position_embeddings, **kwargs)
@@ -140,6 +146,8 @@ def fused_causal_lm_forward(self, input_ids=None, attention_mask=None, position_
              and w.shape[1] % 8 == 0 and w.dtype in (torch.bfloat16, torch.float16) and _on_gpu(w)
              and isinstance(logits_to_keep, int) and logits_to_keep == 0)
     if not fused:
+        if labels is not None and self.training:
+            note_fallback(self, w, "lm_head_loss_unfused")
         return type(self).forward(self, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
                                   past_key_values=past_key_values, inputs_embeds=inputs_embeds, labels=labels,
                                   use_cache=use_cache, logits_to_keep=logits_to_keep, **kwargs)

@@ -490,13 +490,25 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
     # a residual epilogue on a tile grid that cannot fill the GPU (o_proj / down_proj of a short prompt: 80 tiles on 256
     # CUs): the residual goes into C first and the product is accumulated onto it, which split-K can do -- the same
     # roundings, round(round(acc) + R), for the price of copying a small C
-    if (epilogue == EPI_RESIDUAL and bias is None and sched is None and residual is not None
-            and residual.shape == out.shape and gemm_workspace_bytes(m, n, k_a, EPI_ACCUM)):
-        out.copy_(residual)
-        residual, epilogue = None, EPI_ACCUM
+    ws_bytes = 0
+    if residual is not None:
+        # the kernel reads R as the output's element type through 16-byte accesses: checked here because the rewrite
+        # below takes R out of the C call (whose own checks would otherwise catch a stray dtype / stride / alignment)
+        if residual.dtype != out.dtype:
+            raise TamdError(f"gemm residual dtype {residual.dtype} != output dtype {out.dtype}")
+        if residual.dim() != 2 or residual.stride(1) != 1 or residual.stride(0) % 8 or residual.data_ptr() % 16:
+            raise TamdError("gemm residual must be a 2-D row-major view with a 16-byte aligned base and a row stride "
+                            "that is a multiple of 8 elements")
+    if sched is None:  # (one evaluation of the split-K policy per GEMM: this path is host-bound for small models)
+        if epilogue == EPI_RESIDUAL and bias is None and residual is not None and residual.shape == out.shape:
+            ws_bytes = gemm_workspace_bytes(m, n, k_a, EPI_ACCUM)
+            if ws_bytes:
+                out.copy_(residual)
+                residual, epilogue = None, EPI_ACCUM
+        else:
+            ws_bytes = gemm_workspace_bytes(m, n, k_a, epilogue)
     ldr = residual.stride(0) if residual is not None else 0
     # split-K for tile grids that cannot fill the GPU (weight gradients of narrow layers): needs an fp32 workspace
-    ws_bytes = gemm_workspace_bytes(m, n, k_a, epilogue) if sched is None else 0
     if ws_bytes:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
         be.lib.check(be.lib.tamd_gemm_ws(_p(a), _p(b), _p(out), _p(bias), _p(residual), m, n, k_a, a.stride(0),
