@@ -188,7 +188,10 @@ int tamd_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_
 int tamd_cross_entropy_fwd(const void* logits, const int64_t* labels, float* lse, float* row_loss, int64_t tokens,
                            int64_t vocab, int64_t ld, int64_t ignore_index, int dtype, tamd_stream_t stream);
 /* dlogits[t,j] = (exp(logits[t,j]-lse[t]) - [j==label[t]]) * (*gscale)   (0 for ignored rows);
- * gscale: device fp32 scalar = upstream grad / normaliser. */
+ * gscale: device fp32 scalar = upstream grad / normaliser.
+ * dlogits is a [tokens, ld] buffer (the row stride of `logits`): columns vocab .. ld-1 of every row are row padding and
+ * are set to ZERO, so that the buffer is a valid zero-padded operand of the following dX / dW GEMMs when vocab is not a
+ * multiple of 8 (bert-base: vocab 30522 in rows of 30528; models/bert/modeling_bert.py:466-497). */
 int tamd_cross_entropy_bwd(const void* logits, const int64_t* labels, const float* lse, const float* gscale,
                            void* dlogits, int64_t tokens, int64_t vocab, int64_t ld, int64_t ignore_index,
                            int dtype, tamd_stream_t stream);

@@ -294,7 +294,10 @@ def _grad_parity(fast, ref, ref32, skip=()):
             continue
         assert p.grad is not None, n
         ef, er = rel_err(p.grad, g32[n].grad), rel_err(gref[n].grad, g32[n].grad)
-        assert ef <= 1.6 * er + 3e-3, (n, ef, er)
+        record("grad_parity:" + type(fast).__name__, n, ef, er)
+        # noise-floor gate: ours <= 1.25x the reference's own bf16 error + 2e-3 (the additive term
+        # covers parameters whose reference error is ~0: biases summed in fp32 by both); measured worst ratio 1.07
+        assert ef <= 1.25 * er + 2e-3, (n, ef, er)
 
 
 @pytest.mark.parametrize("padding_side", ["right", "left"])
@@ -305,7 +308,8 @@ def test_bert_masked_lm_parity(env, padding_side):
 
     torch.manual_seed(3)
     big = env.big
-    cfg = BertConfig(vocab_size=1000 if big else 200, hidden_size=768 if big else 128,
+    # vocab % 8 == 2 like bert-base's 30522: the tied decoder runs on zero-padded rows (fused_params.PaddedRows)
+    cfg = BertConfig(vocab_size=1002 if big else 202, hidden_size=768 if big else 128,
                      num_hidden_layers=2, num_attention_heads=12 if big else 2,
                      intermediate_size=3072 if big else 256, max_position_embeddings=512 if big else 64,
                      attn_implementation="eager", hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
@@ -330,8 +334,14 @@ def test_bert_masked_lm_parity(env, padding_side):
     transformers_amd.accelerate(fast)
     assert type(fast.bert.embeddings).__name__ == "TamdBertEmbeddings"
     dev = env.device
+    transformers_amd.fallback_calls(reset=True)
     o = fast(input_ids=ids.to(dev), attention_mask=am.to(dev), labels=labels.to(dev))
     o.loss.backward()
+    assert transformers_amd.fallback_calls() == {}, transformers_amd.fallback_calls()  # nothing served by ATen modules
+    assert o.logits.shape == o32.logits.shape and o.logits.stride(-2) % 64 == 0  # the [.., V] view of padded rows
+    e_fast, e_ref = abs(o.loss.item() - o32.loss.item()), abs(o_ref.loss.item() - o32.loss.item())
+    record("bert_model", f"{padding_side}:loss_abs", e_fast, e_ref)
+    assert e_fast <= 1.1 * e_ref + 2e-3 * abs(o32.loss.item()), (e_fast, e_ref)
     v = am.bool()
     e_fast, e_ref = rel_err(o.logits[v.to(dev)], o32.logits[v]), rel_err(o_ref.logits[v], o32.logits[v])
     assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)

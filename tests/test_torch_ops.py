@@ -44,7 +44,7 @@ def test_namespace_is_complete():
                     "gemm_out", "attn_fwd", "attn_bwd"]
     differentiable = ["rmsnorm", "add_rmsnorm", "layernorm", "add_layernorm", "linear", "fused_linear", "conv1d", "rope",
                       "attention", "swiglu", "bias_act", "embedding", "bert_embeddings", "cross_entropy_sum",
-                      "linear_cross_entropy", "llama_layer"]
+                      "linear_cross_entropy", "llama_layer", "padded_vocab_head"]
     for name in kernel_level + differentiable:
         op = getattr(T, name).default
         assert torch._C._dispatch_has_kernel_for_dispatch_key(op.name(), "CUDA"), name
@@ -94,6 +94,14 @@ def test_opcheck_differentiable_ops(env):
     opcheck(T.embedding, (ids, _bf(50, 64, dev=dev, grad=True), -1), test_utils=CHECKS)
     logits = _bf(12, 200, dev=dev, grad=True)
     opcheck(T.cross_entropy_sum, (logits, torch.randint(0, 200, (12,)).to(dev), -100), test_utils=CHECKS)
+    # the padded vocabulary head (an output that is a row-strided view of an internal [M, Vp] buffer)
+    wp = torch.zeros(256, 128, dtype=torch.bfloat16, device=dev)
+    wp[:202] = _bf(202, 128, dev=dev, scale=0.05)
+    bp = torch.zeros(256, dtype=torch.bfloat16, device=dev)
+    wv, bv = wp[:202].detach().requires_grad_(True), bp[:202].detach().requires_grad_(True)
+    hh = _bf(24, 128, dev=dev, grad=True)
+    opcheck(T.padded_vocab_head, (hh, wp, bp, wv, bv, torch.randint(0, 202, (24,)).to(dev), -100, True), test_utils=CHECKS)
+    opcheck(T.padded_vocab_head, (hh, wp, bp, wv, bv, None, -100, True), test_utils=CHECKS)
     # in-place kernel-level op: the schema declares the mutation
     opcheck(T.rope_, (qkv.detach().clone().view(80, 384), cos, sin, 40, 5, 64), test_utils=("test_schema",))
 
@@ -192,3 +200,47 @@ def test_llama_layer_saved_swiglu_product_matches_rematerialised(env, monkeypatc
         grads.append({n: p.grad.clone() for n, p in m.named_parameters()})
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+def test_padded_vocab_head_matches_fp32_autograd(env):
+    """BERT's MLM head at a vocabulary that is not a multiple of 8 (modeling_bert.py:483-496, 970-975): scores, loss and
+    the gradients of hidden / tied weight / bias against torch autograd in fp32 -- through the loss, through a custom
+    function of the scores, and through both at once."""
+    from transformers_amd.fused_params import PaddedRows
+
+    dev = env.device
+    torch.manual_seed(7)
+    m, k, v = (1024, 768, 30522) if env.big else (40, 128, 203)
+    lin = torch.nn.Linear(k, v).to(torch.bfloat16).to(dev)
+    with torch.no_grad():
+        lin.bias.normal_(0, 0.5)
+    pr = PaddedRows(lin)
+    w_pad, b_pad = pr.buffers()
+    assert w_pad.shape[0] % 64 == 0 and lin.weight.data_ptr() == w_pad.data_ptr() and lin.weight.shape == (v, k)
+    assert not w_pad[v:].any() and not b_pad[v:].any()
+    h = _bf(2, m // 2, k, dev=dev, grad=True)
+    labels = torch.randint(0, v, (2, m // 2))
+    labels[0, ::3] = -100
+    gl = (torch.randn(2, m // 2, v) * 1e-3).bfloat16()
+    hr, wr, br = (a.detach().float().cpu().requires_grad_(True) for a in (h, lin.weight, lin.bias))
+    for use_loss, use_scores in ((True, False), (False, True), (True, True)):
+        for t in (h, lin.weight, lin.bias, hr, wr, br):
+            t.grad = None
+        loss, scores = ops.padded_vocab_head(h, w_pad, b_pad, lin.weight, lin.bias, labels.to(dev) if use_loss else None)
+        sr = torch.nn.functional.linear(hr, wr, br)
+        assert scores.shape == (2, m // 2, v) and rel_err(scores, sr) < 4e-3
+        obj, objr = 0.0, 0.0
+        if use_loss:
+            lr_ = torch.nn.functional.cross_entropy(sr.view(-1, v), labels.view(-1))
+            assert abs(loss.item() - lr_.item()) < 2e-3 * abs(lr_.item())
+            obj, objr = obj + loss * 3, objr + lr_ * 3
+        else:
+            assert loss is None
+        if use_scores:
+            obj, objr = obj + (scores.float() * gl.to(dev).float()).sum(), objr + (sr * gl.float()).sum()
+        obj.backward()
+        objr.backward()
+        for a, r in ((h, hr), (lin.weight, wr), (lin.bias, br)):
+            assert a.grad.shape == r.grad.shape and rel_err(a.grad, r.grad) < 8e-3
+    # the parameters are still views of the padded buffers, whose padding stayed zero
+    assert pr._coherent() and not w_pad[v:].any() and not b_pad[v:].any()

@@ -528,6 +528,8 @@ __global__ __launch_bounds__(kCEThreads) void cross_entropy_bwd_kernel(const T* 
     const float v = elem<T>::to_f32(reinterpret_cast<const raw*>(lr)[i]);
     reinterpret_cast<raw*>(dr)[i] = elem<T>::from_f32((__expf(v - l) - (i == lab ? 1.f : 0.f)) * g);
   }
+  // row padding (include/tamd.h: dlogits is [tokens, ld]): zero, so the buffer is a valid K-padded GEMM operand
+  for (int64_t i = vocab + threadIdx.x; i < ld; i += kCEThreads) reinterpret_cast<raw*>(dr)[i] = elem<T>::from_f32(0.f);
 }
 
 static unsigned stream_grid(int64_t work_items, int threads) {

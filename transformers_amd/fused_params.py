@@ -80,3 +80,45 @@ class FusedWeights:
         if self.has_bias:
             members += [lin.bias for lin in self.linears]
         return ops.fused_linear(x, wf, self.bias(), members)
+
+
+class PaddedRows:
+    """An nn.Linear whose out_features is not a multiple of 8 (BERT's MLM decoder: 30522 x 768, tied to the word
+    embeddings; models/bert/modeling_bert.py:490) kept in row-PADDED storage: weight.data / bias.data become views of the
+    first `n` rows of zero-padded buffers [n_pad, in] / [n_pad] (n_pad = n rounded up to 64), so the MFMA GEMM's 16-byte
+    row stores and the K-padded backward GEMMs run on whole rows.  Same invariants as FusedWeights: parameter identity,
+    shape, names, tying and state_dict are untouched; optimizers / load_state_dict / DDP broadcast write through."""
+
+    ALIGN = 64
+
+    def __init__(self, linear: nn.Linear):
+        self.linear = linear
+        self._w: Optional[torch.Tensor] = None
+        self._b: Optional[torch.Tensor] = None
+
+    def _coherent(self) -> bool:
+        w, b = self.linear.weight, self.linear.bias
+        if self._w is None or self._w.device != w.device or self._w.dtype != w.dtype:
+            return False
+        if w.data_ptr() != self._w.data_ptr() or not w.is_contiguous():
+            return False
+        return b is None or (self._b is not None and b.data_ptr() == self._b.data_ptr())
+
+    @torch.no_grad()
+    def repad(self) -> None:
+        w, b = self.linear.weight, self.linear.bias
+        n, k = w.shape
+        n_pad = -(-n // self.ALIGN) * self.ALIGN
+        self._w = torch.zeros(n_pad, k, dtype=w.dtype, device=w.device)
+        self._w[:n].copy_(w.data)
+        w.data = self._w[:n]
+        if b is not None:
+            self._b = torch.zeros(n_pad, dtype=b.dtype, device=b.device)
+            self._b[:n].copy_(b.data)
+            b.data = self._b[:n]
+
+    def buffers(self):
+        """-> (w_pad [n_pad, in], b_pad [n_pad] or None), re-established if the parameters were moved or re-assigned."""
+        if not self._coherent():
+            self.repad()
+        return self._w, (self._b if self.linear.bias is not None else None)

@@ -1,8 +1,10 @@
 """MI355X execution path for the BERT encoder blocks (src/transformers/models/bert/modeling_bert.py).
 
 Post-LN blocks with biases: `LayerNorm(dropout(dense(x)) + residual)`.  With dropout inactive (eval mode or p = 0)
-the residual add rides in the GEMM epilogue; in train mode with hidden dropout the GEMM keeps the bias, torch's dropout
-runs on its output, and the residual add joins the LayerNorm kernel.
+the residual add rides in the GEMM epilogue; in train mode with hidden dropout the GEMM keeps the bias and one kernel
+draws the dropout mask, adds the residual and normalises (`ops.dropout_add_layernorm`).  The masked-LM head (transform +
+a 30522-wide tied decoder + CrossEntropyLoss) runs on the same GEMM through zero-padded weight rows and on the
+cross-entropy kernels (`TamdBertLMPredictionHead`, `masked_lm_forward`).
 """
 from __future__ import annotations
 
@@ -10,7 +12,7 @@ import torch
 from transformers.models.bert import modeling_bert as ref
 
 from .. import ops
-from ..fused_params import FusedWeights
+from ..fused_params import FusedWeights, PaddedRows
 from .common import _gpu, note_fallback
 
 
@@ -93,13 +95,7 @@ class TamdBertIntermediate(ref.BertIntermediate):
     """dense + GELU, modeling_bert.py:334-337: bias and activation live in the GEMM epilogue."""
 
     def forward(self, hidden_states):
-        act = getattr(self, "_tamd_act", None)
-        if act is None:  # BertIntermediate keeps only the callable: recover its name from ACT2FN
-            from transformers.activations import ACT2FN
-            fn = self.intermediate_act_fn
-            act = next((k for k in ("gelu", "gelu_new", "quick_gelu", "silu", "gelu_pytorch_tanh")
-                        if type(ACT2FN[k]) is type(fn)), "")
-            self._tamd_act = act
+        act = _act_name(self, "_tamd_act", self.intermediate_act_fn)
         if not (_gpu(hidden_states) and act in ops.ACT_CODES and ops.ACT_CODES[act] != ops.ACT_NONE
                 and hidden_states.dtype in (torch.bfloat16, torch.float16) and self.dense.bias is not None):
             note_fallback(self, hidden_states)
@@ -130,7 +126,95 @@ class TamdBertEmbeddings(ref.BertEmbeddings):
         return out if _no_dropout(self) else torch.nn.functional.dropout(out, self.dropout.p, True)
 
 
+def _act_name(mod, attr: str, fn) -> str:
+    """The reference modules keep only the activation callable: recover its ACT2FN name (cached on the module)."""
+    act = mod.__dict__.get(attr)
+    if act is None:
+        from transformers.activations import ACT2FN
+
+        act = next((k for k in ("gelu", "gelu_new", "quick_gelu", "silu", "gelu_pytorch_tanh")
+                    if type(ACT2FN[k]) is type(fn)), "")
+        mod.__dict__[attr] = act
+    return act
+
+
+class TamdBertPredictionHeadTransform(ref.BertPredictionHeadTransform):
+    """dense -> activation -> LayerNorm, modeling_bert.py:466-480: bias + activation in the GEMM epilogue."""
+
+    def forward(self, hidden_states):
+        act = _act_name(self, "_tamd_act", self.transform_act_fn)
+        if not (_gpu(hidden_states) and ops.ACT_CODES.get(act, ops.ACT_NONE) != ops.ACT_NONE
+                and hidden_states.dtype in (torch.bfloat16, torch.float16) and self.dense.bias is not None
+                and self.dense.weight.dtype == hidden_states.dtype):
+            note_fallback(self, hidden_states)
+            return super().forward(hidden_states)
+        y = ops.linear(hidden_states, self.dense.weight, self.dense.bias, act=ops.ACT_CODES[act])
+        return ops.layernorm(y, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps)
+
+
+class TamdBertLMPredictionHead(ref.BertLMPredictionHead):
+    """transform -> decoder, modeling_bert.py:483-496.  The decoder is [vocab, hidden] tied to the word embeddings with
+    vocab = 30522 for bert-base: not a multiple of 8, so it lives in zero-padded rows (fused_params.PaddedRows) and the
+    scores come back as the [.., vocab] view of a [.., vocab_pad] buffer."""
+
+    def _padded(self) -> PaddedRows:
+        pr = self.__dict__.get("_tamd_padded")
+        if pr is None or pr.linear is not self.decoder:
+            pr = PaddedRows(self.decoder)
+            self.__dict__["_tamd_padded"] = pr
+        return pr
+
+    def _fast_ok(self, h) -> bool:
+        w = self.decoder.weight
+        return (_gpu(h) and h.dtype in (torch.bfloat16, torch.float16) and w.dtype == h.dtype and w.shape[1] % 8 == 0
+                and h.numel() > 0)
+
+    def scores_and_loss(self, hidden_states, labels=None):
+        """-> (masked-LM loss or None, prediction scores): `CrossEntropyLoss()` of modeling_bert.py:973-975 on the
+        cross-entropy kernels (fp32 in registers) when labels are given."""
+        h = self.transform(hidden_states)
+        w_pad, b_pad = self._padded().buffers()
+        return ops.padded_vocab_head(h, w_pad, b_pad, self.decoder.weight, self.decoder.bias, labels)
+
+    def forward(self, hidden_states):
+        if not self._fast_ok(hidden_states):
+            note_fallback(self, hidden_states)
+            return super().forward(hidden_states)
+        return self.scores_and_loss(hidden_states)[1]
+
+
+def masked_lm_forward(self, input_ids=None, attention_mask=None, token_type_ids=None, position_ids=None,
+                      inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None, labels=None, **kwargs):
+    """BertForMaskedLM.forward (modeling_bert.py:939-982) with the loss on the cross-entropy kernels.  Installed on the
+    INSTANCE by `accelerate` (the class, `config.architectures` and the reference's registries stay untouched; `revert`
+    removes it).  Same outputs as the reference: the loss AND the full prediction scores."""
+    head = self.cls.predictions
+    if labels is None or not isinstance(head, TamdBertLMPredictionHead):
+        return type(self).forward(self, input_ids=input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids,
+                                  position_ids=position_ids, inputs_embeds=inputs_embeds,
+                                  encoder_hidden_states=encoder_hidden_states,
+                                  encoder_attention_mask=encoder_attention_mask, labels=labels, **kwargs)
+    from transformers.modeling_outputs import MaskedLMOutput
+
+    return_dict = kwargs.pop("return_dict", None)
+    outputs = self.bert(input_ids, attention_mask=attention_mask, token_type_ids=token_type_ids,
+                        position_ids=position_ids, inputs_embeds=inputs_embeds,
+                        encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
+                        return_dict=True, **kwargs)
+    sequence_output = outputs[0]
+    if not head._fast_ok(sequence_output):
+        note_fallback(self, sequence_output, "mlm_loss")
+        scores = self.cls(sequence_output)
+        loss = torch.nn.functional.cross_entropy(scores.view(-1, self.config.vocab_size), labels.view(-1))
+    else:
+        loss, scores = head.scores_and_loss(sequence_output, labels)
+    out = MaskedLMOutput(loss=loss, logits=scores, hidden_states=outputs.hidden_states, attentions=outputs.attentions)
+    return out.to_tuple() if return_dict is False else out
+
+
 REPLACEMENTS = {
+    ref.BertPredictionHeadTransform: TamdBertPredictionHeadTransform,
+    ref.BertLMPredictionHead: TamdBertLMPredictionHead,
     ref.BertSelfAttention: TamdBertSelfAttention,
     ref.BertSelfOutput: TamdBertSelfOutput,
     ref.BertOutput: TamdBertOutput,

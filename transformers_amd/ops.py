@@ -433,14 +433,19 @@ def raw_cross_entropy_fwd(logits2d, labels, ignore_index=-100):
 
 
 @_device_guard
-def raw_cross_entropy_bwd(logits2d, labels, lse, gscale, ignore_index=-100):
+def raw_cross_entropy_bwd(logits2d, labels, lse, gscale, ignore_index=-100, padded=False):
+    """-> dlogits [t, v], a view of a fresh [t, ld] buffer (ld = the row stride of logits2d) whose padding columns
+    v .. ld-1 the kernel zeroes; `padded=True` returns that whole buffer (a K-padded GEMM operand)."""
     be = _prep(logits2d, labels, lse, gscale)
     t, v = logits2d.shape
-    dlogits = torch.empty_like(logits2d)
-    be.lib.check(be.lib.tamd_cross_entropy_bwd(_p(logits2d), _p(labels), _p(lse), _p(gscale), _p(dlogits), t, v,
-                                               logits2d.stride(0), ignore_index, _code(logits2d),
+    ld = logits2d.stride(0)
+    if logits2d.stride(1) != 1 or ld < v:
+        raise TamdError("cross_entropy_bwd needs row-major logits")
+    buf = torch.empty(t, ld, dtype=logits2d.dtype, device=logits2d.device)
+    be.lib.check(be.lib.tamd_cross_entropy_bwd(_p(logits2d), _p(labels), _p(lse), _p(gscale), _p(buf), t, v,
+                                               ld, ignore_index, _code(logits2d),
                                                be.stream(logits2d)), "tamd_cross_entropy_bwd")
-    return dlogits
+    return buf if (padded or ld == v) else buf[:, :v]
 
 
 def gemm_supported(m, n, k, dtype) -> bool:
@@ -829,7 +834,10 @@ define_op("cross_entropy_fwd(Tensor logits2d, Tensor labels, int ignore_index=-1
           lambda logits2d, labels, ignore_index=-100: (_f32(logits2d, logits2d.shape[0]),
                                                        _f32(logits2d, logits2d.shape[0])))
 define_op("cross_entropy_bwd(Tensor logits2d, Tensor labels, Tensor lse, Tensor gscale, int ignore_index=-100) -> Tensor",
-          raw_cross_entropy_bwd, lambda logits2d, labels, lse, gscale, ignore_index=-100: torch.empty_like(logits2d))
+          lambda logits2d, labels, lse, gscale, ignore_index=-100: raw_cross_entropy_bwd(logits2d, labels, lse, gscale,
+                                                                                         ignore_index),
+          lambda logits2d, labels, lse, gscale, ignore_index=-100: torch.empty_strided(
+              logits2d.shape, (logits2d.stride(0), 1), dtype=logits2d.dtype, device=logits2d.device))
 
 
 def _adamw_impl(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
@@ -1386,6 +1394,66 @@ define_op("linear_cross_entropy(Tensor h2d, Tensor w, Tensor labels, Tensor norm
           _linear_cross_entropy_backward, _linear_cross_entropy_setup)
 
 
+# Vocabulary projection whose width is not a multiple of 8 (+ optional token-level cross-entropy): BERT's MLM head,
+# `self.decoder(hidden)` then `CrossEntropyLoss()(scores.view(-1, V), labels.view(-1))` (models/bert/modeling_bert.py:
+# 483-496, 970-975; bert-base: V = 30522).  The GEMM stores 16-byte row segments, so the weight / bias live in buffers
+# padded with ZERO rows to Vp = a multiple of 64 (fused_params.PaddedRows: the tied parameters are row-slice views of them),
+# the logits are computed as [M, Vp] and handed out as the [M, V] view of that buffer (row stride Vp), and the backward runs
+# the dX / dW GEMMs on the K-padded gradient buffer the loss kernel writes (padding columns zero).
+#   -> (loss_sum fp32 scalar: SUM of the per-token losses, 0 when labels is None; logits [M, V] (strided); lse [M] fp32)
+def _padded_vocab_head_impl(h2d, w_pad, b_pad, w, b, labels, ignore_index, train):
+    n = w.shape[0]
+    logits_pad = raw_gemm(h2d, w_pad, bias=b_pad, epilogue=EPI_BIAS if b_pad is not None else EPI_NONE)
+    logits = logits_pad[:, :n] if n != w_pad.shape[0] else logits_pad
+    if labels is None:
+        return torch.zeros((), dtype=torch.float32, device=h2d.device), logits, _f32(h2d, 0)
+    lse, row_loss = raw_cross_entropy_fwd(logits, labels, ignore_index)
+    return row_loss.sum(), logits, lse
+
+
+def _padded_vocab_head_fake(h2d, w_pad, b_pad, w, b, labels, ignore_index, train):
+    m, vp = h2d.shape[0], w_pad.shape[0]
+    logits = torch.empty_strided((m, w.shape[0]), (vp, 1), dtype=h2d.dtype, device=h2d.device)
+    return _f32(h2d), logits, _f32(h2d, m if labels is not None else 0)
+
+
+def _padded_vocab_head_setup(ctx, inputs, output):
+    h2d, w_pad, _b_pad, _w, b, labels, ignore_index, _train = inputs
+    ctx.save_for_backward(h2d, w_pad, labels, output[1], output[2])
+    ctx.has_bias, ctx.ignore_index = b is not None, ignore_index
+    ctx.set_materialize_grads(False)
+
+
+def _padded_vocab_head_backward(ctx, g_loss, g_logits, _dlse):
+    none = (None,) * 8
+    if g_loss is None and g_logits is None:
+        return none
+    h2d, w_pad, labels, logits, lse = ctx.saved_tensors
+    m, n = logits.shape
+    vp = w_pad.shape[0]
+    dlog = None
+    if g_loss is not None and labels is not None:
+        gs = g_loss.detach().to(torch.float32).reshape(1).contiguous()
+        dlog = raw_cross_entropy_bwd(logits, labels, lse, gs, ctx.ignore_index, padded=True)  # [M, Vp], padding zero
+    if g_logits is not None:  # the scores themselves were differentiated (a custom loss on `logits`): generic path
+        if dlog is None:
+            dlog = torch.zeros(m, vp, dtype=logits.dtype, device=logits.device)
+        dlog[:, :n] += g_logits
+    dh = dw = db = None
+    if ctx.needs_input_grad[0]:
+        dh = raw_gemm(dlog, w_pad, b_kn=True)                            # dX = dY . W        (K = Vp, padded with zeros)
+    if ctx.needs_input_grad[3]:
+        dw = raw_gemm(dlog, h2d, a_km=True, b_kn=True)[:n]               # dW = dY^T . X      (rows V .. Vp-1 dropped)
+    if ctx.has_bias and ctx.needs_input_grad[4]:
+        db = raw_colsum(dlog)[:n]
+    return (dh, None, None, dw, db) + none[5:]
+
+
+define_op("padded_vocab_head(Tensor h2d, Tensor w_pad, Tensor? b_pad, Tensor w, Tensor? b, Tensor? labels, "
+          "int ignore_index, bool train) -> (Tensor, Tensor, Tensor)", _padded_vocab_head_impl, _padded_vocab_head_fake,
+          _padded_vocab_head_backward, _padded_vocab_head_setup)
+
+
 # --------------------------------------------------------------------------- Python-level wrappers
 def rmsnorm(x, w, eps, residual=None):
     """-> y  (or (y, h) with h = x + residual when a residual is given)."""
@@ -1531,6 +1599,20 @@ def fused_linear_cross_entropy(hidden, weight, labels, num_items_in_batch=None, 
     grad = torch.is_grad_enabled()
     return T.linear_cross_entropy(h2d, weight, labels, norm, int(ignore_index), int(chunk_tokens),
                                   grad and hidden.requires_grad, grad and weight.requires_grad)[0]
+
+
+def padded_vocab_head(hidden, w_pad, b_pad, w, b, labels=None, ignore_index=-100):
+    """`hidden @ w.T + b` for a vocabulary width that is not a multiple of 8, through zero-padded weight / bias buffers
+    (fused_params.PaddedRows), with the token-level cross-entropy of `labels` (mean over the labels != ignore_index, what
+    `CrossEntropyLoss()` computes) when labels are given.  -> (loss or None, logits [..., V])"""
+    h2d = _c(hidden).view(-1, hidden.shape[-1])
+    lab = None if labels is None else labels.reshape(-1).to(hidden.device).contiguous()
+    loss_sum, logits, _ = T.padded_vocab_head(h2d, w_pad, b_pad, w, b, lab, int(ignore_index),
+                                              _wants_grad(hidden, w, b))
+    out = logits.view(*hidden.shape[:-1], w.shape[0])  # (splitting the leading dimension of a row-strided matrix is a view)
+    if lab is None:
+        return None, out
+    return loss_sum / (lab != ignore_index).sum(), out
 
 
 def bert_embeddings(input_ids, token_type_ids, position_ids, word, typ, pos, ln_w, ln_b, eps, padding_idx=None):

@@ -57,6 +57,14 @@ def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bo
         if not isinstance(model, LlamaForCausalLM):
             raise TypeError("fused_lm_head_loss=True is implemented for LlamaForCausalLM")
         model.forward = types.MethodType(fused_causal_lm_forward, model)  # instance attribute: the class is untouched
+    from transformers.models.bert.modeling_bert import BertForMaskedLM
+
+    if isinstance(model, BertForMaskedLM) and fuse_loss:
+        import types
+
+        from .models.bert import masked_lm_forward
+
+        model.forward = types.MethodType(masked_lm_forward, model)  # instance attribute, like the fused Llama forward
     if attn_implementation and hasattr(model, "set_attn_implementation"):
         dtypes = {p.dtype for p in model.parameters() if p.is_floating_point()}
         if dtypes and not dtypes & {torch.bfloat16, torch.float16}:
@@ -73,6 +81,9 @@ def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bo
         fuse = getattr(m, "_fused", None)
         if callable(fuse) and all(p.is_cuda for p in m.parameters(recurse=True)):
             fuse().weight()
+        pad = getattr(m, "_padded", None)
+        if callable(pad) and all(p.is_cuda for p in m.parameters(recurse=True)):
+            pad().buffers()
     if fuse_loss and getattr(model, "loss_type", None) == "ForCausalLM":
         from .ops import causal_lm_loss
 
