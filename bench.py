@@ -138,8 +138,8 @@ class GemmTimer:
 
         # every caller (the torch.ops implementations in ops.py / layer_ops.py) looks `raw_gemm` up at call time
         ops.raw_gemm = timed_gemm
-        # the two GEMMs with the SwiGLU product / its backward in the epilogue (same kernel, own entry points)
-        inner_sw, inner_swb = ops.raw_gemm_swiglu, ops.raw_gemm_swiglu_bwd
+        # the gate|up GEMM with the SwiGLU product in its epilogue (same kernel, own entry point)
+        inner_sw = ops.raw_gemm_swiglu
 
         def timed_swiglu(x2, wgu, need_gu=True):
             if not timer.enabled:
@@ -152,18 +152,7 @@ class GemmTimer:
             timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n * (1.5 if need_gu else 0.5))))
             return out
 
-        def timed_swiglu_bwd(dy2, wd, gu):
-            if not timer.enabled:
-                return inner_swb(dy2, wd, gu)
-            (m, k), n = dy2.shape, wd.shape[1]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = inner_swb(dy2, wd, gu)
-            e.record()
-            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + 5 * m * n), "swiglu_bwd"))  # reads gate|up, writes d_gate|d_up, act
-            return out
-
-        ops.raw_gemm_swiglu, ops.raw_gemm_swiglu_bwd = timed_swiglu, timed_swiglu_bwd
+        ops.raw_gemm_swiglu = timed_swiglu
         inner_rope = getattr(ops, "raw_gemm_rope", None)
 
         def timed_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 5
+#define TAMD_ABI_VERSION 6
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -204,7 +204,12 @@ enum tamd_gemm_flags {
   /* diagnostic schedule hints (A/B measurements, tests); 0 = library default (full-line kernel when K % 64 == 0,
    * else ping-pong).  A hint that does not apply to K is ignored. */
   TAMD_GEMM_SCHED_PP = 1 << 8, /* 8-wave ping-pong kernel, 32-deep stages (every layout, any K)                */
-  TAMD_GEMM_SCHED_FL = 3 << 8  /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
+  TAMD_GEMM_SCHED_FL = 3 << 8, /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
+  /* the full-line kernel as one persistent workgroup per CU whose XCD groups start every dispatch round together
+   * (plain / accumulate epilogues and split-K; other calls ignore the hint), _SYNC: and re-align every 64 stages
+   * inside a tile.  Same results as TAMD_GEMM_SCHED_FL bit for bit. */
+  TAMD_GEMM_SCHED_FL_PERSIST = 4 << 8,
+  TAMD_GEMM_SCHED_FL_PERSIST_SYNC = 5 << 8
 };
 enum tamd_gemm_epilogue {
   TAMD_EPI_NONE = 0,
@@ -240,14 +245,6 @@ int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const 
  * GU may be NULL (inference: the projection outputs are never written to HBM).  K % 64 == 0, I % 8 == 0. */
 int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* ACT, int64_t M, int64_t I, int64_t K, int64_t ldx,
                      int64_t ldw, int64_t ldgu, int64_t ldact, int dtype, tamd_stream_t stream);
-
-/* Backward of that product fused into the GEMM that produces its incoming gradient (the dX product of down_proj):
- *   d_act[M, I] = dY[M, K] . Wd[K, I]   with Wd = down_proj.weight as stored, [hidden = K, I]
- *   DGU[M, 2I]  = d_gate | d_up,  ACT[M, I] = silu(gate) * up   from the saved GU[M, 2I] = gate | up
- * d_act never reaches HBM; results are bit-identical to tamd_gemm (TAMD_GEMM_B_KN) followed by tamd_swiglu_bwd. */
-int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* DGU, void* ACT, int64_t M, int64_t I,
-                         int64_t K, int64_t lddy, int64_t ldw, int64_t ldgu, int64_t lddgu, int64_t ldact, int dtype,
-                         tamd_stream_t stream);
 
 /* q|k|v projection with apply_rotary_pos_emb in the GEMM epilogue (models/llama/modeling_llama.py:254-262):
  *   QKV[M, N] = X[M,K] . Wqkv[N,K]^T, rotary embedding on the first rope_cols columns (query + key heads of 128),

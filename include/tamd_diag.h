@@ -20,35 +20,17 @@ int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N,
  * NULL switches it off.  tools/gemm_clock.py */
 int tamd_gemm_set_clock_buffer(void* buf);
 
-/* Ablation selector for the full-line GEMM kernel (row-major operands, plain epilogue; WRONG RESULTS by design):
- * bit mask 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier;
- * supported values 0, 1, 2, 4, 8, 12, 15 (tools/gemm_fl_dbg.py), and 32 = LDS-DMA pieces issued in the first half of
- * every k-step instead of the second, 64 = a second barrier per k-step between its fragment-read half and its LDS-DMA
- * half (both CORRECT, bit-identical results; each combines with tamd_gemm_set_stagger). */
+/* Ablation / A-B selector for the full-line GEMM kernel (plain epilogue).  Row-major operands, WRONG RESULTS by design:
+ * bit mask 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier
+ * (supported: 1, 2, 4, 8, 12, 15; tools/gemm_fl_dbg.py).  CORRECT, bit-identical results: 32 = the early LDS-DMA piece
+ * placement (the product schedule of the row-major layout) in every layout, 128 = the late placement of round 2 for
+ * row-major operands (tools/gemm_persist_ab.py). */
 int tamd_gemm_set_dbg(int dbg);
-
-/* Staggered K start for plain-epilogue GEMMs of every layout (CORRECT results; the fp32 summation order of a tile
- * rotates): a workgroup starts its K loop (key % units) * stride_stages stages in (stride 0 = K / units apart) and wraps
- * around.  mode: key = 1 XCD of the workgroup, 2 tile row, 3 tile column, 4 tile row + column; mode 0 or units < 2 =
- * off.  tools/gemm_stagger_ab.py */
-int tamd_gemm_set_stagger(int mode, int units, int stride_stages);
 
 /* Phase trace of the attention forward kernel: while `buf` (uint64[32], device memory) is set, workgroup 0 of every
  * tamd_attn_fwd launch stores per-wave shader-clock sums of its tile-loop phases at buf[wave * 8 + phase]
  * (0 tile-load issue, 1 K.Q^T, 2 mask + softmax, 3 P.V, 4 vmcnt wait, 5 barrier).  NULL switches it off. */
 int tamd_attn_set_trace(void* buf);
-
-/* Experimental forward attention kernel with 64 query rows per wave (csrc/attention_fwd64.inc): while on, tamd_attn_fwd
- * uses it for head_dim 128 without padding mask / dropout / packed sequences and seq_k % 64 == 0; results are
- * bit-identical to the product kernel (tools/attn_fwd64_ab.py; 954 vs 1008 TFLOP/s bidirectional in round 2).  Returns the number of
- * forwards that have taken the experimental kernel so far. */
-int tamd_attn_set_fwd64(int on);
-
-/* Causal attention with two query tiles per workgroup (the heaviest remaining tile, then the lightest: equal work per
- * workgroup, half as many workgroups to dispatch).  `on` bit 0: tamd_attn_fwd, bit 1: the dQ kernel of tamd_attn_bwd, for
- * causal calls without padding mask / dropout / packed sequences; results are bit-identical to the product kernels.
- * Returns the number of launches that have taken a paired variant so far.  tools/attn_fwd64_ab.py */
-int tamd_attn_set_pair(int on);
 
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
  * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to

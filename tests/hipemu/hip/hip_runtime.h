@@ -34,6 +34,11 @@ inline void __syncthreads() { hipemu::syncthreads(); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
   hipemu::launch([=]() { kernel(__VA_ARGS__); }, (grid), (block), (smem))
+// (launches are synchronous in the model, so "async" memory operations are plain ones)
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  memset(p, v, n);
+  return hipSuccess;
+}
 
 // ---- math
 inline float __expf(float x) { return std::exp(x); }

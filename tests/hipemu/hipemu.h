@@ -189,6 +189,14 @@ inline void run_block(Block* b, const std::function<void()>& body, dim3 bid, dim
   }
 }
 
+// OS threads a launch runs its blocks on (= blocks that make progress at the same time: what a persistent kernel with
+// cross-block barriers may rely on)
+inline unsigned launch_threads() {
+  unsigned nthr = std::thread::hardware_concurrency();
+  if (const char* e = getenv("HIPEMU_THREADS")) nthr = (unsigned)atoi(e);
+  return nthr < 1 ? 1 : nthr;
+}
+
 inline int launch(const std::function<void()>& body, dim3 grid, dim3 block, size_t smem) {
   if (smem > kMaxDynSmem) {
     fprintf(stderr, "hipemu: dynamic LDS request %zu exceeds 160 KiB\n", smem);
@@ -197,9 +205,7 @@ inline int launch(const std::function<void()>& body, dim3 grid, dim3 block, size
   }
   const uint64_t nblk = (uint64_t)grid.x * grid.y * grid.z;
   std::atomic<uint64_t> next{0};
-  unsigned nthr = std::thread::hardware_concurrency();
-  if (const char* e = getenv("HIPEMU_THREADS")) nthr = (unsigned)atoi(e);
-  if (nthr < 1) nthr = 1;
+  unsigned nthr = launch_threads();
   if (nthr > nblk) nthr = (unsigned)nblk;
   auto worker = [&]() {
     Block* b = new Block();

@@ -405,6 +405,10 @@ inline void setprio_hi() {}
 inline void setprio_lo() {}
 inline unsigned long long device_clock() { return 0ull; }
 inline unsigned long long device_realtime() { return 0ull; }
+// cross-workgroup arrival counters: blocks run on OS threads, so real atomics and a real yield
+inline unsigned atomic_add_agent(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomic_load_agent(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline void short_sleep() { std::this_thread::yield(); }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_log2(float x) { return log2f(x); }

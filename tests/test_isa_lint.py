@@ -86,7 +86,7 @@ def lint_kernel(name, lines):
 @pytest.mark.parametrize("src,flags,defines", [
     ("attention_bwd_dkdv.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"], []),
     ("attention.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], []),
-    ("attention.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], ["-DTAMD_DIAG"]),  # + the experimental attn_fwd64_kernel
+    ("attention.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], ["-DTAMD_DIAG"]),  # + the phase-trace instrumentation
     ("gemm.hip", [], [])])
 def test_untracked_lds_reads_are_not_touched_before_their_wait(src, flags, defines, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

@@ -620,25 +620,6 @@ def test_gemm_swiglu_epilogue_is_bit_identical_to_unfused(env, dtype):
     assert torch.equal(o, gu_ref) and torch.equal(a, act_ref)
 
 
-def test_gemm_swiglu_bwd_epilogue_is_bit_identical_to_unfused(env):
-    """dX product of down_proj with the SwiGLU backward in its epilogue (tamd_gemm_swiglu_bwd) against the two-kernel
-    path (tamd_gemm with the k-major B operand, tamd_swiglu_bwd): d_gate | d_up and the re-materialised act, same bits."""
-    torch.manual_seed(32)
-    shapes = [(4096, 14336, 4096), (1000, 2816, 1024), (333, 1000, 512)] if env.big else [(130, 192, 64), (64, 72, 128)]
-    for t, inter, hd in shapes:
-        dy = torch.randn(t, hd).bfloat16().to(env.device)
-        wd = (torch.randn(hd, inter) * inter ** -0.5).bfloat16().to(env.device)
-        gu = torch.randn(t, 2 * inter).bfloat16().to(env.device)
-        assert ops.gemm_swiglu_bwd_supported(dy, wd, gu)
-        d_act = ops.raw_gemm(dy, wd, b_kn=True)
-        dgu_ref, act_ref = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
-        dgu, act = ops.raw_gemm_swiglu_bwd(dy, wd, gu)
-        assert torch.equal(dgu, dgu_ref), (t, inter, hd)
-        assert torch.equal(act, act_ref), (t, inter, hd)
-    a, b = torch.ops.tamd.gemm_swiglu_bwd(dy, wd, gu)
-    assert torch.equal(a, dgu_ref) and torch.equal(b, act_ref)
-
-
 @pytest.mark.parametrize("cols", [128, 768, 1024])
 def test_dropout_add_layernorm(env, cols):
     """LayerNorm(dropout(x, p) + residual) with the mask drawn inside the norm kernel (BertSelfOutput / BertOutput in train
@@ -759,122 +740,55 @@ def test_residual_epilogue_on_a_small_grid_goes_through_split_k(env):
         assert rel_err(got, (x.float() @ w.float().t()).bfloat16().float() + r.float()) < 0.0036
 
 
-def test_attention_fwd64_matches_fwd(env):
-    """The experimental forward kernel with 64 query rows per wave (csrc/attention_fwd64.inc, diagnostic library only) is
-    bit-identical to the product kernel: causal and bidirectional, GQA, query counts that are not multiples of 256,
-    more keys than queries (KV offset), outputs and LSE."""
-    import math
-
+def test_gemm_piece_placements_and_persistent_walk_are_bit_identical(env):
+    """The schedule variants of the full-line GEMM kernel compute the same bits as the product schedule:
+    * LDS-DMA piece placement: early (product for row-major operands; tamd_gemm_set_dbg(32) selects it for the k-major
+      layouts) and late (round 2's; dbg 128 for row-major operands) -- diagnostic entry points;
+    * the persistent walk (one workgroup per CU, XCD groups start every dispatch round together; `sched="fl_persist"`) and
+      its variant with hand-shakes inside the tiles (`"fl_persist_sync"`): every layout, plain / accumulate epilogues and
+      split-K, several tiles per workgroup with a ragged last round, K long enough for hand-shakes."""
     lib = ops.backend().lib
-    if not hasattr(lib, "tamd_attn_set_fwd64"):
-        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
-    torch.manual_seed(53)
-    dev = env.device
-    cases = ([(2, 1024, 1024, 8, 2), (1, 700, 704, 4, 4), (1, 4096, 4096, 2, 1)] if env.big else
-             [(1, 320, 320, 2, 1), (1, 100, 192, 2, 2), (2, 256, 256, 1, 1)])
-    for (b, sq, sk, hq, hkv) in cases:
-        d = 128
-        q = torch.randn(b, sq, hq, d).bfloat16().to(dev)
-        k = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
-        v = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
-        for causal in (True, False):
-            o_ref, lse_ref = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal)
-            before = lib.tamd_attn_set_fwd64(1)
-            try:
-                o, lse = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal)
-            finally:
-                after = lib.tamd_attn_set_fwd64(0)
-            assert after == before + 1, "the experimental kernel was not taken"
-            assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, causal)
-
-
-def test_attention_fwd_paired_tiles_matches_fwd(env):
-    """Diagnostic variant of the causal forward with two query tiles per workgroup (heaviest + lightest,
-    tamd_attn_set_pair): bit-identical to the product kernel, odd and even tile counts, GQA, a KV offset, ragged ends."""
-    import math
-
-    lib = ops.backend().lib
-    if not hasattr(lib, "tamd_attn_set_pair"):
-        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
-    torch.manual_seed(67)
-    dev = env.device
-    cases = ([(2, 1024, 1024, 8, 2, 128), (1, 700, 704, 4, 4, 128), (1, 4096, 4096, 2, 1, 128), (2, 640, 640, 4, 2, 64)]
-             if env.big else [(1, 384, 384, 2, 1, 128), (1, 100, 192, 2, 2, 128), (2, 256, 256, 2, 1, 64), (1, 128, 128, 1, 1, 64)])
-    for (b, sq, sk, hq, hkv, d) in cases:
-        q = torch.randn(b, sq, hq, d).bfloat16().to(dev)
-        k = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
-        v = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
-        o_ref, lse_ref = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), True)
-        before = lib.tamd_attn_set_pair(1)
-        try:
-            o, lse = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), True)
-            ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), False)            # bidirectional calls keep the product kernel
-        finally:
-            after = lib.tamd_attn_set_pair(0)
-        assert after == before + 1, "the paired variant was not taken exactly once"
-        assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, d)
-        # the dQ kernel of the backward, paired the same way (bit 1 of the switch)
-        do = torch.randn(b, sq, hq, d).bfloat16().to(dev)
-        ref = ops.raw_attn_bwd(q, k, v, o_ref, lse_ref, do, 1 / math.sqrt(d), True, None)
-        before = lib.tamd_attn_set_pair(2)
-        try:
-            got = ops.raw_attn_bwd(q, k, v, o_ref, lse_ref, do, 1 / math.sqrt(d), True, None)
-        finally:
-            after = lib.tamd_attn_set_pair(0)
-        assert after == before + 1
-        for x, y in zip(got, ref):
-            assert torch.equal(x, y), (b, sq, sk, hq, hkv, d)
-
-
-def test_gemm_staggered_k_start(env):
-    """Diagnostic variant of the GEMM (tamd_gemm_set_stagger, include/tamd_diag.h): a workgroup starts its K loop a few
-    stages in and wraps around.  Same products, rotated fp32 summation order: results agree with the product kernel to
-    rounding in every layout, and a cancellation pattern that is sensitive to the order shows which tiles rotated."""
-    lib = ops.backend().lib
-    if not hasattr(lib, "tamd_gemm_set_stagger"):
-        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
     torch.manual_seed(61)
     dev = env.device
-    m, n, k = (1024, 768, 1280) if env.big else (512, 512, 640)
+    # tiles: emu 6 x 4 = 24 over 8 persistent workgroups (3 rounds; 2 groups of 4), hip 24 x 16 = 384 over 256 (2 rounds)
+    m, n, k = (6144, 4096, 8320) if env.big else (1536, 1000, 4288)
     x = torch.randn(m, k).bfloat16().to(dev)
     w = (torch.randn(n, k) * k ** -0.5).bfloat16().to(dev)
     layouts = [((x, w), {}), ((x, w.t().contiguous()), {"b_kn": True}),
                ((x.t().contiguous(), w.t().contiguous()), {"a_km": True, "b_kn": True})]
     ref = x.float() @ w.float().t()
-    try:
-        for args, kw in layouts:
-            plain = ops.raw_gemm(*args, **kw)
-            for mode, units, stride in ((1, 8, 0), (2, 3, 1), (3, 2, 3), (4, 5, 0), (2, 255, 7)):
-                assert lib.tamd_gemm_set_stagger(mode, units, stride) == 0
-                got = ops.raw_gemm(*args, **kw)
-                assert rel_err(got, plain) < 2e-3 and rel_err(got, ref) < 0.0036, (kw, mode, units, stride)
-        # order-sensitive operands: +2^30 in the first stage, -2^30 in the last, ones in between: the product kernel adds
-        # the ones to 2^30 (lost, 64 at a time) and ends at 0; a tile that starts one stage in keeps them
-        xs = torch.ones(m, k)
-        xs[:, 0], xs[:, -1] = 2.0 ** 15, -(2.0 ** 15)
-        ws = torch.ones(n, k)
-        ws[:, 0] = ws[:, -1] = 2.0 ** 15
-        xs, ws = xs.bfloat16().to(dev), ws.bfloat16().to(dev)
-        lib.tamd_gemm_set_stagger(0, 0, 0)
-        plain = ops.raw_gemm(xs, ws).float()
-        lib.tamd_gemm_set_stagger(2, 2, 1)                               # odd tile rows start at stage 1
-        got = ops.raw_gemm(xs, ws).float()
-        assert torch.equal(got[:256], plain[:256]) and torch.equal(got[512:768], plain[512:768])
-        assert (got[256:512] != plain[256:512]).all()
-        assert lib.tamd_gemm_set_stagger(7, 2, 1) != 0                   # unknown mode is refused
-        # early LDS-DMA pieces (tamd_gemm_set_dbg(32), row-major operands): same summation order, identical bits --
-        # alone and on top of a stagger
-        lib.tamd_gemm_set_stagger(0, 0, 0)
-        plain = ops.raw_gemm(x, w)
-        for dbg in (32, 64):                                             # 64: a second barrier per k-step
-            lib.tamd_gemm_set_dbg(dbg)
-            assert torch.equal(ops.raw_gemm(x, w), plain), dbg
-        lib.tamd_gemm_set_dbg(0)
-        lib.tamd_gemm_set_stagger(4, 5, 2)
-        staggered = ops.raw_gemm(x, w)
-        for dbg in (32, 64):
-            lib.tamd_gemm_set_dbg(dbg)
-            assert torch.equal(ops.raw_gemm(x, w), staggered), dbg
-    finally:
-        lib.tamd_gemm_set_stagger(0, 0, 0)
-        lib.tamd_gemm_set_dbg(0)
+    for args, kw in layouts:
+        plain = ops.raw_gemm(*args, sched="fl", **kw)
+        assert rel_err(plain, ref) < 0.0036
+        for sched in ("fl_persist", "fl_persist_sync"):
+            assert torch.equal(ops.raw_gemm(*args, sched=sched, **kw), plain), (kw, sched)
+        acc0 = torch.randn(m, n).bfloat16().to(dev)
+        want = ops.raw_gemm(*args, epilogue=ops.EPI_ACCUM, out=acc0.clone(), sched="fl", **kw)
+        got = ops.raw_gemm(*args, epilogue=ops.EPI_ACCUM, out=acc0.clone(), sched="fl_persist_sync", **kw)
+        assert torch.equal(got, want), kw
+        if hasattr(lib, "tamd_gemm_set_dbg"):
+            try:
+                for dbg in (32, 128):
+                    lib.tamd_gemm_set_dbg(dbg)
+                    assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
+            finally:
+                lib.tamd_gemm_set_dbg(0)
+    # split-K under the persistent walk (through the C ABI directly: the Python wrapper only splits without a hint)
+    if env.big:  # the q|k|v weight gradient of Llama-3-8B: 384 tiles x 2 splits
+        m, n, k = 6144, 4096, 32768
+        a_, b_ = torch.randn(k, m).bfloat16().to(dev), (torch.randn(k, n) * k ** -0.5).bfloat16().to(dev)
+    else:
+        a_, b_ = layouts[2][0]
+    be = ops.backend()
+    ws_bytes = be.lib.tamd_gemm_workspace_bytes(m, n, k, 3, ops.EPI_NONE)
+    assert ws_bytes > 0
+
+    def splitk(flags):
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        be.lib.check(be.lib.tamd_gemm_ws(a_.data_ptr(), b_.data_ptr(), out.data_ptr(), None, None, m, n, k, a_.stride(0),
+                                         b_.stride(0), n, 0, 3 | flags, ops.EPI_NONE, 0, ops._code(a_), ws.data_ptr(),
+                                         ws_bytes, be.stream(a_)), "tamd_gemm_ws")
+        return out
+
+    assert torch.equal(splitk(4 << 8), splitk(0))

@@ -806,3 +806,125 @@ def test_bert_decoder_cross_attention_matches_reference(env):
                      encoder_attention_mask=enc_mask.to(dev)).last_hidden_state
         e_fast, e_ref = rel_err(c, a32), rel_err(a, a32)
         assert e_fast <= 1.1 * e_ref + 1e-3, (sq, sk, e_fast, e_ref)
+
+
+@pytest.mark.gpu
+def test_decoder_stack_replays_as_one_hip_graph():
+    """Forward-only calls of a whole Llama stack (transformers_amd/graph_stack.py): the second sighting of a shape is
+    captured, later calls replay the graph -- the same bits as the eager path, for changing inputs; calls that want
+    per-layer hidden states, gradients or a KV cache stay eager."""
+    from transformers_amd import graph_stack
+
+    torch.manual_seed(41)
+    dev = torch.device("cuda:0")
+    cfg = tiny_llama(True)
+    model = transformers_amd.accelerate(LlamaForCausalLM(cfg).bfloat16().to(dev).eval())
+    stack = model.model.layers[0].__dict__["_tamd_stack"][0]
+    ids = [torch.randint(0, cfg.vocab_size, (2, 300), device=dev) for _ in range(4)]
+    old = graph_stack.set_enabled(False)
+    try:
+        with torch.no_grad():
+            want = [model(input_ids=i, use_cache=False).logits.clone() for i in ids]
+        graph_stack.set_enabled(True)
+        with torch.no_grad():
+            got = [model(input_ids=i, use_cache=False).logits.clone() for i in ids]
+            assert stack.replays == 3  # first call eager, second captures and replays, then replays
+            for g, w in zip(got, want):
+                assert torch.equal(g, w)
+            # per-layer hidden states: eager, and each layer's own output
+            before = stack.replays
+            hs = model(input_ids=ids[0], use_cache=False, output_hidden_states=True).hidden_states
+            assert stack.replays == before and len(hs) == cfg.num_hidden_layers + 1
+            assert not torch.equal(hs[1], hs[2])
+            # a padded batch is another signature (first sighting: eager), then its own graph
+            am = torch.ones(2, 300, dtype=torch.long, device=dev)
+            am[0, :17] = 0
+            a = model(input_ids=ids[1], attention_mask=am, use_cache=False).logits.clone()
+            b = model(input_ids=ids[1], attention_mask=am, use_cache=False).logits.clone()
+            assert stack.replays == before + 1 and torch.equal(a, b)
+        # training / gradients: eager
+        before = stack.replays
+        model.train()
+        model(input_ids=ids[0], labels=ids[0], use_cache=False).loss.backward()
+        assert stack.replays == before
+    finally:
+        graph_stack.set_enabled(old)
+
+
+@pytest.mark.parametrize("p_hidden", [0.0, 0.1])
+def test_bert_layer_op_matches_reference_layer(env, p_hidden):
+    """torch.ops.tamd.bert_layer (TamdBertLayer: BertLayer.forward as one autograd node, modeling_bert.py:374-416) against
+    the reference's own BertLayer in fp32, with a padding mask: output, input gradient and every parameter gradient.
+    With hidden dropout the reference layer is restated with the kernels' keep masks rebuilt on the host from the seeds
+    (counter-based hash, not torch's Philox stream), as in the post-LN block test above."""
+    from transformers import BertConfig
+    from transformers.models.bert import modeling_bert as mb
+
+    from transformers_amd import ops
+    from transformers_amd.patch import _tables
+
+    torch.manual_seed(71)
+    big = env.big
+    hd, inter, heads = (768, 3072, 12) if big else (128, 256, 2)
+    b, s = (4, 384) if big else (2, 40)
+    cfg = BertConfig(hidden_size=hd, intermediate_size=inter, num_attention_heads=heads, hidden_dropout_prob=p_hidden,
+                     attention_probs_dropout_prob=0.0, attn_implementation="eager")
+    ref = mb.BertLayer(cfg).float().train()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():  # non-trivial biases and LayerNorm gains
+            if p.dim() == 1:
+                p.copy_(torch.randn_like(p) * 0.1 + (1.0 if n.endswith("LayerNorm.weight") else 0.0))
+    dev = env.device
+    fast = copy.deepcopy(ref).bfloat16().to(dev)
+    transformers_amd.attention.register()
+    fcfg = copy.deepcopy(cfg)
+    fcfg._attn_implementation = "tamd"
+    for m in fast.modules():
+        r = _tables().get(type(m))
+        if r is not None:
+            m.__class__ = r
+        if hasattr(m, "config"):
+            m.config = fcfg
+    assert type(fast).__name__ == "TamdBertLayer"
+    ref = copy.deepcopy(fast).cpu().float()  # the reference holds the SAME (bf16-rounded) weights, in fp32
+    for m in ref.modules():
+        inv = {v: k for k, v in _tables().items()}
+        if type(m) in inv:
+            m.__class__ = inv[type(m)]
+        if hasattr(m, "config"):
+            m.config = cfg
+    ref.__dict__.pop("_tamd_stack", None)
+    x = torch.randn(b, s, hd).bfloat16()
+    valid = torch.ones(b, s, dtype=torch.bool)
+    valid[0, s - 9:] = False
+    add_mask = torch.zeros(b, 1, 1, s).masked_fill(~valid[:, None, None, :], torch.finfo(torch.float32).min)
+    xr = x.float().requires_grad_(True)
+    xf = x.to(dev).requires_grad_(True)
+    torch.manual_seed(5)
+    seeds = (ops.dropout_seed(), ops.dropout_seed()) if p_hidden > 0 else (0, 0)
+    torch.manual_seed(5)
+    transformers_amd.fallback_calls(reset=True)
+    yf = fast(xf, attention_mask=valid.to(dev))
+    assert transformers_amd.fallback_calls() == {}
+    if p_hidden == 0.0:
+        yr = ref(xr, attention_mask=add_mask)
+    else:  # the reference layer with the kernels' masks: BertSelfOutput / BertOutput restated (modeling_bert.py:289-293, 347-351)
+        keep1 = ops.hidden_dropout_keep_mask(seeds[0], b * s, hd, p_hidden).view(b, s, hd)
+        keep2 = ops.hidden_dropout_keep_mask(seeds[1], b * s, hd, p_hidden).view(b, s, hd)
+        att = ref.attention
+        a, _ = att.self(xr, attention_mask=add_mask)
+        h1 = att.output.LayerNorm(att.output.dense(a) * keep1 / (1 - p_hidden) + xr)
+        yr = ref.output.LayerNorm(ref.output.dense(ref.intermediate(h1)) * keep2 / (1 - p_hidden) + h1)
+    v = valid
+    assert rel_err(yf[v.to(dev)], yr[v]) < 6e-3
+    g = torch.randn(b, s, hd).bfloat16()
+    g[~valid] = 0
+    yr.backward(g.float())
+    yf.backward(g.to(dev))
+    assert rel_err(xf.grad[v.to(dev)], xr.grad[v]) < 1.2e-2
+    gr = dict(ref.named_parameters())
+    for n, p in fast.named_parameters():
+        if "key.bias" in n:  # exactly zero (softmax shift invariance)
+            continue
+        assert p.grad is not None, n
+        assert rel_err(p.grad, gr[n].grad) < 1.5e-2, n

@@ -44,7 +44,7 @@ def test_namespace_is_complete():
                     "gemm_out", "attn_fwd", "attn_bwd"]
     differentiable = ["rmsnorm", "add_rmsnorm", "layernorm", "add_layernorm", "linear", "fused_linear", "conv1d", "rope",
                       "attention", "swiglu", "bias_act", "embedding", "bert_embeddings", "cross_entropy_sum",
-                      "linear_cross_entropy", "llama_layer", "padded_vocab_head"]
+                      "linear_cross_entropy", "llama_layer", "bert_layer", "padded_vocab_head"]
     for name in kernel_level + differentiable:
         op = getattr(T, name).default
         assert torch._C._dispatch_has_kernel_for_dispatch_key(op.name(), "CUDA"), name

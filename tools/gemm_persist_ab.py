@@ -1,0 +1,98 @@
+"""A/B of the GEMM schedule variants of round 3 against the product schedule on the Llama-3-8B shapes, interleaved rounds
+in one process (TFLOP/s per arm and round):
+
+  fl              the product kernel (early LDS-DMA pieces for row-major operands, late for k-major ones)
+  persist         TAMD_GEMM_SCHED_FL_PERSIST: one workgroup per CU, XCD groups start every dispatch round together
+  persist_sync    ... and re-align every 64 stages inside a tile
+  early / late    the other piece placement of the layout (diagnostic library: tamd_gemm_set_dbg 32 / 128)
+
+Split-K products (q|k|v and down dW) go through tamd_gemm_ws with the workspace the policy asks for.
+
+    python tools/gemm_persist_ab.py [--rounds 3] [--iters 6] [--shapes qkv,o_proj,gate_up,down,lm_head] [--legs fwd,dX,dW]
+Under `rocprofv3 --pmc FETCH_SIZE` (with --rounds 1 --iters 2) the kernel names carry the variant (last template
+argument 1 / 2 = persistent), so the fabric traffic per launch separates by arm."""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import _diag  # noqa: E402
+from transformers_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--iters", type=int, default=6)
+ap.add_argument("--shapes", default="qkv,o_proj,gate_up,down,lm_head")
+ap.add_argument("--legs", default="fwd,dX,dW")
+ap.add_argument("--no-diag", action="store_true", help="product library only (no early / late arms)")
+args = ap.parse_args()
+lib = None if args.no_diag else _diag.use_diag()
+be = ops.backend()
+dev = torch.device("cuda:0")
+T = 32768
+SHAPES = {"qkv": (T, 6144, 4096), "o_proj": (T, 4096, 4096), "gate_up": (T, 28672, 4096), "down": (T, 4096, 14336),
+          "lm_head": (T, 128256, 4096)}
+HINT = {"fl": 0, "persist": 4 << 8, "persist_sync": 5 << 8}
+
+
+def gemm(a, b, flags, m, n, k, out, ws):
+    be.lib.check(be.lib.tamd_gemm_ws(a.data_ptr(), b.data_ptr(), out.data_ptr(), None, None, m, n, k, a.stride(0),
+                                     b.stride(0), out.stride(0), 0, flags, ops.EPI_NONE, 0, ops._code(a),
+                                     ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                     be.stream(a)), "tamd_gemm_ws")
+
+
+def time_ms(fn):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(args.iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / args.iters
+
+
+for name in args.shapes.split(","):
+    m, n, k = SHAPES[name]
+    x = torch.randn(m, k, device=dev).bfloat16()
+    w = (torch.randn(n, k, device=dev) * 0.02).bfloat16()
+    dy = torch.randn(m, n, device=dev).bfloat16()
+    # (operands, layout flags, GEMM M N K) of the three products of a linear layer
+    legs = {"fwd": (x, w, 0, m, n, k), "dX": (dy, w, 2, m, k, n), "dW": (dy, x, 3, n, k, m)}
+    for leg in args.legs.split(","):
+        a, b, lay, gm, gn, gk = legs[leg]
+        out = torch.empty(gm, gn, dtype=torch.bfloat16, device=dev)
+        ws_bytes = be.lib.tamd_gemm_workspace_bytes(gm, gn, gk, lay, ops.EPI_NONE)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        arms = ["fl", "persist", "persist_sync"]
+        if lib is not None and ws is None:
+            arms.append("late" if lay == 0 else "early")
+        res = {c: [] for c in arms}
+        ref = None
+        for rnd in range(args.rounds):
+            for c in arms:
+                if lib is not None:
+                    lib.tamd_gemm_set_dbg({"late": 128, "early": 32}.get(c, 0))
+                flags = lay | HINT.get(c, 0)
+                # (a hint turns split-K off in the library unless a workspace comes with it: it does here)
+                fn = lambda: gemm(a, b, flags, gm, gn, gk, out, ws)  # noqa: E731
+                res[c].append(round(2.0 * gm * gn * gk / time_ms(fn) / 1e9))
+                if rnd == 0:
+                    if ref is None:
+                        ref = out.clone()
+                    elif not torch.equal(out, ref):
+                        res[c].append("MISMATCH")
+        if lib is not None:
+            lib.tamd_gemm_set_dbg(0)
+        med = {c: sorted(v for v in vals if not isinstance(v, str))[len(vals) // 2] for c, vals in res.items()}
+        print(json.dumps({"shape": name, "leg": leg, "mnk": [gm, gn, gk], "split_k": bool(ws_bytes), "tflops": res,
+                          "median_vs_fl": {c: round(med[c] / med["fl"] - 1, 4) for c in arms}}), flush=True)
+        del out, ws
+    del x, w, dy

@@ -14,7 +14,7 @@ TAMD_BF16, TAMD_F16, TAMD_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 GEMM_A_KM, GEMM_B_KN = 1, 2
 EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_BIAS_ACT, EPI_ACCUM = 0, 1, 2, 3, 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 P = c_void_p
 I64 = c_int64
@@ -73,7 +73,6 @@ SIGNATURES = {
     "tamd_gemm_ws": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P, c_size_t,
                              P]),
     "tamd_gemm_swiglu": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
-    "tamd_gemm_swiglu_bwd": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_gemm_rope": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),
@@ -85,10 +84,7 @@ DIAG_SIGNATURES = {
     "tamd_gemm_trace": (c_int, [P, P, P, I64, I64, I64, P, P]),
     "tamd_gemm_set_clock_buffer": (c_int, [P]),
     "tamd_gemm_set_dbg": (c_int, [c_int]),
-    "tamd_gemm_set_stagger": (c_int, [c_int, c_int, c_int]),
     "tamd_attn_set_trace": (c_int, [P]),
-    "tamd_attn_set_fwd64": (c_int, [c_int]),
-    "tamd_attn_set_pair": (c_int, [c_int]),
     "tamd_mfma_power": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "tamd_probe": (c_int, [P, P, P, c_int, c_int, P]),
     "tamd_bw_probe": (c_int, [P, c_size_t, c_int, c_size_t, c_int, c_int, c_int, P, P]),

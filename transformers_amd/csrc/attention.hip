@@ -26,24 +26,10 @@
 
 namespace tamd {
 
-#define TAMD_FWD_KERNEL attn_fwd_kernel
-#define TAMD_FWD_PAIR 0
 #include "attention_fwd_kernel.inc"
-#undef TAMD_FWD_KERNEL
-#undef TAMD_FWD_PAIR
-#ifdef TAMD_DIAG  // two query tiles per workgroup (tamd_attn_set_pair): diagnostic library only
-#define TAMD_FWD_KERNEL attn_fwd_pair_kernel
-#define TAMD_FWD_PAIR 1
-#include "attention_fwd_kernel.inc"
-#undef TAMD_FWD_KERNEL
-#undef TAMD_FWD_PAIR
-#endif
 
 }  // namespace tamd
 
-#ifdef TAMD_DIAG
-#include "attention_fwd64.inc"  // experimental 64-rows-per-wave forward: diagnostic library only
-#endif
 #include "attention_bwd.inc"
 
 using namespace tamd;
@@ -52,10 +38,6 @@ namespace {
 
 #ifdef TAMD_DIAG
 unsigned long long* g_attn_trace = nullptr;
-int g_attn_fwd64 = 0;  // tamd_attn_set_fwd64: route eligible forwards to attn_fwd64_kernel
-int g_attn_fwd64_launches = 0;
-int g_attn_pair = 0;  // tamd_attn_set_pair: causal forwards without mask / dropout take the two-tiles-per-workgroup variant
-int g_attn_pair_launches = 0;
 #endif
 
 template <typename T, int D>
@@ -64,28 +46,6 @@ int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
   dim3 grid((unsigned)(a.nqt * a.heads_q * a.batch)), block(kAttnThreads);
   const bool mask = a.key_valid != nullptr;
   const bool drop = a.drop_thr != 0;
-#ifdef TAMD_DIAG
-  if (g_attn_fwd64 && D == 128 && !mask && !drop && a.q_start == nullptr && a.seq_k % kKB == 0 && a.kss == a.vss &&
-      TileFeed<128>::usable(a.kss)) {
-    const int nqt64 = (a.seq_q + kQB64 - 1) / kQB64;
-    dim3 grid64((unsigned)(nqt64 * a.heads_q * a.batch));
-    ++g_attn_fwd64_launches;
-    const size_t smem64 = (size_t)3 * 2 * kKB * 128 * 2;  // 3 x (K + V) = 96 KiB (covers the O staging: 8 x 32 x 272 B)
-    if (causal)
-      hipLaunchKernelGGL((attn_fwd64_kernel<T, true>), grid64, block, smem64, s, a);
-    else
-      hipLaunchKernelGGL((attn_fwd64_kernel<T, false>), grid64, block, smem64, s, a);
-    return launch_status();
-  }
-#endif
-#ifdef TAMD_DIAG
-  if (g_attn_pair && causal && !mask && !drop && a.q_start == nullptr) {
-    ++g_attn_pair_launches;
-    dim3 gridp((unsigned)(((a.nqt + 1) / 2) * a.heads_q * a.batch));
-    hipLaunchKernelGGL((attn_fwd_pair_kernel<T, D, true, false, false>), gridp, block, smem, s, a);
-    return launch_status();
-  }
-#endif
 #define TAMD_AF(C_, M_, D_) hipLaunchKernelGGL((attn_fwd_kernel<T, D, C_, M_, D_>), grid, block, smem, s, a)
   if (drop) {  // the dropout variants always carry the padding-mask code (rare path: keep the instantiation count down)
     if (causal)
@@ -173,18 +133,6 @@ AttnArgs make_args(const tamd_attn_params* p) {
 extern "C" int tamd_attn_set_trace(void* buf) {
   g_attn_trace = reinterpret_cast<unsigned long long*>(buf);
   return TAMD_OK;
-}
-// 1: tamd_attn_fwd takes the experimental 64-rows-per-wave kernel (attention_fwd64.inc) wherever it applies
-// bit 0: causal forwards, bit 1: causal dQ launches without mask / dropout take two query tiles per workgroup (heavy +
-// light); returns how many launches have taken a paired variant so far
-extern "C" int tamd_attn_set_pair(int on) {
-  g_attn_pair = on & 1;
-  g_attn_pair_bwd = (on >> 1) & 1;
-  return g_attn_pair_launches + g_attn_pair_bwd_launches;
-}
-extern "C" int tamd_attn_set_fwd64(int on) {
-  g_attn_fwd64 = on;
-  return g_attn_fwd64_launches;  // (how many forwards have taken the experimental kernel so far)
 }
 #endif
 

@@ -58,8 +58,8 @@ __device__ __attribute__((aligned(16))) static const unsigned int g_zero16[4] = 
   const unsigned long long clk_t0 = g.trace ? device_clock() : 0ull, clk_r0 = g.trace ? device_realtime() : 0ull;
 #define TAMD_CLOCK_END                                          \
   if (g.trace != nullptr && threadIdx.x == 0) {                 \
-    g.trace[2 * (size_t)blockIdx.x] = device_clock() - clk_t0;  \
-    g.trace[2 * (size_t)blockIdx.x + 1] = device_realtime() - clk_r0; \
+    g.trace[2 * (size_t)vbid] = device_clock() - clk_t0;  \
+    g.trace[2 * (size_t)vbid + 1] = device_realtime() - clk_r0; \
   }
 #else
 #define TAMD_CLOCK_BEGIN
@@ -86,13 +86,13 @@ struct GemmArgs {
   // rotary epilogue (kEpiRope): R = cos, C2 = sin ([cos_batch, seq, 128] in the storage dtype), n_half = the leading
   // columns to rotate (query + key heads, a multiple of 128), seq / cos_batch below
   int64_t seq, cos_batch;
-#ifdef TAMD_DIAG
-  int stagger;  // staggered K start of the DBG=16 instantiations: mode | units << 4 | stride_stages << 12
-#endif
+  // persistent walk (PERSIST instantiations): arrival counters of the launch (16 unsigned per group: [0] round starts,
+  // [8] hand-shakes inside a tile), number of groups (= XCDs) and of virtual blocks (tiles x splits)
+  unsigned* sync;
+  int sync_groups, total_wgs;
 };
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
-constexpr int kEpiSwiGLUBwd = 102;
 constexpr int kEpiRope = 103;
 
 // the LlamaMLP inner product (models/llama/modeling_llama.py:174-176; same expression as swiglu_fwd_kernel in
@@ -184,7 +184,7 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int bid, i
 // Epilogue of one wave over a (HALVES*64) x (NCOLS) piece of C at (row0, col0).  Per 64 rows: `stage(half, bias4)` rounds
 // the accumulators (+bias, +activation) into this wave's private LDS region (row pitch NCOLS*2 + 16 bytes; the
 // accumulator layout is the caller's business: stage32 / stage16 below), then full-row 16-byte stores (+residual / +C /
-// SwiGLU backward) leave from there.
+// rotary embedding) leave from there.
 template <typename T, int EPI, int ACT, int NCOLS, int HALVES, typename StageFn>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem, unsigned st_off, int64_t row0, int64_t col0,
                                                    int lane, StageFn stage) {
@@ -193,11 +193,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
   constexpr int RPI = 64 / SLOTS;        // rows per wave instruction on the way out
   T* C = reinterpret_cast<T*>(g.C);
   const T* R = reinterpret_cast<const T*>(g.R);
-  // operands the way out reads from memory (residual / previous C / the saved gate|up): all of a half's loads are issued
+  // operands the way out reads from memory (residual / previous C / cos and sin rows): all of a half's loads are issued
   // BEFORE the accumulators are rounded and staged, so their latency overlaps that work and 16-32 KiB per wave are in
-  // flight instead of 4 (the way out was latency-bound at ~2.7 TB/s: 1.05 ms of the 3.8 ms SwiGLU-backward GEMM)
+  // flight instead of 4 (a way out that loads inside its row loop is latency-bound at ~2.7 TB/s)
   constexpr bool ROPE = (EPI == kEpiRope && NCOLS == 128);  // (cos / sin rows of the rotary epilogue are such operands too)
-  constexpr int NR = (EPI == kEpiSwiGLUBwd || ROPE) ? 2 : ((EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0);
+  constexpr int NR = ROPE ? 2 : ((EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0);
   constexpr int NIT = 64 / RPI;
   // rotary epilogue: this wave's 128 columns are one head; value heads (col0 >= n_half) pass through.  The cos / sin row
   // of a token is its position in its sequence: ONE 64-bit modulo per wave, the rows of the piece count up from there
@@ -209,8 +209,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
     const int64_t crow = crow_base + r;  // r < 128 <= seq (tamd_gemm_rope refuses shorter shared-table sequences): one wrap
     return (g.cos_batch == 1 && crow >= g.seq) ? crow - g.seq : crow;
   };
-  // (the SwiGLU backward carries two loads per row segment: in two chunks of 8 iterations -- 64 registers of loads in
-  // flight -- so that nothing spills; a kernel with scratch also throttles how many of its waves the CU runs)
+  // (two loads per row segment -- the rotary epilogue's cos and sin -- go in two chunks of 8 iterations: 64 registers of
+  // loads in flight, so that nothing spills)
   constexpr int CH = (NR == 2 && NIT > 8) ? 8 : NIT;
 #pragma unroll
   for (int half = 0; half < HALVES; ++half) {
@@ -222,10 +222,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
         const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
         const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
         const bool ok = gm_ < g.M && gn < g.N;
-        if (EPI == kEpiSwiGLUBwd) {
-          pre[2 * i] = ok ? ld16(R + gm_ * g.ldr + gn) : u32x4{0u, 0u, 0u, 0u};
-          pre[2 * i + 1] = ok ? ld16(R + gm_ * g.ldr + g.n_half + gn) : u32x4{0u, 0u, 0u, 0u};
-        } else if (ROPE) {
+        if (ROPE) {
           if (rope_here) {
             const int64_t crow = rope_row(half * 64 + row);
             pre[2 * i] = ok ? ld16(R + crow * 128 + slot * 8) : u32x4{0u, 0u, 0u, 0u};
@@ -248,27 +245,6 @@ __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem
       const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
       const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
       u32x4 v = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)slot * 16u);
-      if (EPI == kEpiSwiGLUBwd) {
-        // v = d_act[gm_, gn..gn+7] (rounded, as the two-kernel path stores it); R = the saved gate|up [M, 2I]:
-        // d_gate | d_up -> C [M, 2I], act = silu(gate)*up re-materialised -> C2 [M, I]   (swiglu_bwd_kernel's formulas)
-        if (gm_ < g.M && gn < g.N) {
-          float d[8], gt[8], up[8], dg[8], du[8], ac[8];
-          unpack16<T>(v, d);
-          unpack16<T>(pre[NR == 2 ? 2 * pi : 0], gt);
-          unpack16<T>(pre[NR == 2 ? 2 * pi + 1 : 0], up);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float sl = round_through<T>(gemm_silu(gt[e]));
-            du[e] = d[e] * sl;
-            dg[e] = round_through<T>(d[e] * up[e]) * gemm_dsilu(gt[e]);
-            ac[e] = sl * up[e];
-          }
-          st16(C + gm_ * g.ldc + gn, pack16<T>(dg));
-          st16(C + gm_ * g.ldc + g.n_half + gn, pack16<T>(du));
-          st16(reinterpret_cast<T*>(g.C2) + gm_ * g.ldc2 + gn, pack16<T>(ac));
-        }
-        continue;
-      }
       if (ROPE && rope_here) {
         // apply_rotary_pos_emb on a query / key head (this wave's 128 columns are exactly one head of 128):
         //   out = round(round(x * cos) + round(rotate_half(x) * sin)),  rotate_half(x)[d] = -x[d+64] (d < 64), x[d-64]
@@ -573,27 +549,65 @@ __device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
   return (unsigned)(8 * g4 + kq) * 512u + (unsigned)slot * 16u + (unsigned)(col & 7) * 2u;
 }
 
-// DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_GEMM_DBG=n, wrong results): 1 no LDS-DMA after the prologue, 2 no LDS
-// fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier.  16 (CORRECT results, tamd_gemm_set_stagger): the K loop
-// of a workgroup starts `soff` stages in and wraps around -- workgroups that run side by side then ask the memory
-// system for different k ranges at the same moment instead of sweeping the same address bits in lockstep (what
-// hipBLASLt's gfx950 kernels call StaggerU); the fp32 summation order of a tile rotates with it.  32 (correct,
-// bit-identical results; row-major operands): the LDS-DMA pieces of a k-step go out behind its MFMA pairs 2, 5, .. 23
-// instead of 17, 19, .. 31 -- 23 MFMAs (~400 cycles) more on average for a piece to land before the hand-off waits for
-// it (hipBLASLt's kernel gives its operands 84-182 MFMAs, ours 64-94 for B) -- with the fragment reads of the next
-// k-step on the pairs between them.  64 (correct, bit-identical; row-major operands): a second barrier per k-step between
-// its fragment-read half and its LDS-DMA half (hipBLASLt's loop has three barriers per stage, ours one).
-template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
+// DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_GEMM_DBG=n): wrong results by
+// design -- 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier; correct,
+// bit-identical results -- 32 the early piece placement (below) for the k-major layouts too, 128 the late placement
+// (pieces behind the odd MFMA pairs 17..31: the schedule of round 2) for row-major operands.
+// Piece placement (EARLY): the 8 LDS-DMA pieces of a k-step go out behind its MFMA pairs 2, 5, .. 23, the 16 fragment
+// reads of the next k-step on the pairs between them -- 23 MFMAs (~400 cycles) more on average for a piece to land
+// before the hand-off waits for it than behind the odd pairs 17..31 (hipBLASLt's gfx950 kernel gives its operands
+// 84-182 MFMAs).  Measured on MI355X (profiles/r03a_gemm_stagger_ab.jsonl): +1.0 ... +2.0 % on all four forward shapes
+// of Llama-3-8B, so it is the product schedule for row-major operands.  The same A/B buried two other differences to
+// hipBLASLt's loop: a staggered, wrapping K start per workgroup (13 configurations: -1 ... +2 %, no pattern) and a
+// second barrier per k-step (+-0.5 %).
+// PERSIST (TAMD_GEMM_SCHED_FL_PERSIST / _SYNC hints, long-K products): `gridDim.x` = groups x per_round persistent
+// workgroups; workgroup (x = blockIdx % groups, slot = blockIdx / groups) walks the virtual block ids
+// x + groups * (slot + per_round * round), i.e. exactly the blocks the hardware would have given the CUs of XCD x in
+// dispatch round `round`, and the workgroups of one XCD start each round TOGETHER (an arrive-and-wait on a counter in
+// global memory, bounded spin).  Why: the 32 tiles an XCD runs side by side share their A / B panels through its 4 MiB
+// L2 only while they sweep k in step (the L2 holds ~10 stages of a patch's 12 panels); a 512-stage weight-gradient tile
+// drifts further than that, and from the second dispatch round on the tiles do not even start together -- the one
+// 1-round dW (o_proj, 256 tiles) runs at 1514 TFLOP/s and reads 1.4x the patch floor, the 7-round gate|up dW at 1426
+// and 2.0x.  PERSIST = 2 additionally re-aligns the XCD every kSyncStages stages inside a tile.
+constexpr int kSyncStages = 64;
+constexpr int kSyncSpinLimit = 1 << 20;
+
+// arrive on `ctr` and wait until `target` workgroups have (one lane polls; agent-scope atomics: correct wherever the
+// workgroups of a "group" really run); gives up after kSyncSpinLimit polls -- alignment is an optimisation, never a
+// correctness condition, and a partner that is not resident (CU-masked stream, shared GPU) must not hang the kernel
+__device__ __forceinline__ void group_arrive_wait(unsigned* ctr, unsigned target) {
+  atomic_add_agent(ctr, 1u);
+  for (int spin = 0; spin < kSyncSpinLimit && atomic_load_agent(ctr) < target; ++spin) short_sleep();
+}
+
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0, int PERSIST = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
   const int wm = wave >> 1, wn = wave & 1;
   const int g4 = lane >> 4, l15 = lane & 15;
+  // persistent walk (see PERSIST above): virtual block id of this round; the plain kernel runs the loop body once
+  const int p_group = PERSIST ? (int)(blockIdx.x % (unsigned)g.sync_groups) : 0;
+  const int p_slot = PERSIST ? (int)(blockIdx.x / (unsigned)g.sync_groups) : 0;
+  const int p_per_round = PERSIST ? (int)(gridDim.x / (unsigned)g.sync_groups) : 1;
+  const int p_in_group = PERSIST ? (g.total_wgs - p_group + g.sync_groups - 1) / g.sync_groups : 1;  // virtual blocks of this group
+#pragma unroll 1
+  for (int p_round = 0;; ++p_round) {
+  const int vbid = PERSIST ? p_group + g.sync_groups * (p_slot + p_per_round * p_round) : (int)blockIdx.x;
+  if (PERSIST) {
+    if (vbid >= g.total_wgs) break;
+    // every wave is done with the previous tile's LDS staging; the group's workgroups of this round start together
+    if (threadIdx.x == 0) {
+      const int done = p_per_round * (p_round + 1);
+      group_arrive_wait(g.sync + p_group * 16, (unsigned)(done < p_in_group ? done : p_in_group));
+    }
+    raw_barrier();
+  }
   TAMD_CLOCK_BEGIN
   int tile_m, tile_n;
-  const int split = (EPI == kEpiSplitK) ? (int)(blockIdx.x % (unsigned)g.splits) : 0;
-  gemm_tile_of_block(g, (EPI == kEpiSplitK) ? (int)(blockIdx.x / (unsigned)g.splits) : (int)blockIdx.x, &tile_m, &tile_n);
+  const int split = (EPI == kEpiSplitK) ? (int)((unsigned)vbid % (unsigned)g.splits) : 0;
+  gemm_tile_of_block(g, (EPI == kEpiSplitK) ? (int)((unsigned)vbid / (unsigned)g.splits) : vbid, &tile_m, &tile_n);
   const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
@@ -622,24 +636,6 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096 + (int64_t)st0 * kinc_a;
   const int64_t nb0 = (EPI == kEpiSwiGLU) ? 0 : n0;  // SwiGLU: per-lane offsets address the whole fused weight
   const char* base_b = (const char*)(B_KN ? B + n0 : B + nb0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
-  // staggered K start (DBG & 16): stage issues left until the operand base wraps back to k = 0, and the wrap distance
-  int wrap_a = 0x7fffffff, wrap_b = 0x7fffffff;
-  int64_t wrap_bytes_a = 0, wrap_bytes_b = 0;
-#ifdef TAMD_DIAG
-  if (DBG & 16) {
-    const int mode = g.stagger & 15, units = (g.stagger >> 4) & 255, stride = g.stagger >> 12;
-    const int key = mode == 1 ? (int)(blockIdx.x & 7u) : mode == 2 ? tile_m : mode == 3 ? tile_n : tile_m + tile_n;
-    const int step = stride ? stride : (nst / (units > 0 ? units : 1) > 0 ? nst / (units > 0 ? units : 1) : 1);
-    const int soff = units > 0 ? (int)(((int64_t)(key % units) * step) % nst) : 0;
-    if (soff) {
-      base_a += soff * kinc_a;
-      base_b += soff * kinc_b;
-      wrap_a = wrap_b = nst - soff;
-      wrap_bytes_a = nst * kinc_a;
-      wrap_bytes_b = nst * kinc_b;
-    }
-  }
-#endif
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (wave * 8 + i) * 8 + (lane >> 3);
@@ -666,7 +662,6 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     base_b -= kinc_b;
     kinc_a = 0;
     kinc_b = 0;
-    wrap_a = wrap_b = 0x7fffffff;
   };
   const unsigned piece0 = (unsigned)wave * 8192u;  // this wave's first piece inside an operand stage
   bool dma_on = true;
@@ -680,14 +675,8 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
       case 2: glds16_buf<2048>(base, voff[p], smem, dst); break;
       default: glds16_buf<3072>(base, voff[p], smem, dst); break;
     }
-    if (p == 7) {  // every piece of the operand stage is out: step to the next stage
-      base_a += kinc_a;
-      if ((DBG & 16) && --wrap_a == 0) base_a -= wrap_bytes_a;
-    }
-    if (p == 15) {
-      base_b += kinc_b;
-      if ((DBG & 16) && --wrap_b == 0) base_b -= wrap_bytes_b;
-    }
+    if (p == 7) base_a += kinc_a;  // every piece of the operand stage is out: step to the next stage
+    if (p == 15) base_b += kinc_b;
   };
   // fragment offsets inside a half-slot (block t = 16 rows / columns of this wave's 128, k-step q = 32 of the stage's 64)
   //   row-major: one register per k-step, the block is the immediate t*2048;
@@ -737,12 +726,13 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
       fw[buf][r - 8] = frag_b(sb, q, r - 8);
   };
   // one k-step: 64 MFMAs from fragment buffer `buf` issued as 32 pairs, acc[nb][mb] with mb innermost (the W fragment
-  // stays on the MFMA's A port for 8 instructions); behind pair p < 16 fragment read p of the NEXT k-step (stage slots
-  // ra / rb, k-step rq, into the other buffer), behind the odd pairs 17..31 the LDS-DMA pieces pb .. pb+7 into half-slot
+  // stays on the MFMA's A port for 8 instructions); in the gaps between the pairs the 16 fragment reads of the NEXT
+  // k-step (stage slots ra / rb, k-step rq, into the other buffer) and the LDS-DMA pieces pb .. pb+7 into half-slot
   // ps -- one small group of feed instructions per gap, pinned with sched_barrier(0) so the matrix pipe (one wave per
-  // SIMD: nobody else fills it) never waits behind a clump of LDS / LDS-DMA issues.
-  // (placing the pieces behind every fourth pair instead, and staggering the four waves' piece gaps one pair apart, both
-  // measured +-1 %: profiles/r02i_gemm_piece_placement.jsonl)
+  // SIMD: nobody else fills it) never waits behind a clump of LDS / LDS-DMA issues.  EARLY: of the pairs 0..23 every
+  // third carries a piece, the other two a fragment read (the last read 9 pairs ahead of the hand-off's lgkmcnt(0));
+  // otherwise reads behind the pairs 0..15, pieces behind the odd pairs 17..31.
+  constexpr bool EARLY = ((!A_KM && !B_KN) || (DBG & 32)) && !(DBG & 128);
   auto kstep = [&](int buf, int ra, int rb, int rq, int pb, int ps) __attribute__((always_inline)) {
     kstep_open();
 #pragma unroll
@@ -750,11 +740,10 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
       const int nb = p >> 2, mb = (p & 3) * 2;
       acc[nb][mb] = mfma16<T>(fw[buf][nb], fx[buf][mb], acc[nb][mb]);
       acc[nb][mb + 1] = mfma16<T>(fw[buf][nb], fx[buf][mb + 1], acc[nb][mb + 1]);
-      if ((DBG & 64) && p == 16) raw_barrier();  // (diagnostic) the four waves enter the LDS-DMA half of the k-step together
       sched_fence();
-      if ((DBG & 32) && !A_KM && !B_KN) {  // early pieces: of the pairs 0..23 every third carries an LDS-DMA piece, the
-        if (p < 24 && p % 3 != 2) rd1(ra, rb, rq, buf ^ 1, p - p / 3);  // other two a fragment read (the last one 9 pairs
-        if (p < 24 && p % 3 == 2) issue(pb + p / 3, ps);                 // ahead of the hand-off's lgkmcnt(0))
+      if (EARLY) {
+        if (p < 24 && p % 3 != 2) rd1(ra, rb, rq, buf ^ 1, p - p / 3);
+        if (p < 24 && p % 3 == 2) issue(pb + p / 3, ps);
       } else {
         if (p < 16) rd1(ra, rb, rq, buf ^ 1, p);
         if (p >= 16 && (p & 1)) issue(pb + ((p - 17) >> 1), ps);
@@ -789,6 +778,15 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
         // hand-off: stage s+1 has landed for everybody; everybody's reads of stage s are in registers
         if (!(DBG & 4)) wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 newest (A_{s+2}) stay in flight
         wait_lgkmcnt0();
+        if (PERSIST == 2 && EPI != kEpiSplitK && (s % kSyncStages) == kSyncStages - 1 && s + 1 < nst) {
+          // re-align the XCD's workgroups inside the tile (the other waves wait at the hand-off barrier below)
+          if (threadIdx.x == 0) {
+            const int hpt = (nst - 1) / kSyncStages;  // hand-shakes per tile (every tile of a launch has nst stages)
+            const int before = p_per_round * p_round < p_in_group ? p_per_round * p_round : p_in_group;
+            const int here = p_in_group - before < p_per_round ? p_in_group - before : p_per_round;
+            group_arrive_wait(g.sync + p_group * 16 + 8, (unsigned)(hpt * before + here * (s / kSyncStages + 1)));
+          }
+        }
         if (!(DBG & 8)) raw_barrier();
         sched_fence();
         kstep(1, sa1, sb1, 0, 8, sb2);  // k-step 1 | first-half fragments of stage s+1 | B_{s+2} into the slot A_s vacated
@@ -799,9 +797,11 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   wait_lgkmcnt0();
   raw_barrier();
   TAMD_CLOCK_END
-  // (the epilogue takes its lane index from v_mbcnt: kept from the kernel entry it is spilled around the K loop in the
-  // k-major variants, and a kernel with scratch is throttled in how many of its waves a CU runs)
-  const int elane = (A_KM && B_KN) ? lane_id_mbcnt() : lane;
+  // (the epilogue takes its lane index from v_mbcnt: kept from the kernel entry it is spilled around the K loop, and a
+  // kernel with scratch is throttled in how many of its waves a CU runs)
+  // (... except the row-major residual epilogue, where it is the other way round: checked per instantiation with
+  // tools/gemm_isa.sh -- no product kernel of the Llama / BERT step has scratch)
+  const int elane = (EPI == TAMD_EPI_RESIDUAL && !(A_KM && B_KN)) ? lane : lane_id_mbcnt();
   if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per accumulator block
     float* ws = g.ws + (int64_t)split * g.M * g.N;
     const int l15 = elane & 15, g4 = elane >> 4;
@@ -816,15 +816,15 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
                                        f32_as_u32(acc[nb][mb][3])});
       }
     }
-    return;
-  }
-  if (EPI == kEpiSwiGLU) {
+  } else if (EPI == kEpiSwiGLU) {
     gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), m0 + wm * 128,
                             (n0 >> 1) + wn * 64, elane);
-    return;
+  } else {
+    gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
+        g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
   }
-  gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
-      g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+  if (!PERSIST) break;
+  }  // persistent walk
 }
 
 // out[m][n] = round(sum_s ws[s][m][n] (+ out[m][n] if ACCUM)): 4 columns per thread (16-byte reads, 8-byte stores)
@@ -869,9 +869,49 @@ static int gemm_diag_dbg() {
   return g_gemm_dbg;
 }
 #endif
-#ifdef TAMD_DIAG
-static int g_gemm_stagger = 0;  // tamd_gemm_set_stagger: packed like GemmArgs::stagger, 0 = off
+// Arrival counters of the persistent launches: a ring of slots in device memory, one per launch in flight (the host
+// hands them out round robin and zeroes a slot on the launch's own stream right before the kernel; 64 slots: 64 GEMMs of
+// this kind would have to be in flight on one device at once for two of them to share counters -- and sharing only
+// weakens the alignment, see group_arrive_wait).
+constexpr int kSyncSlots = 64, kSyncSlotWords = 16 * 16;  // up to 16 groups of 16 words
+__device__ unsigned g_gemm_sync[kSyncSlots * kSyncSlotWords];
+static unsigned* gemm_sync_slot(hipStream_t s) {
+#ifdef __HIPCC__
+  static unsigned* base[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+  if (base[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gemm_sync)) != hipSuccess) return nullptr;
+    base[dev] = reinterpret_cast<unsigned*>(p);
+  }
+  unsigned* b = base[dev];
+#else
+  unsigned* b = g_gemm_sync;  // (CPU execution model: `__device__` data is host data)
 #endif
+  static unsigned next = 0;
+  unsigned* slot = b + (size_t)(__atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % kSyncSlots) * kSyncSlotWords;
+  if (hipMemsetAsync(slot, 0, kSyncSlotWords * sizeof(unsigned), s) != hipSuccess) return nullptr;
+  return slot;
+}
+// workgroups of a persistent launch: one per CU (the kernel owns a CU: 160 KiB of LDS), in `groups` = 8 XCD groups
+static int gemm_persistent_grid(int* groups) {
+#ifdef __HIPCC__
+  static int cus[32] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+  if (cus[dev] == 0) {
+    hipDeviceProp_t prop;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+  }
+  *groups = 8;
+  return cus[dev] > 0 ? cus[dev] / 8 * 8 : 0;
+#else
+  *groups = 2;  // the CPU model runs one workgroup per OS thread: 2 groups of (threads / 2) so the barrier has partners
+  const int t = hipemu::launch_threads();
+  return t / 2 * 2;
+#endif
+}
 #define TAMD_EPI_SWITCH(LAUNCH)                                           \
   switch (epilogue) {                                                     \
     case TAMD_EPI_NONE: LAUNCH(TAMD_EPI_NONE, TAMD_ACT_NONE)              \
@@ -908,20 +948,37 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
   return gemm_pp_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
+// persistent launch of the plain / accumulate / split-K products (sched hint; see PERSIST at the kernel): falls back to
+// the plain launch (returns -1) when the grid would not be persistent anyway or the counters are not available
+template <typename T, bool A_KM, bool B_KN, int EPI>
+static int gemm_fl_launch_persist(const GemmArgs& g0, int persist, hipStream_t s) {
+  GemmArgs g = g0;
+  g.total_wgs = g.tiles_m * g.tiles_n * (EPI == kEpiSplitK ? g.splits : 1);
+  const int grid = gemm_persistent_grid(&g.sync_groups);
+  if (grid < 2 * g.sync_groups || g.total_wgs <= grid) return -1;
+  g.sync = gemm_sync_slot(s);
+  if (g.sync == nullptr) return -1;
+  if (persist == 2)
+    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, EPI, TAMD_ACT_NONE, 0, 2>), dim3((unsigned)grid), dim3(kFlThreads),
+                       (size_t)kXSmem, s, g);
+  else
+    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, EPI, TAMD_ACT_NONE, 0, 1>), dim3((unsigned)grid), dim3(kFlThreads),
+                       (size_t)kXSmem, s, g);
+  return launch_status();
+}
+
 template <typename T, bool A_KM, bool B_KN>
-static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
+static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, int persist, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
-#ifdef TAMD_DIAG  // ablation instantiations (wrong results by design): libtamd_diag.so only, never the product library
+  if (persist && (epilogue == TAMD_EPI_NONE || epilogue == TAMD_EPI_ACCUM)) {
+    const int rc = epilogue == TAMD_EPI_NONE ? gemm_fl_launch_persist<T, A_KM, B_KN, TAMD_EPI_NONE>(g, persist, s)
+                                             : gemm_fl_launch_persist<T, A_KM, B_KN, TAMD_EPI_ACCUM>(g, persist, s);
+    if (rc >= 0) return rc;
+  }
+#ifdef TAMD_DIAG  // ablation / A-B instantiations: libtamd_diag.so only, never the product library
   const int dbg = gemm_diag_dbg();
-  if (g_gemm_stagger && epilogue == TAMD_EPI_NONE) {  // staggered K start: every layout, plain epilogue, correct results
-    GemmArgs gs = g;
-    gs.stagger = g_gemm_stagger;
-    if (dbg == 32 && !A_KM && !B_KN)
-      hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, 48>), grid, block, (size_t)kXSmem, s, gs);
-    else if (dbg == 64 && !A_KM && !B_KN)
-      hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, 80>), grid, block, (size_t)kXSmem, s, gs);
-    else
-      hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 16>), grid, block, (size_t)kXSmem, s, gs);
+  if (dbg == 32 && epilogue == TAMD_EPI_NONE) {  // early piece placement in every layout (correct results)
+    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 32>), grid, block, (size_t)kXSmem, s, g);
     return launch_status();
   }
   if (dbg && epilogue == TAMD_EPI_NONE && !A_KM && !B_KN) {
@@ -936,8 +993,7 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       case 8: TAMD_GD(8)
       case 12: TAMD_GD(12)
       case 15: TAMD_GD(15)
-      case 32: TAMD_GD(32)
-      case 64: TAMD_GD(64)
+      case 128: TAMD_GD(128)
       default: break;
     }
 #undef TAMD_GD
@@ -952,9 +1008,10 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
 
 // split-K: partial tiles into the fp32 workspace, then the reduction (TAMD_EPI_NONE / TAMD_EPI_ACCUM only)
 template <typename T, bool A_KM, bool B_KN>
-static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, hipStream_t s) {
+static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, int persist, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(kFlThreads);
-  hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, kEpiSplitK, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem, s, g);
+  if (!persist || gemm_fl_launch_persist<T, A_KM, B_KN, kEpiSplitK>(g, 1, s) < 0)  // (no hand-shakes inside a split)
+    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, kEpiSplitK, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem, s, g);
   const int64_t nvec = g.M * (g.N / 4);
   int64_t blocks = ceil_div(nvec, 256);
   if (blocks > 4096) blocks = 4096;
@@ -968,21 +1025,21 @@ static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, hipStream_t s
 }
 
 template <typename T>
-static int gemm_fl_splitk_launch(const GemmArgs& g, int flags, int epilogue, hipStream_t s) {
+static int gemm_fl_splitk_launch(const GemmArgs& g, int flags, int epilogue, int persist, hipStream_t s) {
   const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
-  if (!akm && !bkn) return gemm_fl_splitk_launch2<T, false, false>(g, epilogue, s);
-  if (!akm && bkn) return gemm_fl_splitk_launch2<T, false, true>(g, epilogue, s);
-  if (akm && bkn) return gemm_fl_splitk_launch2<T, true, true>(g, epilogue, s);
-  return gemm_fl_splitk_launch2<T, true, false>(g, epilogue, s);
+  if (!akm && !bkn) return gemm_fl_splitk_launch2<T, false, false>(g, epilogue, persist, s);
+  if (!akm && bkn) return gemm_fl_splitk_launch2<T, false, true>(g, epilogue, persist, s);
+  if (akm && bkn) return gemm_fl_splitk_launch2<T, true, true>(g, epilogue, persist, s);
+  return gemm_fl_splitk_launch2<T, true, false>(g, epilogue, persist, s);
 }
 
 template <typename T>
-static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
+static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, int persist, hipStream_t s) {
   const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
-  if (!akm && !bkn) return gemm_fl_launch_epi<T, false, false>(g, epilogue, act, s);
-  if (!akm && bkn) return gemm_fl_launch_epi<T, false, true>(g, epilogue, act, s);
-  if (akm && bkn) return gemm_fl_launch_epi<T, true, true>(g, epilogue, act, s);
-  return gemm_fl_launch_epi<T, true, false>(g, epilogue, act, s);
+  if (!akm && !bkn) return gemm_fl_launch_epi<T, false, false>(g, epilogue, act, persist, s);
+  if (!akm && bkn) return gemm_fl_launch_epi<T, false, true>(g, epilogue, act, persist, s);
+  if (akm && bkn) return gemm_fl_launch_epi<T, true, true>(g, epilogue, act, persist, s);
+  return gemm_fl_launch_epi<T, true, false>(g, epilogue, act, persist, s);
 }
 
 }  // namespace tamd
@@ -992,11 +1049,6 @@ using namespace tamd;
 #ifdef TAMD_DIAG
 extern "C" int tamd_gemm_set_dbg(int dbg) {
   g_gemm_dbg = dbg;
-  return TAMD_OK;
-}
-extern "C" int tamd_gemm_set_stagger(int mode, int units, int stride_stages) {
-  if (mode < 0 || mode > 4 || units < 0 || units > 255 || stride_stages < 0 || stride_stages > 4095) return TAMD_E_ARG;
-  g_gemm_stagger = (mode && units > 1) ? (mode | units << 4 | stride_stages << 12) : 0;
   return TAMD_OK;
 }
 static unsigned long long* g_gemm_clock = nullptr;
@@ -1035,9 +1087,9 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->n_half = 0;
   g->seq = 1;
   g->cos_batch = 1;
-#ifdef TAMD_DIAG
-  g->stagger = 0;
-#endif
+  g->sync = nullptr;
+  g->sync_groups = 1;
+  g->total_wgs = g->tiles_m * g->tiles_n;
   return TAMD_OK;
 }
 
@@ -1087,6 +1139,20 @@ static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int epilogue, int
   return (int)ceil_div(nst, sps);  // no empty split
 }
 
+// Which products take the persistent, XCD-aligned walk without being asked (0 none, 1 aligned rounds, 2 + hand-shakes
+// inside a tile).  OFF until measured on MI355X (tools/gemm_persist_ab.py): TAMD_GEMM_PERSIST=1|2 in the environment
+// turns it on for the long-K products (K >= 128 stages) of more than one dispatch round.
+static int gemm_persist_policy(int64_t M, int64_t N, int64_t K, int flags, int epilogue) {
+  (void)flags;
+  static const int mode = [] {
+    const char* e = getenv("TAMD_GEMM_PERSIST");
+    return e ? atoi(e) : 0;
+  }();
+  if (mode <= 0 || (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM)) return 0;
+  if (K % kXK != 0 || K / kXK < 128) return 0;
+  return mode >= 2 ? 2 : 1;
+}
+
 extern "C" size_t tamd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags, int epilogue) {
   (void)flags;
   int sps;
@@ -1126,6 +1192,9 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
   }();
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
+  // persistent walk with XCD-aligned rounds (4) and hand-shakes inside the tiles (5): by hint, or by the policy below
+  int persist = sched == 4 ? 1 : (sched == 5 ? 2 : 0);
+  if (sched == 0) persist = gemm_persist_policy(M, N, K, flags, epilogue);
   if (sched != 1 && workspace != nullptr) {
     int sps;
     const int splits = gemm_choose_splits(M, N, K, epilogue, &sps);
@@ -1133,11 +1202,11 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
       g.ws = reinterpret_cast<float*>(workspace);
       g.splits = splits;
       g.stages_per_split = sps;
-      TAMD_DISPATCH_HALF(dtype, return (gemm_fl_splitk_launch<T>(g, flags, epilogue, TAMD_STREAM(stream))));
+      TAMD_DISPATCH_HALF(dtype, return (gemm_fl_splitk_launch<T>(g, flags, epilogue, persist, TAMD_STREAM(stream))));
     }
   }
   if (K % kXK == 0 && sched != 1) {
-    TAMD_DISPATCH_HALF(dtype, return (gemm_fl_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
+    TAMD_DISPATCH_HALF(dtype, return (gemm_fl_launch<T>(g, flags, epilogue, act, persist, TAMD_STREAM(stream))));
   } else {
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   }
@@ -1197,31 +1266,6 @@ extern "C" int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const 
   return TAMD_E_DTYPE;
 }
 
-// Backward of the SwiGLU product fused into the GEMM that produces its incoming gradient:
-//   d_act[M, I] = dY[M, K] . Wd[K, I]    (Wd = down_proj.weight stored [hidden = K, I]: the k-major B operand)
-//   d_gate | d_up -> DGU[M, 2I],  act = silu(gate) * up -> ACT[M, I] (re-materialised for the down_proj weight gradient)
-// from the saved gate|up GU[M, 2I]; d_act never reaches HBM.  Formulas and roundings of tamd_gemm (B_KN) followed by
-// tamd_swiglu_bwd: bit-identical results.
-extern "C" int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* DGU, void* ACT, int64_t M,
-                                    int64_t I, int64_t K, int64_t lddy, int64_t ldw, int64_t ldgu, int64_t lddgu,
-                                    int64_t ldact, int dtype, tamd_stream_t stream) {
-  if (!dY || !Wd || !GU || !DGU || !ACT) return TAMD_E_NULL;
-  if (M <= 0 || I <= 0 || K <= 0) return TAMD_E_SHAPE;
-  if ((K % kXK) || (I % 8) || (lddy % 8) || (ldw % 8) || (ldgu % 8) || (lddgu % 8) || (ldact % 8)) return TAMD_E_SHAPE;
-  if (!aligned16(dY) || !aligned16(Wd) || !aligned16(GU) || !aligned16(DGU) || !aligned16(ACT)) return TAMD_E_ALIGN;
-  GemmArgs g;
-  gemm_fill_args(&g, dY, Wd, DGU, nullptr, GU, M, I, K, lddy, ldw, lddgu, ldgu);
-  g.C2 = ACT;
-  g.ldc2 = ldact;
-  g.n_half = I;
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
-  TAMD_DISPATCH_HALF(dtype, {
-    hipLaunchKernelGGL((gemm_fl_kernel<T, false, true, kEpiSwiGLUBwd, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
-                       TAMD_STREAM(stream), g);
-    return launch_status();
-  });
-  return TAMD_E_DTYPE;
-}
 #else
 }  // namespace tamd
 #endif  // TAMD_GEMM_KERNELS_ONLY

@@ -236,6 +236,15 @@ __device__ __forceinline__ unsigned long long device_clock() { return __builtin_
 // constant-rate (100 MHz) counter: shader-clock ticks / real-time ticks = the clock a kernel actually ran at
 __device__ __forceinline__ unsigned long long device_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 
+// cross-workgroup arrival counters (gemm.hip, persistent walk): agent-scope atomics on global memory and a short nap
+__device__ __forceinline__ unsigned atomic_add_agent(unsigned* p, unsigned v) {
+  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned atomic_load_agent(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(8); }
+
 // fast transcendental pieces
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -24,11 +24,9 @@ T = torch.ops.tamd
 # instructions) is what TAMD_FUSE_ROPE_FWD=1 selects.  profiles/r02_gemm_variants.md section 7
 _FUSE_ROPE_FWD = os.environ.get("TAMD_FUSE_ROPE_FWD", "0") == "1"
 _FUSE_ROPE_BWD = os.environ.get("TAMD_FUSE_ROPE_BWD", "1") != "0"
-# SwiGLU backward in the d_act GEMM epilogue (tamd_gemm_swiglu_bwd): OFF by default.  The fused kernel is 0.2 ms per
-# layer faster than GEMM + swiglu_bwd on some runs (3.65 vs 3.87 ms) and 1.9 ms slower on others (5.7 ms; same binary,
-# same data -- the epilogue streams five large arrays in lockstep and its speed depends on where the run's buffers land
-# physically): 1292 vs 1359 ms per step measured back to back on one box.  profiles/r02_regression_note.md
-_FUSE_SWIGLU_BWD = os.environ.get("TAMD_FUSE_SWIGLU_BWD", "0") == "1"
+# (Round 2 also carried the SwiGLU backward as an epilogue of the d_act GEMM: 0.2 ms per layer faster than GEMM +
+# swiglu_bwd_kernel in its good regime, 1.9 ms slower in its bad one -- profiles/r02_regression_note.md -- and, with one
+# workgroup per CU, an epilogue that streams four large arrays has nothing to overlap with: removed in round 3.)
 # The SiLU*up product `act` [T, I] (the down projection's input, needed again for its weight gradient) is KEPT for the
 # backward instead of re-materialised there: the gate|up GEMM's epilogue writes it anyway, so keeping it costs no time
 # and T*I*2 bytes per layer (0.94 GB at the Llama-3-8B shape: 30 GB over 32 layers on a 288 GB part, peak 141 -> 171 GB),
@@ -98,15 +96,12 @@ def _llama_layer_bwd_impl(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqk
     x = ops._c(h_in).view(t, hd)
     dh = ops._c(d_hout).view(t, hd)
     # ---- MLP
-    if _FUSE_SWIGLU_BWD and ops.gemm_swiglu_bwd_supported(dh, wd, gu):  # d_act = dh . Wd with the SwiGLU backward in its epilogue
-        d_gu, act = ops.raw_gemm_swiglu_bwd(dh, wd, gu)
+    d_act = ops.raw_gemm(dh, wd, b_kn=True)                                  # [T, I]
+    if act_saved.numel():
+        d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=False)[0], act_saved
     else:
-        d_act = ops.raw_gemm(dh, wd, b_kn=True)                              # [T, I]
-        if act_saved.numel():
-            d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=False)[0], act_saved
-        else:
-            d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
-        del d_act
+        d_gu, act = ops.raw_swiglu_bwd(gu, d_act, want_act=True)
+    del d_act
     dwd = ops.raw_gemm(dh, act, a_km=True, b_kn=True)                        # [hd, I]
     del act
     d_xn2 = ops.raw_gemm(d_gu, wgu, b_kn=True)                               # [T, hd]
@@ -185,3 +180,163 @@ def llama_layer(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo,
     train = ops._wants_grad(h_in, w_ln1, wq, wk, wv, wo, w_ln2, wg, wu, wd)
     return T.llama_layer(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo, w_ln2, wgu, wg, wu, wd,
                          float(eps), int(hq), int(hkv), int(d), float(scale), bool(causal), train)[0]
+
+
+# ============================================================================================ BertLayer as one op
+# tamd::bert_layer / tamd::bert_layer_bwd    BertLayer.forward (encoder layer: BertAttention -> BertIntermediate ->
+# BertOutput), models/bert/modeling_bert.py:164-203, 289-293, 334-351, 374-416.  Post-LN blocks with biases:
+#     y1 = dropout(attn_out . Wo^T + bo) + x ;   h1 = LayerNorm1(y1)
+#     y2 = dropout(act(h1 . Wi^T + bi) . Wo2^T + bo2) + h1 ;   out = LayerNorm2(y2)
+# forward : fused q|k|v GEMM(+bias) -> attention (dropout inside) -> dense GEMM -> [dropout+]add+LayerNorm -> GEMM(+bias[,
+#           +act]) -> dense GEMM -> [dropout+]add+LayerNorm.  Without hidden dropout the residual adds ride in the dense
+#           GEMMs' epilogues; with it the add joins the dropout + LayerNorm kernel.
+# backward: the same chain reversed; the two places where a tensor feeds both a projection and a residual (x, h1) get their
+#           gradient sum from the residual epilogue of the dX GEMM -- as separate ops autograd adds them (49 `at::add`
+#           launches per bert-base step, 4 % of it) and rebuilds d_qkv from three slices (36 fills + copies).
+def _bert_layer_impl(h_in, key_valid, wqkv, bqkv, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w,
+                     ln2_b, eps, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train):
+    b, s, hd = h_in.shape
+    t = b * s
+    x = ops._c(h_in).view(t, hd)
+    qkv = ops.raw_gemm(x, wqkv, bias=bqkv, epilogue=ops.EPI_BIAS)
+    q, k, v = _split_qkv(qkv, b, s, heads, heads, d)
+    o, lse = ops.raw_attn_fwd(q, k, v, scale, False, key_valid, need_lse=train, dropout_p=p_attn, seed=seed_attn)
+    o2 = o.view(t, hd)
+
+    def dense_add_ln(inp, w, bias, res, ln_w, ln_b, seed):
+        if p_hidden > 0.0:
+            a = ops.raw_gemm(inp, w, bias=bias, epilogue=ops.EPI_BIAS)
+            return ops.raw_layernorm_dropout_fwd(a, ln_w, ln_b, eps, res, p_hidden, seed)   # (y, pre-norm sum, mean, rstd)
+        y = ops.raw_gemm(inp, w, bias=bias, residual=res, epilogue=EPI_RESIDUAL)
+        out, _, mean, rstd = ops.raw_layernorm_fwd(y, ln_w, ln_b, eps)
+        return out, y, mean, rstd
+
+    h1, y1, mean1, rstd1 = dense_add_ln(o2, wo, bo, x, ln1_w, ln1_b, seed1)
+    if train:  # the pre-activation is what the activation's backward needs
+        pre = ops.raw_gemm(h1, wi, bias=bi, epilogue=ops.EPI_BIAS)
+        inter = ops.raw_bias_act_fwd(pre, None, act)
+    else:
+        pre = h_in.new_empty(0)
+        inter = ops.raw_gemm(h1, wi, bias=bi, epilogue=ops.EPI_BIAS_ACT, act=act)
+    out, y2, mean2, rstd2 = dense_add_ln(inter, wo2, bo2, h1, ln2_w, ln2_b, seed2)
+    out = out.view(b, s, hd)
+    if not train:
+        e = h_in.new_empty(0)
+        return (out,) + tuple(e.clone() for _ in range(12))
+    return out, qkv, o, lse, y1, mean1, rstd1, h1, pre, inter, y2, mean2, rstd2
+
+
+def _bert_layer_fake(h_in, key_valid, wqkv, bqkv, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w,
+                     ln2_b, eps, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train):
+    b, s, hd = h_in.shape
+    t = b * s
+    out = h_in.new_empty(b, s, hd)
+    if not train:
+        return (out,) + tuple(h_in.new_empty(0) for _ in range(12))
+    f32 = dict(dtype=torch.float32)
+    return (out, h_in.new_empty(t, 3 * hd), h_in.new_empty(b, s, heads, d), h_in.new_empty(b, heads, s, **f32),
+            h_in.new_empty(t, hd), h_in.new_empty(t, **f32), h_in.new_empty(t, **f32), h_in.new_empty(t, hd),
+            h_in.new_empty(t, wi.shape[0]), h_in.new_empty(t, wi.shape[0]), h_in.new_empty(t, hd),
+            h_in.new_empty(t, **f32), h_in.new_empty(t, **f32))
+
+
+def _bert_layer_bwd_impl(d_out, h_in, key_valid, wqkv, wo, ln1_w, wi, wo2, ln2_w, qkv, o, lse, y1, mean1, rstd1, h1, pre,
+                         inter, y2, mean2, rstd2, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2):
+    b, s, hd = h_in.shape
+    t = b * s
+    x = ops._c(h_in).view(t, hd)
+    dy = ops._c(d_out).view(t, hd)
+
+    def ln_bwd(g, y, ln_w, mean, rstd, seed):  # -> (gradient of the residual input, of the dense output, dw, db)
+        if p_hidden > 0.0:
+            return ops.raw_layernorm_dropout_bwd(g, y, ln_w, mean, rstd, p_hidden, seed)
+        dx, dw, db = ops.raw_layernorm_bwd(g, y, ln_w, mean, rstd)
+        return dx, dx, dw, db
+
+    # ---- BertOutput / BertIntermediate
+    d_h1_res, d_b, dw_ln2, db_ln2 = ln_bwd(dy, y2, ln2_w, mean2, rstd2, seed2)
+    dbo2 = ops.raw_colsum(d_b)
+    dwo2 = ops.raw_gemm(d_b, inter, a_km=True, b_kn=True)                    # [hd, I]
+    d_inter = ops.raw_gemm(d_b, wo2, b_kn=True)                              # [T, I]
+    d_pre = ops.raw_bias_act_bwd(pre, None, d_inter, act)
+    del d_inter
+    dbi = ops.raw_colsum(d_pre)
+    dwi = ops.raw_gemm(d_pre, h1, a_km=True, b_kn=True)                      # [I, hd]
+    d_h1 = ops.raw_gemm(d_pre, wi, b_kn=True, residual=d_h1_res, epilogue=EPI_RESIDUAL)  # + the residual path's gradient
+    del d_pre
+    # ---- BertSelfOutput / BertSelfAttention
+    d_x_res, d_a, dw_ln1, db_ln1 = ln_bwd(d_h1, y1, ln1_w, mean1, rstd1, seed1)
+    dbo = ops.raw_colsum(d_a)
+    dwo = ops.raw_gemm(d_a, o.view(t, hd), a_km=True, b_kn=True)
+    d_o = ops.raw_gemm(d_a, wo, b_kn=True)
+    d_qkv = torch.empty_like(qkv)
+    q, k, v = _split_qkv(qkv, b, s, heads, heads, d)
+    dq, dk, dv = _split_qkv(d_qkv, b, s, heads, heads, d)
+    ops.raw_attn_bwd(q, k, v, o, lse, d_o.view(b, s, heads, d), scale, False, key_valid, dq=dq, dk=dk, dv=dv,
+                     dropout_p=p_attn, seed=seed_attn)
+    del d_o
+    dbqkv = ops.raw_colsum(d_qkv)
+    dwqkv = ops.raw_gemm(d_qkv, x, a_km=True, b_kn=True)                     # [3 hd, hd]
+    d_x = ops.raw_gemm(d_qkv, wqkv, b_kn=True, residual=d_x_res, epilogue=EPI_RESIDUAL)
+    return (d_x.view(b, s, hd), dwqkv, dbqkv, dwo, dbo, dw_ln1, db_ln1, dwi, dbi, dwo2, dbo2, dw_ln2, db_ln2)
+
+
+def _bert_layer_bwd_fake(d_out, h_in, key_valid, wqkv, wo, ln1_w, wi, wo2, ln2_w, qkv, o, lse, y1, mean1, rstd1, h1, pre,
+                         inter, y2, mean2, rstd2, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2):
+    vec = lambda w: w.new_empty(w.shape[0])  # noqa: E731
+    return (torch.empty_like(h_in, memory_format=torch.contiguous_format), torch.empty_like(wqkv), vec(wqkv),
+            torch.empty_like(wo), vec(wo), torch.empty_like(ln1_w), torch.empty_like(ln1_w), torch.empty_like(wi), vec(wi),
+            torch.empty_like(wo2), vec(wo2), torch.empty_like(ln2_w), torch.empty_like(ln2_w))
+
+
+def _bert_layer_setup(ctx, inputs, output):
+    (h_in, key_valid, wqkv, _bqkv, _wq, _wk, _wv, _bq, _bk, _bv, wo, _bo, ln1_w, _ln1_b, wi, _bi, wo2, _bo2, ln2_w, _ln2_b,
+     _eps, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train) = inputs
+    _out, qkv, o, lse, y1, mean1, rstd1, h1, pre, inter, y2, mean2, rstd2 = output
+    ctx.save_for_backward(h_in, key_valid, wqkv, wo, ln1_w, wi, wo2, ln2_w, qkv, o, lse, y1, mean1, rstd1, h1, pre, inter,
+                          y2, mean2, rstd2)
+    ctx.meta = (heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train)
+    ctx.set_materialize_grads(False)
+
+
+def _bert_layer_backward(ctx, d_out, *_aux):
+    none = (None,) * 31
+    if d_out is None:
+        return none
+    heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train = ctx.meta
+    if not train:
+        raise ops.TamdError("bert_layer was run with train=False but is being differentiated")
+    (d_x, dwqkv, dbqkv, dwo, dbo, dw_ln1, db_ln1, dwi, dbi, dwo2, dbo2, dw_ln2, db_ln2) = T.bert_layer_bwd(
+        d_out, *ctx.saved_tensors, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2)
+    hd = dwqkv.shape[1]
+    #       h_in kv    wqkv  bqkv  wq          wk                wv              bq          bk                bv
+    return (d_x, None, None, None, dwqkv[:hd], dwqkv[hd:2 * hd], dwqkv[2 * hd:], dbqkv[:hd], dbqkv[hd:2 * hd], dbqkv[2 * hd:],
+            dwo, dbo, dw_ln1, db_ln1, dwi, dbi, dwo2, dbo2, dw_ln2, db_ln2) + none[20:]
+
+
+define_op("bert_layer(Tensor h_in, Tensor? key_valid, Tensor wqkv, Tensor bqkv, Tensor wq, Tensor wk, Tensor wv, Tensor bq, "
+          "Tensor bk, Tensor bv, Tensor wo, Tensor bo, Tensor ln1_w, Tensor ln1_b, Tensor wi, Tensor bi, Tensor wo2, "
+          "Tensor bo2, Tensor ln2_w, Tensor ln2_b, float eps, int heads, int d, float scale, int act, float p_attn, "
+          "float p_hidden, int seed_attn, int seed1, int seed2, bool train) -> (Tensor, Tensor, Tensor, Tensor, Tensor, "
+          "Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+          _bert_layer_impl, _bert_layer_fake, _bert_layer_backward, _bert_layer_setup)
+define_op("bert_layer_bwd(Tensor d_out, Tensor h_in, Tensor? key_valid, Tensor wqkv, Tensor wo, Tensor ln1_w, Tensor wi, "
+          "Tensor wo2, Tensor ln2_w, Tensor qkv, Tensor o, Tensor lse, Tensor y1, Tensor mean1, Tensor rstd1, Tensor h1, "
+          "Tensor pre, Tensor inter, Tensor y2, Tensor mean2, Tensor rstd2, int heads, int d, float scale, int act, "
+          "float p_attn, float p_hidden, int seed_attn, int seed1, int seed2) -> (Tensor, Tensor, Tensor, Tensor, Tensor, "
+          "Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)",
+          _bert_layer_bwd_impl, _bert_layer_bwd_fake)
+
+
+def bert_layer(h_in, key_valid, wqkv, bqkv, members, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w, ln2_b, *, eps, heads, d,
+               scale, act, p_attn, p_hidden):
+    """BertLayer.forward (encoder layer) as one op.  `wqkv` / `bqkv` are the fused buffers the query / key / value
+    parameters `members` = (wq, wk, wv, bq, bk, bv) are row-slice views of (fused_params.py).  Dropout seeds come from
+    torch's CPU generator (ops.dropout_seed): `torch.manual_seed` repeats them, checkpointing regenerates them."""
+    wq, wk, wv, bq, bk, bv = members
+    train = ops._wants_grad(h_in, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w, ln2_b)
+    seed_attn = ops.dropout_seed() if p_attn > 0.0 else 0
+    seed1, seed2 = (ops.dropout_seed(), ops.dropout_seed()) if p_hidden > 0.0 else (0, 0)
+    return T.bert_layer(h_in, key_valid, wqkv, bqkv, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w,
+                        ln2_b, float(eps), int(heads), int(d), float(scale), int(act), float(p_attn), float(p_hidden),
+                        int(seed_attn), int(seed1), int(seed2), train)[0]

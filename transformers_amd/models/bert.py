@@ -11,9 +11,9 @@ from __future__ import annotations
 import torch
 from transformers.models.bert import modeling_bert as ref
 
-from .. import ops
+from .. import layer_ops, ops
 from ..fused_params import FusedWeights, PaddedRows
-from .common import _gpu, note_fallback
+from .common import _gpu, _has_hooks, note_fallback
 
 
 def _no_dropout(mod) -> bool:
@@ -101,6 +101,54 @@ class TamdBertIntermediate(ref.BertIntermediate):
             note_fallback(self, hidden_states)
             return super().forward(hidden_states)
         return ops.linear(hidden_states, self.dense.weight, self.dense.bias, act=ops.ACT_CODES[act])
+
+
+class TamdBertLayer(ref.BertLayer):
+    """BertLayer.forward, modeling_bert.py:374-416, as ONE dispatcher op / autograd node (torch.ops.tamd.bert_layer) for the
+    encoder case: no cross-attention, no KV cache, no feed-forward chunking.  Everything else -- and any layer whose
+    children are hooked or ask for attention weights -- takes the reference's forward over the replacement children."""
+
+    def _fused_ok(self, hidden_states, past_key_values, kwargs) -> bool:
+        att = self.attention
+        sa, so, inter, out = att.self, att.output, self.intermediate, self.output
+        return (type(sa) is TamdBertSelfAttention and type(so) is TamdBertSelfOutput
+                and type(inter) is TamdBertIntermediate and type(out) is TamdBertOutput
+                and _gpu(hidden_states) and hidden_states.dtype in (torch.bfloat16, torch.float16)
+                and past_key_values is None and not self.is_decoder and self.chunk_size_feed_forward == 0
+                and sa.attention_head_size in (64, 128) and sa.config._attn_implementation == "tamd"
+                and not kwargs.get("output_attentions", False) and sa.query.bias is not None
+                and so.dense.bias is not None and inter.dense.bias is not None and out.dense.bias is not None
+                and sa.query.weight.dtype == hidden_states.dtype
+                and ops.ACT_CODES.get(_act_name(inter, "_tamd_act", inter.intermediate_act_fn), ops.ACT_NONE) != ops.ACT_NONE
+                and so.dropout.p == out.dropout.p
+                and not _has_hooks(att, sa, so, inter, out, so.LayerNorm, out.LayerNorm))
+
+    def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
+                past_key_values=None, **kwargs):
+        if encoder_hidden_states is not None or not self._fused_ok(hidden_states, past_key_values, kwargs):
+            # (the children are replacement classes themselves: this level only loses the epilogue fusions)
+            note_fallback(self, hidden_states, "kv_cache" if past_key_values is not None else "layer_unfused")
+            return super().forward(hidden_states, attention_mask=attention_mask,
+                                   encoder_hidden_states=encoder_hidden_states,
+                                   encoder_attention_mask=encoder_attention_mask, past_key_values=past_key_values, **kwargs)
+        att = self.attention
+        sa, so, inter, out = att.self, att.output, self.intermediate, self.output
+        b, s, _ = hidden_states.shape
+        key_valid = None
+        if attention_mask is not None:
+            from ..attention import _key_valid_from_mask
+            key_valid = _key_valid_from_mask(attention_mask, b, s)
+        fw = sa._fused()
+        wqkv, bqkv = fw.weight(), fw.bias()
+        train = self.training
+        return layer_ops.bert_layer(
+            hidden_states, key_valid, wqkv, bqkv,
+            (sa.query.weight, sa.key.weight, sa.value.weight, sa.query.bias, sa.key.bias, sa.value.bias),
+            so.dense.weight, so.dense.bias, so.LayerNorm.weight, so.LayerNorm.bias, inter.dense.weight, inter.dense.bias,
+            out.dense.weight, out.dense.bias, out.LayerNorm.weight, out.LayerNorm.bias, eps=so.LayerNorm.eps,
+            heads=sa.num_attention_heads, d=sa.attention_head_size, scale=sa.scaling,
+            act=ops.ACT_CODES[_act_name(inter, "_tamd_act", inter.intermediate_act_fn)],
+            p_attn=sa.dropout.p if train else 0.0, p_hidden=so.dropout.p if train else 0.0)
 
 
 class TamdBertEmbeddings(ref.BertEmbeddings):
@@ -213,6 +261,7 @@ def masked_lm_forward(self, input_ids=None, attention_mask=None, token_type_ids=
 
 
 REPLACEMENTS = {
+    ref.BertLayer: TamdBertLayer,
     ref.BertPredictionHeadTransform: TamdBertPredictionHeadTransform,
     ref.BertLMPredictionHead: TamdBertLMPredictionHead,
     ref.BertSelfAttention: TamdBertSelfAttention,

@@ -122,8 +122,15 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
         attn, mlp = self.self_attn, self.mlp
         b, s, _ = hidden_states.shape
         cos, sin = position_embeddings
+        stack = self.__dict__.get("_tamd_stack")  # (graph_stack.LlamaStackGraph, index of this layer), set by accelerate()
+        if stack is not None and stack[1] > 0 and stack[0].passthrough(hidden_states):
+            return hidden_states  # layer 0 replayed the whole stack as one HIP graph: this IS the final hidden state
         from ..attention import split_mask
         key_valid, q_start = split_mask(attention_mask, b, s)
+        if stack is not None and stack[1] == 0 and not self.training:
+            out = stack[0].run(hidden_states, cos, sin, key_valid, q_start)
+            if out is not None:
+                return out
         qkv, gu = attn._fused(), mlp._fused()
         return layer_ops.llama_layer(
             hidden_states, cos, sin, key_valid, q_start, self.input_layernorm.weight, qkv.weight(),

@@ -476,7 +476,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int) -> int:
     return -(-nst // sps) * m * n * 4
 
 
-GEMM_SCHED = {None: 0, "pp": 1 << 8, "fl": 3 << 8}  # diagnostic schedule hints (include/tamd.h)
+GEMM_SCHED = {None: 0, "pp": 1 << 8, "fl": 3 << 8, "fl_persist": 4 << 8, "fl_persist_sync": 5 << 8}  # include/tamd.h
 
 
 @_device_guard
@@ -580,28 +580,6 @@ def raw_gemm_swiglu(x2, wgu, need_gu=True):
     be.lib.check(be.lib.tamd_gemm_swiglu(_p(x2), _p(wgu), _p(gu), _p(act), t, inter, k, x2.stride(0), wgu.stride(0),
                                          2 * inter, inter, _code(x2), be.stream(x2)), "tamd_gemm_swiglu")
     return gu, act
-
-
-@_device_guard
-def raw_gemm_swiglu_bwd(dy2, wd, gu):
-    """dy2 [T, hd], wd [hd, I] (down_proj.weight as stored), gu [T, 2I] saved gate|up  ->  (d_gu [T, 2I], act [T, I]):
-    d_act = dy2 . wd never reaches HBM (the SwiGLU backward runs in that GEMM's epilogue)."""
-    be = _prep(dy2, wd, gu)
-    t, hd = dy2.shape
-    inter = wd.shape[1]
-    dgu = torch.empty_like(gu)
-    act = torch.empty(t, inter, dtype=gu.dtype, device=gu.device)
-    be.lib.check(be.lib.tamd_gemm_swiglu_bwd(_p(dy2), _p(wd), _p(gu), _p(dgu), _p(act), t, inter, hd, dy2.stride(0),
-                                             wd.stride(0), gu.stride(0), dgu.stride(0), inter, _code(gu),
-                                             be.stream(gu)), "tamd_gemm_swiglu_bwd")
-    return dgu, act
-
-
-def gemm_swiglu_bwd_supported(dy2, wd, gu) -> bool:
-    hd, inter = wd.shape
-    return (gu.dtype in (torch.bfloat16, torch.float16) and dy2.dtype == gu.dtype and wd.dtype == gu.dtype
-            and hd % 64 == 0 and inter % 8 == 0 and gu.shape[1] == 2 * inter and gu.is_contiguous()
-            and dy2.stride(1) == 1 and wd.stride(1) == 1 and dy2.stride(0) % 8 == 0 and wd.stride(0) % 8 == 0)
 
 
 def _attn_params(q, k, v, o, lse, key_valid, scale, causal, dropout_p=0.0, seed=0, q_start=None):
@@ -879,10 +857,6 @@ def _gemm_swiglu_impl(x2, wgu, need_gu=True):
 define_op("gemm_swiglu(Tensor x2, Tensor wgu, bool need_gu=True) -> (Tensor, Tensor)", _gemm_swiglu_impl,
           lambda x2, wgu, need_gu=True: (x2.new_empty(x2.shape[0], wgu.shape[0]) if need_gu else _nothing(x2),
                                          x2.new_empty(x2.shape[0], wgu.shape[0] // 2)))
-
-
-define_op("gemm_swiglu_bwd(Tensor dy2, Tensor wd, Tensor gu) -> (Tensor, Tensor)", raw_gemm_swiglu_bwd,
-          lambda dy2, wd, gu: (torch.empty_like(gu), gu.new_empty(gu.shape[0], wd.shape[1])))
 
 
 def _attn_fwd_impl(q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None):

@@ -84,6 +84,9 @@ def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bo
         pad = getattr(m, "_padded", None)
         if callable(pad) and all(p.is_cuda for p in m.parameters(recurse=True)):
             pad().buffers()
+    from . import graph_stack
+
+    graph_stack.attach(model)  # forward-only calls of a whole decoder stack replay one HIP graph (graph_stack.py)
     if fuse_loss and getattr(model, "loss_type", None) == "ForCausalLM":
         from .ops import causal_lm_loss
 
@@ -115,4 +118,7 @@ def revert(model: nn.Module) -> nn.Module:
     if isinstance(getattr(model, "loss_function", None), _LossDispatch):
         model.loss_function = model.loss_function.reference
     model.__dict__.pop("forward", None)  # the instance-level fused forward, if installed
+    from . import graph_stack
+
+    graph_stack.detach(model)
     return model
