@@ -109,77 +109,35 @@ def gemm_traffic():
 
 
 class GemmTimer:
-    """HIP-event timing of every MFMA-GEMM launch inside the timed region (stream = torch's current stream,
-    which is the stream the C-ABI launches on)."""
+    """HIP-event timing of every MFMA-GEMM launch inside the timed region.  The launches are issued by the compiled ops
+    (csrc/torch_binding.cpp), so the event pairs are recorded there -- on the launch stream, around each tamd_gemm /
+    tamd_gemm_swiglu / tamd_gemm_rope call -- and read back through transformers_amd._native."""
 
     def __init__(self):
-        self.records = []
-        self.enabled = False
+        self._on = False
+        self._summary = None
+
+    @property
+    def enabled(self):
+        return self._on
+
+    @enabled.setter
+    def enabled(self, on):
+        from transformers_amd import _native
+
+        if on and not self._on:
+            _native.gemm_log(True)
+        elif not on and self._on:
+            _native.gemm_log(False)
+            self._summary = _native.gemm_log_summary()
+        self._on = bool(on)
 
     def install(self):
-        import torch
-
-        from transformers_amd import ops
-
-        inner = ops.raw_gemm
-        timer = self
-
-        def timed_gemm(a, b, *, a_km=False, b_kn=False, **kw):
-            if not timer.enabled:
-                return inner(a, b, a_km=a_km, b_kn=b_kn, **kw)
-            (k, m) = a.shape if a_km else (a.shape[1], a.shape[0])
-            n = b.shape[1] if b_kn else b.shape[0]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = inner(a, b, a_km=a_km, b_kn=b_kn, **kw)
-            e.record()
-            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n)))
-            return out
-
-        # every caller (the torch.ops implementations in ops.py / layer_ops.py) looks `raw_gemm` up at call time
-        ops.raw_gemm = timed_gemm
-        # the gate|up GEMM with the SwiGLU product in its epilogue (same kernel, own entry point)
-        inner_sw = ops.raw_gemm_swiglu
-
-        def timed_swiglu(x2, wgu, need_gu=True):
-            if not timer.enabled:
-                return inner_sw(x2, wgu, need_gu)
-            (m, k), n = x2.shape, wgu.shape[0]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = inner_sw(x2, wgu, need_gu)
-            e.record()
-            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n * (1.5 if need_gu else 0.5))))
-            return out
-
-        ops.raw_gemm_swiglu = timed_swiglu
-        inner_rope = getattr(ops, "raw_gemm_rope", None)
-
-        def timed_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim):
-            if not timer.enabled:
-                return inner_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim)
-            (m, k), n = x2.shape, wqkv.shape[0]
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = inner_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim)
-            e.record()
-            timer.records.append((2.0 * m * n * k, s, e, 2.0 * (m * k + n * k + m * n)))
-            return out
-
-        if inner_rope is not None:
-            ops.raw_gemm_rope = timed_rope
+        pass
 
     def summary(self):
-        if not self.records:
-            return None
-        fl = sum(r[0] for r in self.records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        kinds = {}
-        for r in self.records:
-            if len(r) > 4:
-                kinds.setdefault(r[4], []).append(r[1].elapsed_time(r[2]))
-        return dict(launches=len(self.records), flops=fl, ms=ms, bytes=sum(r[3] for r in self.records),
-                    kinds={k: sum(v) / len(v) for k, v in kinds.items()})
+        s = self._summary
+        return s if s and s["launches"] else None
 
 
 def clock_probe(dev, m=32768, n=28672, k=4096):
@@ -259,10 +217,12 @@ def cpu_baseline(model_cfg, seq, layers, threads=None, iters=3):
                         f"{layers} layers extrapolated; embedding/lm_head/loss excluded"))
 
 
-def cpu_baseline_bert(batch, seq, sample_batch=8, threads=None, iters=2):
+def cpu_baseline_bert(batch, seq, sample_batch=1, threads=None, iters=1):
     """Reference eager path on the host cores for BASELINE config 2: the reference's own BertForMaskedLM (bert-base-uncased
     architecture, random init, bf16, train mode, eager attention) fwd+bwd on a `sample_batch` x seq slice of the workload
-    (every sequence is independent: tokens/s does not depend on the batch beyond cache effects)."""
+    (every sequence is independent: tokens/s does not depend on the batch beyond cache effects).  The sample is ONE sequence:
+    the reference's bf16 path ran 33 tokens/s on the GPU box's 256 host cores in round 3 (profiles/r03b_bench_bert_cpu.json:
+    123 s per 8 x 512 step), so one sequence is the ~15 s budget."""
     import torch
     from transformers import BertConfig, BertForMaskedLM
 
@@ -279,7 +239,10 @@ def cpu_baseline_bert(batch, seq, sample_batch=8, threads=None, iters=2):
         model(input_ids=ids, labels=labels).loss.backward()
         model.zero_grad(set_to_none=True)
 
-    step()  # warm-up (allocator, thread pool)
+    ids_full, labels_full = ids, labels
+    ids, labels = ids_full[:, :32], labels_full[:, :32]
+    step()  # warm-up (allocator, thread pool) on a short sequence
+    ids, labels = ids_full, labels_full
     times = []
     for _ in range(iters):
         t0 = time.perf_counter()
@@ -511,7 +474,7 @@ def main():
                             avg_launch_ms=gs["ms"] / gs["launches"],
                             avg_launch_tflop=gs["flops"] / gs["launches"] / 1e12,
                             avg_launch_algorithmic_bytes=gs["bytes"] / gs["launches"],
-                            gemm_share_of_step_time=gs["ms"] * 1e-3 / dt, avg_ms_by_kind=gs.get("kinds"))
+                            gemm_share_of_step_time=gs["ms"] * 1e-3 / dt)
         line = {
             "metric": metric,
             "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -204,12 +204,7 @@ enum tamd_gemm_flags {
   /* diagnostic schedule hints (A/B measurements, tests); 0 = library default (full-line kernel when K % 64 == 0,
    * else ping-pong).  A hint that does not apply to K is ignored. */
   TAMD_GEMM_SCHED_PP = 1 << 8, /* 8-wave ping-pong kernel, 32-deep stages (every layout, any K)                */
-  TAMD_GEMM_SCHED_FL = 3 << 8, /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
-  /* the full-line kernel as one persistent workgroup per CU whose XCD groups start every dispatch round together
-   * (plain / accumulate epilogues and split-K; other calls ignore the hint), _SYNC: and re-align every 64 stages
-   * inside a tile.  Same results as TAMD_GEMM_SCHED_FL bit for bit. */
-  TAMD_GEMM_SCHED_FL_PERSIST = 4 << 8,
-  TAMD_GEMM_SCHED_FL_PERSIST_SYNC = 5 << 8
+  TAMD_GEMM_SCHED_FL = 3 << 8  /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
 };
 enum tamd_gemm_epilogue {
   TAMD_EPI_NONE = 0,

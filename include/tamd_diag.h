@@ -22,9 +22,9 @@ int tamd_gemm_set_clock_buffer(void* buf);
 
 /* Ablation / A-B selector for the full-line GEMM kernel (plain epilogue).  Row-major operands, WRONG RESULTS by design:
  * bit mask 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier
- * (supported: 1, 2, 4, 8, 12, 15; tools/gemm_fl_dbg.py).  CORRECT, bit-identical results: 32 = the early LDS-DMA piece
- * placement (the product schedule of the row-major layout) in every layout, 128 = the late placement of round 2 for
- * row-major operands (tools/gemm_persist_ab.py). */
+ * (supported: 1, 2, 4, 8, 12, 15; tools/gemm_fl_dbg.py).  CORRECT, bit-identical results, every layout: 32 = the early
+ * LDS-DMA piece placement (the product schedule whenever A is row-major), 128 = the late placement (the product
+ * schedule of the dW layout).  tools/gemm_piece_ab.py */
 int tamd_gemm_set_dbg(int dbg);
 
 /* Phase trace of the attention forward kernel: while `buf` (uint64[32], device memory) is set, workgroup 0 of every

@@ -563,7 +563,7 @@ def test_attention_packed_sequences(env):
                                       scale, True, None)
                 assert rel_err(o[:1, st:st + ln], alone) < 0.0038
             st += ln
-    with pytest.raises(ops.TamdError):  # packing is a causal notion
+    with pytest.raises(RuntimeError, match="tamd"):  # packing is a causal notion (refused by the compiled op)
         ops.attention(q.detach(), k.detach(), v.detach(), scale, False, None, q_start=q_start)
 
 
@@ -678,7 +678,7 @@ def test_gemm_rope_epilogue_is_bit_identical_to_unfused(env):
                 cos, sin = cos[0], sin[0]
             if cos.dim() == 2 and s < 128:
                 assert not ops.gemm_rope_supported(x, w, cos, d)
-                with pytest.raises(ops.TamdError):
+                with pytest.raises(RuntimeError, match="tamd"):
                     ops.raw_gemm_rope(x, w, cos, sin, s, hq + hkv, d)
                 continue
             assert ops.gemm_rope_supported(x, w, cos, d)
@@ -740,55 +740,28 @@ def test_residual_epilogue_on_a_small_grid_goes_through_split_k(env):
         assert rel_err(got, (x.float() @ w.float().t()).bfloat16().float() + r.float()) < 0.0036
 
 
-def test_gemm_piece_placements_and_persistent_walk_are_bit_identical(env):
-    """The schedule variants of the full-line GEMM kernel compute the same bits as the product schedule:
-    * LDS-DMA piece placement: early (product for row-major operands; tamd_gemm_set_dbg(32) selects it for the k-major
-      layouts) and late (round 2's; dbg 128 for row-major operands) -- diagnostic entry points;
-    * the persistent walk (one workgroup per CU, XCD groups start every dispatch round together; `sched="fl_persist"`) and
-      its variant with hand-shakes inside the tiles (`"fl_persist_sync"`): every layout, plain / accumulate epilogues and
-      split-K, several tiles per workgroup with a ragged last round, K long enough for hand-shakes."""
+def test_gemm_piece_placements_are_bit_identical(env):
+    """The two LDS-DMA piece placements of the full-line GEMM kernel -- early (the product schedule whenever A is row-major:
+    forward and dX) and late (dW) -- compute the same bits in every layout; the diagnostic entry point
+    tamd_gemm_set_dbg(32 / 128) selects the other one (tools/gemm_piece_ab.py measures them)."""
     lib = ops.backend().lib
+    if not hasattr(lib, "tamd_gemm_set_dbg"):
+        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
     torch.manual_seed(61)
     dev = env.device
-    # tiles: emu 6 x 4 = 24 over 8 persistent workgroups (3 rounds; 2 groups of 4), hip 24 x 16 = 384 over 256 (2 rounds)
-    m, n, k = (6144, 4096, 8320) if env.big else (1536, 1000, 4288)
+    m, n, k = (1536, 1024, 1280) if env.big else (512, 520, 640)
     x = torch.randn(m, k).bfloat16().to(dev)
     w = (torch.randn(n, k) * k ** -0.5).bfloat16().to(dev)
     layouts = [((x, w), {}), ((x, w.t().contiguous()), {"b_kn": True}),
                ((x.t().contiguous(), w.t().contiguous()), {"a_km": True, "b_kn": True})]
     ref = x.float() @ w.float().t()
-    for args, kw in layouts:
-        plain = ops.raw_gemm(*args, sched="fl", **kw)
-        assert rel_err(plain, ref) < 0.0036
-        for sched in ("fl_persist", "fl_persist_sync"):
-            assert torch.equal(ops.raw_gemm(*args, sched=sched, **kw), plain), (kw, sched)
-        acc0 = torch.randn(m, n).bfloat16().to(dev)
-        want = ops.raw_gemm(*args, epilogue=ops.EPI_ACCUM, out=acc0.clone(), sched="fl", **kw)
-        got = ops.raw_gemm(*args, epilogue=ops.EPI_ACCUM, out=acc0.clone(), sched="fl_persist_sync", **kw)
-        assert torch.equal(got, want), kw
-        if hasattr(lib, "tamd_gemm_set_dbg"):
-            try:
-                for dbg in (32, 128):
-                    lib.tamd_gemm_set_dbg(dbg)
-                    assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
-            finally:
+    try:
+        for args, kw in layouts:
+            plain = ops.raw_gemm(*args, sched="fl", **kw)
+            assert rel_err(plain, ref) < 0.0036
+            for dbg in (32, 128):
+                lib.tamd_gemm_set_dbg(dbg)
+                assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
                 lib.tamd_gemm_set_dbg(0)
-    # split-K under the persistent walk (through the C ABI directly: the Python wrapper only splits without a hint)
-    if env.big:  # the q|k|v weight gradient of Llama-3-8B: 384 tiles x 2 splits
-        m, n, k = 6144, 4096, 32768
-        a_, b_ = torch.randn(k, m).bfloat16().to(dev), (torch.randn(k, n) * k ** -0.5).bfloat16().to(dev)
-    else:
-        a_, b_ = layouts[2][0]
-    be = ops.backend()
-    ws_bytes = be.lib.tamd_gemm_workspace_bytes(m, n, k, 3, ops.EPI_NONE)
-    assert ws_bytes > 0
-
-    def splitk(flags):
-        out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        be.lib.check(be.lib.tamd_gemm_ws(a_.data_ptr(), b_.data_ptr(), out.data_ptr(), None, None, m, n, k, a_.stride(0),
-                                         b_.stride(0), n, 0, 3 | flags, ops.EPI_NONE, 0, ops._code(a_), ws.data_ptr(),
-                                         ws_bytes, be.stream(a_)), "tamd_gemm_ws")
-        return out
-
-    assert torch.equal(splitk(4 << 8), splitk(0))
+    finally:
+        lib.tamd_gemm_set_dbg(0)

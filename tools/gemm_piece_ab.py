@@ -1,16 +1,16 @@
-"""A/B of the GEMM schedule variants of round 3 against the product schedule on the Llama-3-8B shapes, interleaved rounds
-in one process (TFLOP/s per arm and round):
+"""A/B of the two LDS-DMA piece placements of the full-line GEMM kernel on the Llama-3-8B shapes, interleaved rounds in one
+process (TFLOP/s per arm and round):
 
-  fl              the product kernel (early LDS-DMA pieces for row-major operands, late for k-major ones)
-  persist         TAMD_GEMM_SCHED_FL_PERSIST: one workgroup per CU, XCD groups start every dispatch round together
-  persist_sync    ... and re-align every 64 stages inside a tile
-  early / late    the other piece placement of the layout (diagnostic library: tamd_gemm_set_dbg 32 / 128)
+  fl              the product kernel (early pieces whenever A is row-major: forward and dX; late for dW)
+  early / late    the other placement (diagnostic library: tamd_gemm_set_dbg 32 / 128)
+
+(profiles/r03b_gemm_persist_ab.jsonl was written by this tool when it still carried the two arms of the persistent,
+XCD-aligned walk -- profiles/r03b_gemm_persist.patch.)
 
 Split-K products (q|k|v and down dW) go through tamd_gemm_ws with the workspace the policy asks for.
 
-    python tools/gemm_persist_ab.py [--rounds 3] [--iters 6] [--shapes qkv,o_proj,gate_up,down,lm_head] [--legs fwd,dX,dW]
-Under `rocprofv3 --pmc FETCH_SIZE` (with --rounds 1 --iters 2) the kernel names carry the variant (last template
-argument 1 / 2 = persistent), so the fabric traffic per launch separates by arm."""
+    python tools/gemm_piece_ab.py [--rounds 3] [--iters 6] [--shapes qkv,o_proj,gate_up,down,lm_head] [--legs fwd,dX,dW]
+"""
 import argparse
 import json
 import sys
@@ -36,7 +36,6 @@ dev = torch.device("cuda:0")
 T = 32768
 SHAPES = {"qkv": (T, 6144, 4096), "o_proj": (T, 4096, 4096), "gate_up": (T, 28672, 4096), "down": (T, 4096, 14336),
           "lm_head": (T, 128256, 4096)}
-HINT = {"fl": 0, "persist": 4 << 8, "persist_sync": 5 << 8}
 
 
 def gemm(a, b, flags, m, n, k, out, ws):
@@ -71,17 +70,16 @@ for name in args.shapes.split(","):
         out = torch.empty(gm, gn, dtype=torch.bfloat16, device=dev)
         ws_bytes = be.lib.tamd_gemm_workspace_bytes(gm, gn, gk, lay, ops.EPI_NONE)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        arms = ["fl", "persist", "persist_sync"]
+        arms = ["fl"]
         if lib is not None and ws is None:
-            arms.append("late" if lay == 0 else "early")
+            arms.append("early" if lay == 3 else "late")
         res = {c: [] for c in arms}
         ref = None
         for rnd in range(args.rounds):
             for c in arms:
                 if lib is not None:
                     lib.tamd_gemm_set_dbg({"late": 128, "early": 32}.get(c, 0))
-                flags = lay | HINT.get(c, 0)
-                # (a hint turns split-K off in the library unless a workspace comes with it: it does here)
+                flags = lay
                 fn = lambda: gemm(a, b, flags, gm, gn, gk, out, ws)  # noqa: E731
                 res[c].append(round(2.0 * gm * gn * gk / time_ms(fn) / 1e9))
                 if rnd == 0:

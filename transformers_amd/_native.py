@@ -1,0 +1,70 @@
+"""Loader of libtamd_torch.so -- the compiled `torch.ops.tamd.*` (csrc/torch_binding.cpp).
+
+`torch.ops.load_library` registers the op schemas and their CUDA (= HIP) / CPU implementations; the three plain-C entry
+points next to them are bound with ctypes: `bind` points the ops at a C-ABI kernel library (libtamd.so, libtamd_diag.so,
+or the CPU execution model of the test-suite), `gemm_log` / `gemm_log_summary` drive the HIP-event log around the MFMA-GEMM
+launches that bench.py's `roofline` object is computed from.
+"""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+import torch
+
+from ._cabi import TamdError
+
+LIB_PATH = Path(__file__).resolve().parent / "libtamd_torch.so"
+_dll = None
+
+
+def load():
+    """Load the compiled ops (idempotent).  Raises with the build command when the library is missing."""
+    global _dll
+    if _dll is not None:
+        return _dll
+    if not LIB_PATH.exists():
+        # first import of a fresh checkout: the binding is 15 s of host C++ (no GPU, no hipcc needed); the kernel library
+        # itself is built by `python -m transformers_amd.build` / __graft_entry__.build()
+        try:
+            from . import build
+
+            build.build_torch_binding()
+        except Exception as e:
+            raise TamdError(f"{LIB_PATH} not found and building it failed ({e}); run `python -m transformers_amd.build` "
+                            "(the compiled torch.ops.tamd.* binding; the MI355X path has no Python/eager fallback)") from e
+    torch.ops.load_library(str(LIB_PATH))
+    dll = ctypes.CDLL(str(LIB_PATH))
+    dll.tamd_torch_bind.restype = ctypes.c_int
+    dll.tamd_torch_bind.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    dll.tamd_torch_last_error.restype = ctypes.c_char_p
+    dll.tamd_torch_bound_path.restype = ctypes.c_char_p
+    dll.tamd_torch_gemm_log.argtypes = [ctypes.c_int]
+    dll.tamd_torch_gemm_log_summary.restype = ctypes.c_int
+    dll.tamd_torch_gemm_log_summary.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    _dll = dll
+    return dll
+
+
+def bind(path, emulated: bool = False) -> None:
+    """Point the compiled ops at the C-ABI library at `path` (every symbol of include/tamd.h, same ABI version)."""
+    dll = load()
+    if dll.tamd_torch_bind(str(path).encode(), int(bool(emulated))) != 0:
+        raise TamdError(dll.tamd_torch_last_error().decode())
+
+
+def bound_path() -> str:
+    return load().tamd_torch_bound_path().decode()
+
+
+def gemm_log(on: bool) -> None:
+    """Start (clearing what was recorded) / stop the HIP-event log around every MFMA-GEMM launch."""
+    load().tamd_torch_gemm_log(int(bool(on)))
+
+
+def gemm_log_summary():
+    """-> dict(launches, flops, ms, bytes) of the recorded launches (synchronises their events, clears the log)."""
+    out = (ctypes.c_double * 4)()
+    if load().tamd_torch_gemm_log_summary(out) != 0:
+        raise TamdError("reading the GEMM event log failed")
+    return dict(launches=int(out[0]), flops=out[1], ms=out[2], bytes=out[3])

@@ -1,8 +1,9 @@
-"""Build libtamd.so (the gfx950 C-ABI kernel library) in-tree with hipcc.
+"""Build the native libraries in-tree: libtamd.so (the gfx950 C-ABI kernel library, hipcc) and libtamd_torch.so (the
+compiled `torch.ops.tamd.*` binding over it, host C++ against the torch headers).
 
 `python -m transformers_amd.build [--force]` or `transformers_amd.build.build()`.
-hipcc cross-compiles for gfx950 without a GPU; the resulting `.so` sits next to this
-file (git-ignored, but it travels with the tree to the GPU box).
+hipcc cross-compiles for gfx950 without a GPU; the resulting `.so` files sit next to this
+file (git-ignored, but they travel with the tree to the GPU box).
 """
 from __future__ import annotations
 
@@ -83,9 +84,48 @@ def _build(lib: Path, sources, obj_dir: Path, defines, force: bool, verbose: boo
     return lib
 
 
+TORCH_LIB = HERE / "libtamd_torch.so"  # torch.ops.tamd.*: csrc/torch_binding.cpp (host C++ only, no device code)
+
+
+def build_torch_binding(force: bool = False, verbose: bool = False) -> Path:
+    """Compile csrc/torch_binding.cpp against the installed torch (TORCH_LIBRARY(tamd, ...): the compiled dispatcher ops
+    that call the C ABI of include/tamd.h through a table bound at run time)."""
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    src = CSRC / "torch_binding.cpp"
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no C++ compiler found for the torch binding")
+    torch_lib = Path(torch.__file__).resolve().parent / "lib"
+    rocm = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-unused-result"]
+    for inc in ce.include_paths():
+        cmd += ["-isystem", inc]
+    cmd += ["-isystem", str(rocm / "include"), str(src), "-o", str(TORCH_LIB), f"-L{torch_lib}", "-ltorch", "-ltorch_cpu",
+            "-lc10", "-lc10_hip", "-ltorch_hip", f"-L{rocm / 'lib'}", "-lamdhip64", "-ldl", f"-Wl,-rpath,{torch_lib}",
+            f"-Wl,-rpath,{rocm / 'lib'}"]
+    stamp = OBJ_DIR / "torch_binding.stamp"
+    digest = _digest([src, INCLUDE / "tamd.h"]) + torch.__version__ + " ".join(cmd)
+    if not force and TORCH_LIB.exists() and stamp.exists() and stamp.read_text() == digest:
+        return TORCH_LIB
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building {TORCH_LIB.name} failed:\n{r.stdout}\n{r.stderr[-6000:]}")
+    stamp.write_text(digest)
+    return TORCH_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP source for gfx950 and link libtamd.so (the product library).  Returns the library path."""
-    return _build(LIB, SOURCES, OBJ_DIR, (), force, verbose)
+    """Compile every HIP source for gfx950 and link libtamd.so (the product library), then the compiled torch binding
+    over it (libtamd_torch.so).  Returns the kernel library path."""
+    lib = _build(LIB, SOURCES, OBJ_DIR, (), force, verbose)
+    build_torch_binding(force, verbose)
+    return lib
 
 
 def build_diag(force: bool = False, verbose: bool = False) -> Path:

@@ -86,10 +86,6 @@ struct GemmArgs {
   // rotary epilogue (kEpiRope): R = cos, C2 = sin ([cos_batch, seq, 128] in the storage dtype), n_half = the leading
   // columns to rotate (query + key heads, a multiple of 128), seq / cos_batch below
   int64_t seq, cos_batch;
-  // persistent walk (PERSIST instantiations): arrival counters of the launch (16 unsigned per group: [0] round starts,
-  // [8] hand-shakes inside a tile), number of groups (= XCDs) and of virtual blocks (tiles x splits)
-  unsigned* sync;
-  int sync_groups, total_wgs;
 };
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
@@ -551,59 +547,31 @@ __device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
 
 // DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_GEMM_DBG=n): wrong results by
 // design -- 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier; correct,
-// bit-identical results -- 32 the early piece placement (below) for the k-major layouts too, 128 the late placement
-// (pieces behind the odd MFMA pairs 17..31: the schedule of round 2) for row-major operands.
+// bit-identical results -- 32 the early piece placement (below) in every layout, 128 the late placement (pieces behind
+// the odd MFMA pairs 17..31: the schedule of round 2) in every layout.
 // Piece placement (EARLY): the 8 LDS-DMA pieces of a k-step go out behind its MFMA pairs 2, 5, .. 23, the 16 fragment
 // reads of the next k-step on the pairs between them -- 23 MFMAs (~400 cycles) more on average for a piece to land
 // before the hand-off waits for it than behind the odd pairs 17..31 (hipBLASLt's gfx950 kernel gives its operands
-// 84-182 MFMAs).  Measured on MI355X (profiles/r03a_gemm_stagger_ab.jsonl): +1.0 ... +2.0 % on all four forward shapes
-// of Llama-3-8B, so it is the product schedule for row-major operands.  The same A/B buried two other differences to
+// 84-182 MFMAs).  Measured on MI355X (profiles/r03a_gemm_stagger_ab.jsonl, r03b_gemm_persist_ab.jsonl): +1.0 ... +2.6 %
+// on the five forward shapes of Llama-3-8B and +0.7 ... +2.9 % on their dX products (lm_head dX, 2004 stages: +10 %), but
+// -3 ... -4 % on the long dW products -- so it is the product schedule whenever A is row-major (forward and dX), and the
+// late placement stays for dW (both operands k-major).  The same A/B buried two other differences to
 // hipBLASLt's loop: a staggered, wrapping K start per workgroup (13 configurations: -1 ... +2 %, no pattern) and a
 // second barrier per k-step (+-0.5 %).
-// PERSIST (TAMD_GEMM_SCHED_FL_PERSIST / _SYNC hints, long-K products): `gridDim.x` = groups x per_round persistent
-// workgroups; workgroup (x = blockIdx % groups, slot = blockIdx / groups) walks the virtual block ids
-// x + groups * (slot + per_round * round), i.e. exactly the blocks the hardware would have given the CUs of XCD x in
-// dispatch round `round`, and the workgroups of one XCD start each round TOGETHER (an arrive-and-wait on a counter in
-// global memory, bounded spin).  Why: the 32 tiles an XCD runs side by side share their A / B panels through its 4 MiB
-// L2 only while they sweep k in step (the L2 holds ~10 stages of a patch's 12 panels); a 512-stage weight-gradient tile
-// drifts further than that, and from the second dispatch round on the tiles do not even start together -- the one
-// 1-round dW (o_proj, 256 tiles) runs at 1514 TFLOP/s and reads 1.4x the patch floor, the 7-round gate|up dW at 1426
-// and 2.0x.  PERSIST = 2 additionally re-aligns the XCD every kSyncStages stages inside a tile.
-constexpr int kSyncStages = 64;
-constexpr int kSyncSpinLimit = 1 << 20;
-
-// arrive on `ctr` and wait until `target` workgroups have (one lane polls; agent-scope atomics: correct wherever the
-// workgroups of a "group" really run); gives up after kSyncSpinLimit polls -- alignment is an optimisation, never a
-// correctness condition, and a partner that is not resident (CU-masked stream, shared GPU) must not hang the kernel
-__device__ __forceinline__ void group_arrive_wait(unsigned* ctr, unsigned target) {
-  atomic_add_agent(ctr, 1u);
-  for (int spin = 0; spin < kSyncSpinLimit && atomic_load_agent(ctr) < target; ++spin) short_sleep();
-}
-
-template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0, int PERSIST = 0>
+// (Round 3 also measured a persistent walk -- one workgroup per CU, the XCD's workgroups starting every dispatch round
+// together through an arrival counter, optionally re-aligned every 64 stages inside a tile -- against the drift of the
+// long-K products: it took the L2 hit rate of the gate|up dX / dW from 74 / 62 % to the 81 % of the 8 x 4 patch and their
+// fabric traffic to the patch floor (11.2 GB), and bought nothing: 1492 vs 1498 TFLOP/s with aligned rounds, -22 % with the
+// hand-shakes.  The L2 misses of the long-K products are not what bounds them.  profiles/r03b_gemm_persist_ab.jsonl,
+// r03b_gemm_persist_pmc.txt; the code: profiles/r03b_gemm_persist.patch.)
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
   const int wm = wave >> 1, wn = wave & 1;
   const int g4 = lane >> 4, l15 = lane & 15;
-  // persistent walk (see PERSIST above): virtual block id of this round; the plain kernel runs the loop body once
-  const int p_group = PERSIST ? (int)(blockIdx.x % (unsigned)g.sync_groups) : 0;
-  const int p_slot = PERSIST ? (int)(blockIdx.x / (unsigned)g.sync_groups) : 0;
-  const int p_per_round = PERSIST ? (int)(gridDim.x / (unsigned)g.sync_groups) : 1;
-  const int p_in_group = PERSIST ? (g.total_wgs - p_group + g.sync_groups - 1) / g.sync_groups : 1;  // virtual blocks of this group
-#pragma unroll 1
-  for (int p_round = 0;; ++p_round) {
-  const int vbid = PERSIST ? p_group + g.sync_groups * (p_slot + p_per_round * p_round) : (int)blockIdx.x;
-  if (PERSIST) {
-    if (vbid >= g.total_wgs) break;
-    // every wave is done with the previous tile's LDS staging; the group's workgroups of this round start together
-    if (threadIdx.x == 0) {
-      const int done = p_per_round * (p_round + 1);
-      group_arrive_wait(g.sync + p_group * 16, (unsigned)(done < p_in_group ? done : p_in_group));
-    }
-    raw_barrier();
-  }
+  const int vbid = (int)blockIdx.x;
   TAMD_CLOCK_BEGIN
   int tile_m, tile_n;
   const int split = (EPI == kEpiSplitK) ? (int)((unsigned)vbid % (unsigned)g.splits) : 0;
@@ -732,7 +700,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   // SIMD: nobody else fills it) never waits behind a clump of LDS / LDS-DMA issues.  EARLY: of the pairs 0..23 every
   // third carries a piece, the other two a fragment read (the last read 9 pairs ahead of the hand-off's lgkmcnt(0));
   // otherwise reads behind the pairs 0..15, pieces behind the odd pairs 17..31.
-  constexpr bool EARLY = ((!A_KM && !B_KN) || (DBG & 32)) && !(DBG & 128);
+  constexpr bool EARLY = (!A_KM || (DBG & 32)) && !(DBG & 128);
   auto kstep = [&](int buf, int ra, int rb, int rq, int pb, int ps) __attribute__((always_inline)) {
     kstep_open();
 #pragma unroll
@@ -778,15 +746,6 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
         // hand-off: stage s+1 has landed for everybody; everybody's reads of stage s are in registers
         if (!(DBG & 4)) wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 newest (A_{s+2}) stay in flight
         wait_lgkmcnt0();
-        if (PERSIST == 2 && EPI != kEpiSplitK && (s % kSyncStages) == kSyncStages - 1 && s + 1 < nst) {
-          // re-align the XCD's workgroups inside the tile (the other waves wait at the hand-off barrier below)
-          if (threadIdx.x == 0) {
-            const int hpt = (nst - 1) / kSyncStages;  // hand-shakes per tile (every tile of a launch has nst stages)
-            const int before = p_per_round * p_round < p_in_group ? p_per_round * p_round : p_in_group;
-            const int here = p_in_group - before < p_per_round ? p_in_group - before : p_per_round;
-            group_arrive_wait(g.sync + p_group * 16 + 8, (unsigned)(hpt * before + here * (s / kSyncStages + 1)));
-          }
-        }
         if (!(DBG & 8)) raw_barrier();
         sched_fence();
         kstep(1, sa1, sb1, 0, 8, sb2);  // k-step 1 | first-half fragments of stage s+1 | B_{s+2} into the slot A_s vacated
@@ -823,8 +782,6 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
         g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
   }
-  if (!PERSIST) break;
-  }  // persistent walk
 }
 
 // out[m][n] = round(sum_s ws[s][m][n] (+ out[m][n] if ACCUM)): 4 columns per thread (16-byte reads, 8-byte stores)
@@ -869,49 +826,6 @@ static int gemm_diag_dbg() {
   return g_gemm_dbg;
 }
 #endif
-// Arrival counters of the persistent launches: a ring of slots in device memory, one per launch in flight (the host
-// hands them out round robin and zeroes a slot on the launch's own stream right before the kernel; 64 slots: 64 GEMMs of
-// this kind would have to be in flight on one device at once for two of them to share counters -- and sharing only
-// weakens the alignment, see group_arrive_wait).
-constexpr int kSyncSlots = 64, kSyncSlotWords = 16 * 16;  // up to 16 groups of 16 words
-__device__ unsigned g_gemm_sync[kSyncSlots * kSyncSlotWords];
-static unsigned* gemm_sync_slot(hipStream_t s) {
-#ifdef __HIPCC__
-  static unsigned* base[32] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-  if (base[dev] == nullptr) {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gemm_sync)) != hipSuccess) return nullptr;
-    base[dev] = reinterpret_cast<unsigned*>(p);
-  }
-  unsigned* b = base[dev];
-#else
-  unsigned* b = g_gemm_sync;  // (CPU execution model: `__device__` data is host data)
-#endif
-  static unsigned next = 0;
-  unsigned* slot = b + (size_t)(__atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % kSyncSlots) * kSyncSlotWords;
-  if (hipMemsetAsync(slot, 0, kSyncSlotWords * sizeof(unsigned), s) != hipSuccess) return nullptr;
-  return slot;
-}
-// workgroups of a persistent launch: one per CU (the kernel owns a CU: 160 KiB of LDS), in `groups` = 8 XCD groups
-static int gemm_persistent_grid(int* groups) {
-#ifdef __HIPCC__
-  static int cus[32] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
-  if (cus[dev] == 0) {
-    hipDeviceProp_t prop;
-    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
-  }
-  *groups = 8;
-  return cus[dev] > 0 ? cus[dev] / 8 * 8 : 0;
-#else
-  *groups = 2;  // the CPU model runs one workgroup per OS thread: 2 groups of (threads / 2) so the barrier has partners
-  const int t = hipemu::launch_threads();
-  return t / 2 * 2;
-#endif
-}
 #define TAMD_EPI_SWITCH(LAUNCH)                                           \
   switch (epilogue) {                                                     \
     case TAMD_EPI_NONE: LAUNCH(TAMD_EPI_NONE, TAMD_ACT_NONE)              \
@@ -948,37 +862,16 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
   return gemm_pp_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
-// persistent launch of the plain / accumulate / split-K products (sched hint; see PERSIST at the kernel): falls back to
-// the plain launch (returns -1) when the grid would not be persistent anyway or the counters are not available
-template <typename T, bool A_KM, bool B_KN, int EPI>
-static int gemm_fl_launch_persist(const GemmArgs& g0, int persist, hipStream_t s) {
-  GemmArgs g = g0;
-  g.total_wgs = g.tiles_m * g.tiles_n * (EPI == kEpiSplitK ? g.splits : 1);
-  const int grid = gemm_persistent_grid(&g.sync_groups);
-  if (grid < 2 * g.sync_groups || g.total_wgs <= grid) return -1;
-  g.sync = gemm_sync_slot(s);
-  if (g.sync == nullptr) return -1;
-  if (persist == 2)
-    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, EPI, TAMD_ACT_NONE, 0, 2>), dim3((unsigned)grid), dim3(kFlThreads),
-                       (size_t)kXSmem, s, g);
-  else
-    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, EPI, TAMD_ACT_NONE, 0, 1>), dim3((unsigned)grid), dim3(kFlThreads),
-                       (size_t)kXSmem, s, g);
-  return launch_status();
-}
-
 template <typename T, bool A_KM, bool B_KN>
-static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, int persist, hipStream_t s) {
+static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
-  if (persist && (epilogue == TAMD_EPI_NONE || epilogue == TAMD_EPI_ACCUM)) {
-    const int rc = epilogue == TAMD_EPI_NONE ? gemm_fl_launch_persist<T, A_KM, B_KN, TAMD_EPI_NONE>(g, persist, s)
-                                             : gemm_fl_launch_persist<T, A_KM, B_KN, TAMD_EPI_ACCUM>(g, persist, s);
-    if (rc >= 0) return rc;
-  }
 #ifdef TAMD_DIAG  // ablation / A-B instantiations: libtamd_diag.so only, never the product library
   const int dbg = gemm_diag_dbg();
-  if (dbg == 32 && epilogue == TAMD_EPI_NONE) {  // early piece placement in every layout (correct results)
-    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 32>), grid, block, (size_t)kXSmem, s, g);
+  if ((dbg == 32 || dbg == 128) && epilogue == TAMD_EPI_NONE) {  // the other piece placement (correct results)
+    if (dbg == 32)
+      hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 32>), grid, block, (size_t)kXSmem, s, g);
+    else
+      hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 128>), grid, block, (size_t)kXSmem, s, g);
     return launch_status();
   }
   if (dbg && epilogue == TAMD_EPI_NONE && !A_KM && !B_KN) {
@@ -993,7 +886,6 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, int pers
       case 8: TAMD_GD(8)
       case 12: TAMD_GD(12)
       case 15: TAMD_GD(15)
-      case 128: TAMD_GD(128)
       default: break;
     }
 #undef TAMD_GD
@@ -1008,10 +900,9 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, int pers
 
 // split-K: partial tiles into the fp32 workspace, then the reduction (TAMD_EPI_NONE / TAMD_EPI_ACCUM only)
 template <typename T, bool A_KM, bool B_KN>
-static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, int persist, hipStream_t s) {
+static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(kFlThreads);
-  if (!persist || gemm_fl_launch_persist<T, A_KM, B_KN, kEpiSplitK>(g, 1, s) < 0)  // (no hand-shakes inside a split)
-    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, kEpiSplitK, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem, s, g);
+  hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, kEpiSplitK, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem, s, g);
   const int64_t nvec = g.M * (g.N / 4);
   int64_t blocks = ceil_div(nvec, 256);
   if (blocks > 4096) blocks = 4096;
@@ -1025,21 +916,21 @@ static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, int persist, 
 }
 
 template <typename T>
-static int gemm_fl_splitk_launch(const GemmArgs& g, int flags, int epilogue, int persist, hipStream_t s) {
+static int gemm_fl_splitk_launch(const GemmArgs& g, int flags, int epilogue, hipStream_t s) {
   const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
-  if (!akm && !bkn) return gemm_fl_splitk_launch2<T, false, false>(g, epilogue, persist, s);
-  if (!akm && bkn) return gemm_fl_splitk_launch2<T, false, true>(g, epilogue, persist, s);
-  if (akm && bkn) return gemm_fl_splitk_launch2<T, true, true>(g, epilogue, persist, s);
-  return gemm_fl_splitk_launch2<T, true, false>(g, epilogue, persist, s);
+  if (!akm && !bkn) return gemm_fl_splitk_launch2<T, false, false>(g, epilogue, s);
+  if (!akm && bkn) return gemm_fl_splitk_launch2<T, false, true>(g, epilogue, s);
+  if (akm && bkn) return gemm_fl_splitk_launch2<T, true, true>(g, epilogue, s);
+  return gemm_fl_splitk_launch2<T, true, false>(g, epilogue, s);
 }
 
 template <typename T>
-static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, int persist, hipStream_t s) {
+static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, hipStream_t s) {
   const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
-  if (!akm && !bkn) return gemm_fl_launch_epi<T, false, false>(g, epilogue, act, persist, s);
-  if (!akm && bkn) return gemm_fl_launch_epi<T, false, true>(g, epilogue, act, persist, s);
-  if (akm && bkn) return gemm_fl_launch_epi<T, true, true>(g, epilogue, act, persist, s);
-  return gemm_fl_launch_epi<T, true, false>(g, epilogue, act, persist, s);
+  if (!akm && !bkn) return gemm_fl_launch_epi<T, false, false>(g, epilogue, act, s);
+  if (!akm && bkn) return gemm_fl_launch_epi<T, false, true>(g, epilogue, act, s);
+  if (akm && bkn) return gemm_fl_launch_epi<T, true, true>(g, epilogue, act, s);
+  return gemm_fl_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
 }  // namespace tamd
@@ -1087,9 +978,6 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->n_half = 0;
   g->seq = 1;
   g->cos_batch = 1;
-  g->sync = nullptr;
-  g->sync_groups = 1;
-  g->total_wgs = g->tiles_m * g->tiles_n;
   return TAMD_OK;
 }
 
@@ -1139,20 +1027,6 @@ static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int epilogue, int
   return (int)ceil_div(nst, sps);  // no empty split
 }
 
-// Which products take the persistent, XCD-aligned walk without being asked (0 none, 1 aligned rounds, 2 + hand-shakes
-// inside a tile).  OFF until measured on MI355X (tools/gemm_persist_ab.py): TAMD_GEMM_PERSIST=1|2 in the environment
-// turns it on for the long-K products (K >= 128 stages) of more than one dispatch round.
-static int gemm_persist_policy(int64_t M, int64_t N, int64_t K, int flags, int epilogue) {
-  (void)flags;
-  static const int mode = [] {
-    const char* e = getenv("TAMD_GEMM_PERSIST");
-    return e ? atoi(e) : 0;
-  }();
-  if (mode <= 0 || (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM)) return 0;
-  if (K % kXK != 0 || K / kXK < 128) return 0;
-  return mode >= 2 ? 2 : 1;
-}
-
 extern "C" size_t tamd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags, int epilogue) {
   (void)flags;
   int sps;
@@ -1192,9 +1066,6 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
   }();
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
-  // persistent walk with XCD-aligned rounds (4) and hand-shakes inside the tiles (5): by hint, or by the policy below
-  int persist = sched == 4 ? 1 : (sched == 5 ? 2 : 0);
-  if (sched == 0) persist = gemm_persist_policy(M, N, K, flags, epilogue);
   if (sched != 1 && workspace != nullptr) {
     int sps;
     const int splits = gemm_choose_splits(M, N, K, epilogue, &sps);
@@ -1202,11 +1073,11 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
       g.ws = reinterpret_cast<float*>(workspace);
       g.splits = splits;
       g.stages_per_split = sps;
-      TAMD_DISPATCH_HALF(dtype, return (gemm_fl_splitk_launch<T>(g, flags, epilogue, persist, TAMD_STREAM(stream))));
+      TAMD_DISPATCH_HALF(dtype, return (gemm_fl_splitk_launch<T>(g, flags, epilogue, TAMD_STREAM(stream))));
     }
   }
   if (K % kXK == 0 && sched != 1) {
-    TAMD_DISPATCH_HALF(dtype, return (gemm_fl_launch<T>(g, flags, epilogue, act, persist, TAMD_STREAM(stream))));
+    TAMD_DISPATCH_HALF(dtype, return (gemm_fl_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   } else {
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   }
