@@ -303,9 +303,9 @@ def main():
                          "10-50 us launches and two event records per GEMM add host time to a host-bound step")
     ap.add_argument("--force-ddp", action="store_true",
                     help="wrap in DDP over RCCL even with one rank (exercises init / bucket all-reduce / destroy)")
-    ap.add_argument("--ddp-grads", choices=("none", "zero", "keep"), default="none",
-                    help="between steps: none = zero_grad(set_to_none=True) (Trainer's default), zero = zero in place "
-                         "(gradients stay views of the DDP buckets), keep = no zero_grad (gradients accumulate)")
+    ap.add_argument("--ddp-grads", choices=("none", "zero", "keep"), default=None,
+                    help="between steps: none = zero_grad(set_to_none=True) (Trainer's default; ours without DDP), zero = "
+                         "zero in place (gradients stay views of the DDP buckets; ours under DDP), keep = no zero_grad")
     ap.add_argument("--bucket-mb", type=int, default=int(os.environ.get("TAMD_DDP_BUCKET_MB", "256")))
     args = ap.parse_args()
 
@@ -410,13 +410,15 @@ def main():
                 return fwd(net).logits[0, -1, 0].float()
         out = fwd(net)
         out.loss.backward()
-        # What Trainer does between steps (optimizer.zero_grad(), set_to_none=True).  Under DDP with
-        # gradient_as_bucket_view the next backward then hands DDP fresh gradient tensors, which it copies into the bucket
-        # views (read 16 + write 16 GB: ~6 ms of a 1.28 s step); zeroing in place instead costs a 16 GB memset plus
-        # autograd's in-place accumulate (read 32 + write 16 GB: ~13 ms) -- `--ddp-grads zero|keep` selects those for an A/B
-        if args.ddp_grads == "none":
+        # Between steps.  Without DDP: what Trainer does (optimizer.zero_grad(), set_to_none=True).  Under DDP with
+        # gradient_as_bucket_view the gradients are views of the all-reduce buckets: dropping them makes the next backward
+        # hand DDP fresh tensors that it copies into the buckets and re-points, so they are zeroed in place instead --
+        # measured on MI355X at world size 1 (profiles/r03c_ddp_grads_ab.jsonl): 1299.8 ms per step dropped, 1288.9 zeroed
+        # in place, 1285.8 never zeroed (non-DDP step on the same box: 1273.4).  `--ddp-grads none|zero|keep` overrides.
+        mode = args.ddp_grads or ("zero" if ddp else "none")
+        if mode == "none":
             model.zero_grad(set_to_none=True)
-        elif args.ddp_grads == "zero":
+        elif mode == "zero":
             model.zero_grad(set_to_none=False)
         return out.loss.detach()
 
@@ -491,6 +493,9 @@ def main():
             # GPU tensors served by a reference module's own forward (ATen / vendor kernels) inside the timed region
             "fallback_calls": sum(transformers_amd.fallback_calls().values()),
             "fallbacks": transformers_amd.fallback_calls(),
+            # forward-only decoder stacks replayed as one HIP graph (transformers_amd/graph_stack.py), whole run
+            "stack_graph_replays": sum(m.__dict__["_tamd_stack"][0].replays for m in model.modules()
+                                       if m.__dict__.get("_tamd_stack", (None, 1))[1] == 0),
             "roofline": roofline,
         }
         if roofline is not None and world == 1 and args.config == "llama3-8b":
