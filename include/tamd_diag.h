@@ -32,11 +32,6 @@ int tamd_gemm_set_dbg(int dbg);
  * (0 tile-load issue, 1 K.Q^T, 2 mask + softmax, 3 P.V, 4 vmcnt wait, 5 barrier).  NULL switches it off. */
 int tamd_attn_set_trace(void* buf);
 
-/* The 8-wave attention kernels (256 query rows per workgroup, 4-deep K/V ring): bit 0 the forward, bit 1 the dQ kernel of
- * the backward, switched at run time; the product library reads TAMD_ATTN_FWD8 from the environment instead.
- * tools/attn_fwd8_ab.py */
-int tamd_attn_set_fwd8(int on);
-
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
  * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
  * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */

@@ -765,45 +765,3 @@ def test_gemm_piece_placements_are_bit_identical(env):
                 lib.tamd_gemm_set_dbg(0)
     finally:
         lib.tamd_gemm_set_dbg(0)
-
-
-def test_attention_fwd_8_waves_matches_4_waves(env):
-    """The 8-wave forward kernel (256 query rows per workgroup, 4-deep K/V ring; tamd_attn_set_fwd8 / TAMD_ATTN_FWD8) computes
-    the bits of the 4-wave kernel: every wave does the same arithmetic on the same tiles, only the tile feed differs --
-    causal and bidirectional, GQA, a KV offset, ragged ends (the last tile goes through the generic feed), a padding mask,
-    short key ranges (fewer tiles than ring stages), head_dim 64 and 128."""
-    import math
-
-    lib = ops.backend().lib
-    if not hasattr(lib, "tamd_attn_set_fwd8"):
-        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
-    torch.manual_seed(83)
-    dev = env.device
-    cases = ([(2, 1024, 1024, 8, 2, 128), (1, 700, 704, 4, 4, 128), (1, 4096, 4096, 2, 1, 128), (2, 640, 640, 4, 2, 64),
-              (1, 512, 100, 2, 2, 128)] if env.big else
-             [(1, 512, 512, 2, 1, 128), (1, 520, 600, 2, 2, 64), (1, 512, 100, 1, 1, 64), (1, 600, 300, 1, 1, 128)])
-    for (b, sq, sk, hq, hkv, d) in cases:
-        q = torch.randn(b, sq, hq, d).bfloat16().to(dev)
-        k = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
-        v = torch.randn(b, sk, hkv, d).bfloat16().to(dev)
-        kv = torch.ones(b, sk, dtype=torch.bool)
-        kv[0, sk - 37:] = False
-        for causal in (True, False):
-            for mask in (None, kv.to(dev)):
-                o_ref, lse_ref = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal, mask)
-                lib.tamd_attn_set_fwd8(1)
-                try:
-                    o, lse = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal, mask)
-                finally:
-                    lib.tamd_attn_set_fwd8(0)
-                assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, d, causal, mask is not None)
-                if sq == sk or not causal:  # the dQ kernel with the same feed (bit 1 of the switch): every gradient, bit for bit
-                    do = torch.randn(b, sq, hq, d).bfloat16().to(dev)
-                    ref = ops.raw_attn_bwd(q, k, v, o_ref, lse_ref, do, 1 / math.sqrt(d), causal, mask)
-                    lib.tamd_attn_set_fwd8(2)
-                    try:
-                        got = ops.raw_attn_bwd(q, k, v, o_ref, lse_ref, do, 1 / math.sqrt(d), causal, mask)
-                    finally:
-                        lib.tamd_attn_set_fwd8(0)
-                    for x, y in zip(got, ref):
-                        assert torch.equal(x, y), (b, sq, sk, hq, hkv, d, causal, mask is not None)

@@ -29,6 +29,6 @@ for i in 1 2; do
   timeout 300 python bench.py --config bert-base --steps 30 --warmup 10 --no-cpu-baseline 2>> $out/${tag}_bench_bert.err | tee -a $out/${tag}_bench_bert.jsonl | cut -c1-200
 done
 timeout 300 python bench.py --config llava --steps 20 --warmup 5 2> $out/${tag}_bench_llava.err | tee $out/${tag}_bench_llava.json | cut -c1-200
-timeout 400 python -m pytest tests/test_models.py tests/test_kernels.py -m gpu -q -x --timeout 300 -k "bert_masked or fwd_8_waves or decoder_stack or piece_placements" > $out/${tag}_tests.log 2>&1
+timeout 400 python -m pytest tests/test_models.py tests/test_kernels.py -m gpu -q -x --timeout 300 -k "bert_masked or decoder_stack or piece_placements" > $out/${tag}_tests.log 2>&1
 tail -4 $out/${tag}_tests.log
 find $out/$tag -name "*.csv" -size +3M -delete

@@ -26,18 +26,6 @@
 
 namespace tamd {
 
-// The 8-wave kernels (256 query rows per workgroup, 4-deep K/V ring; see attention_fwd_kernel.inc): bit 0 the forward,
-// bit 1 the dQ kernel of the backward, for calls without dropout whose query length fills such tiles.  TAMD_ATTN_FWD8 in
-// the environment sets the initial value; the diagnostic library can switch it at run time (tamd_attn_set_fwd8).
-static int g_attn_fwd8 = -1;
-static int attn_fwd8() {
-  if (g_attn_fwd8 < 0) {
-    const char* e = getenv("TAMD_ATTN_FWD8");
-    g_attn_fwd8 = e ? atoi(e) : 0;
-  }
-  return g_attn_fwd8;
-}
-
 #include "attention_fwd_kernel.inc"
 
 }  // namespace tamd
@@ -53,32 +41,11 @@ unsigned long long* g_attn_trace = nullptr;
 #endif
 
 template <typename T, int D>
-int attn_fwd_launch(const AttnArgs& a0, bool causal, hipStream_t s) {
-  AttnArgs a = a0;
-  const bool mask = a.key_valid != nullptr;
-  const bool drop = a.drop_thr != 0;
-  if ((attn_fwd8() & 1) && !drop && a.seq_q >= 512) {
-    constexpr int QB8 = 8 * 32;
-    a.nqt = (a.seq_q + QB8 - 1) / QB8;
-    const size_t smem8 = (size_t)4 * 2 * kKB * D * 2;  // 4 ring stages x (K + V); covers the O staging (8 x 32 x (2D+16))
-    dim3 grid8((unsigned)(a.nqt * a.heads_q * a.batch)), block8(8 * 64);
-#define TAMD_AF8(C_, M_) hipLaunchKernelGGL((attn_fwd_kernel<T, D, C_, M_, false, 8>), grid8, block8, smem8, s, a)
-    if (causal) {
-      if (mask)
-        TAMD_AF8(true, true);
-      else
-        TAMD_AF8(true, false);
-    } else {
-      if (mask)
-        TAMD_AF8(false, true);
-      else
-        TAMD_AF8(false, false);
-    }
-#undef TAMD_AF8
-    return launch_status();
-  }
+int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
   const size_t smem = (size_t)4 * kKB * D * 2;  // 2 buffers x (K + V); also covers the O staging (4 x 32 x (2D+16))
   dim3 grid((unsigned)(a.nqt * a.heads_q * a.batch)), block(kAttnThreads);
+  const bool mask = a.key_valid != nullptr;
+  const bool drop = a.drop_thr != 0;
 #define TAMD_AF(C_, M_, D_) hipLaunchKernelGGL((attn_fwd_kernel<T, D, C_, M_, D_>), grid, block, smem, s, a)
   if (drop) {  // the dropout variants always carry the padding-mask code (rare path: keep the instantiation count down)
     if (causal)
@@ -165,13 +132,6 @@ AttnArgs make_args(const tamd_attn_params* p) {
 // phases: 0 tile-load issue, 1 K.Q^T, 2 mask + softmax, 3 P.V, 4 vmcnt wait, 5 barrier.  tools/attn_phases.py
 extern "C" int tamd_attn_set_trace(void* buf) {
   g_attn_trace = reinterpret_cast<unsigned long long*>(buf);
-  return TAMD_OK;
-}
-#endif
-
-#ifdef TAMD_DIAG
-extern "C" int tamd_attn_set_fwd8(int on) {
-  g_attn_fwd8 = on & 3;
   return TAMD_OK;
 }
 #endif

@@ -57,13 +57,13 @@ __device__ __forceinline__ int row_swz(int row) {
 }
 
 // one [64][D] tile: global rows `key0 + r` (stride `stride` elements) -> LDS at tile_off, swizzled by SWZ
-template <typename T, int D, int NW = 4>
+template <typename T, int D>
 __device__ __forceinline__ void issue_kv_tile(const T* __restrict__ base, int64_t stride, int key0, int nkeys,
                                               char* smem, unsigned tile_off, int wave, int lane) {
   constexpr int ROWB = D * 2;            // bytes per row
   constexpr int SLOTS = ROWB / 16;       // 16-byte slots per row
   constexpr int RPI = 1024 / ROWB;       // rows per wave instruction
-  constexpr int NI = (kKB * ROWB) / 1024 / NW;  // instructions per wave (NW waves share the tile)
+  constexpr int NI = (kKB * ROWB) / 1024 / 4;  // instructions per wave (4 waves)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int inst = wave * NI + i;
@@ -81,9 +81,9 @@ __device__ __forceinline__ void issue_kv_tile(const T* __restrict__ base, int64_
 // SALU instructions per piece on 64-bit addresses, the bounds test and the zero page (110 per tile and wave, half of
 // what the softmax costs).  Full tiles only (every row < nkeys) and 32-bit offsets (64 rows x stride x 2 B < 2^31); the
 // callers take issue_kv_tile for the ragged last tile.
-template <int D, int NW = 4>
+template <int D>
 struct TileFeed {
-  static constexpr int NI = (kKB * D * 2) / 1024 / NW;  // pieces per wave (NW waves share the tile)
+  static constexpr int NI = (kKB * D * 2) / 1024 / 4;  // pieces per wave
   unsigned voff[NI];
   __device__ __forceinline__ void init(int64_t stride, int wave, int lane) {
     constexpr int ROWB = D * 2, SLOTS = ROWB / 16, RPI = 1024 / ROWB;
