@@ -98,3 +98,29 @@ def test_mask_for_cross_attention_is_the_padding_mask():
     assert _mask_kv_len(m) == 7 and _mask_kv_len(m.to(torch.int32)[:1]) == 7 and _mask_kv_len(None) is None
     with pytest.raises(ops.TamdError):
         tamd_mask(2, 4, 6, q_offset=3, mask_function=mu.causal_mask_function, device=torch.device("cpu"))
+
+
+def test_varlen_kwargs_give_the_packed_bounds():
+    """The reference's varlen kwargs (cu_seq_lens_q/k, modeling_flash_attention_utils.py:575-590) describe the same
+    block-diagonal structure as restarting position_ids: `q_start_from_cu_seqlens` reproduces `packed_q_start` of the
+    corresponding sequence ids (the oracle's packed_bounds), including a padding tail after the last boundary."""
+    from transformers import masking_utils as mu
+
+    from transformers_amd.attention import varlen_q_start
+
+    pos = torch.tensor([[0, 1, 2, 3, 0, 1, 0, 1, 2, 3, 4, 5]])
+    ids = mu.find_packed_sequence_indices(pos)
+    cu = torch.tensor([0, 4, 6, 12], dtype=torch.int32)
+    got = ops.q_start_from_cu_seqlens(cu, 12)
+    assert got.dtype == torch.int32 and got.shape == (2, 1, 12)
+    assert np.array_equal(got.numpy(), ops.packed_q_start(ids).numpy())
+    assert np.array_equal(got.numpy(), orc.packed_bounds(ids.numpy()))
+    tail = ops.q_start_from_cu_seqlens(torch.tensor([0, 4, 6, 10]), 12)  # two padding tokens after the last sequence
+    assert tail[0, 0].tolist() == [0, 0, 0, 0, 4, 4, 6, 6, 6, 6, 10, 10] and tail[1, 0].tolist()[-2:] == [11, 11]
+    # the attention-layer hook: used when the mask carried no packing, refused where it cannot be honoured
+    assert varlen_q_start(None, {}, 1, 12, 12, True) is None
+    assert torch.equal(varlen_q_start(None, {"cu_seq_lens_q": cu, "cu_seq_lens_k": cu}, 1, 12, 12, True), got)
+    with pytest.raises(ops.TamdError):
+        varlen_q_start(None, {"cu_seq_lens_q": cu, "cu_seq_lens_k": cu}, 2, 12, 12, True)       # not one flattened row
+    with pytest.raises(ops.TamdError):
+        varlen_q_start(None, {"cu_seq_lens_q": cu, "cu_seq_lens_k": torch.tensor([0, 5, 6, 12])}, 1, 12, 12, True)

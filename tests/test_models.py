@@ -6,6 +6,7 @@ reference's backend-parity rule (tests/test_modeling_common.py:199-231: bf16 ato
 gate for hidden states; losses agree to 2e-3 relative; integer paths are exact."""
 import copy
 
+import numpy as np
 import pytest
 import torch
 
@@ -436,6 +437,21 @@ def test_packed_sequences_match_reference_and_separate_runs(env):
         # without position_ids the same tokens are ONE sequence: different logits after the first boundary
         single = fast(input_ids=ids.to(dev), use_cache=False).logits
         assert rel_err(single[:, lens[0]:], packed[:, lens[0]:]) > 5e-2
+        # the reference's varlen kwargs (FlashAttentionKwargs: cu_seq_lens_q/k, max_length_q/k) describe the same packing:
+        # next to the restarting position_ids they change nothing (bit for bit) ...
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=dev)
+        kw = dict(cu_seq_lens_q=cu, cu_seq_lens_k=cu, max_length_q=max(lens), max_length_k=max(lens))
+        both = fast(input_ids=ids.to(dev), position_ids=pos.to(dev), use_cache=False, **kw).logits
+        assert torch.equal(both, packed)
+        # ... and alone (positions 0 .. s-1 run on: the mask factory sees ONE sequence) they still make the attention
+        # block-diagonal: every sequence's slice follows its stand-alone run (rotary angles differ by a per-sequence
+        # offset, which attention scores do not see), unlike the run without them
+        only = fast(input_ids=ids.to(dev), use_cache=False, **kw).logits
+        st = lens[0]
+        for n in lens[1:]:
+            alone = fast(input_ids=ids[:, st:st + n].to(dev), use_cache=False).logits
+            assert rel_err(only[:, st:st + n], alone) < 3e-2 < rel_err(single[:, st:st + n], alone)
+            st += n
     # an overlay the kernels do not implement is refused loudly
     from transformers.masking_utils import and_masks, causal_mask_function, sliding_window_overlay
     from transformers_amd.attention import tamd_mask

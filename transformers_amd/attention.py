@@ -140,6 +140,22 @@ def split_mask(attention_mask, batch: int, kv_len: int):
     return _key_valid_from_mask(attention_mask, batch, kv_len), None
 
 
+def varlen_q_start(q_start, kwargs, batch: int, sq: int, sk: int, causal: bool):
+    """The reference's varlen kwargs (`cu_seq_lens_q / cu_seq_lens_k / max_length_q / max_length_k`,
+    modeling_flash_attention_utils.py:575-590, consumed by its flash path :768-790) for a flattened batch: the same
+    block-diagonal causal attention the mask factory derives from restarting `position_ids` -- used when the mask did not
+    already carry it.  Different query / key boundaries (a KV cache under packing) are refused, not ignored."""
+    cu_q = kwargs.get("cu_seq_lens_q")
+    if q_start is not None or cu_q is None:
+        return q_start
+    cu_k = kwargs.get("cu_seq_lens_k")
+    if batch != 1 or sq != sk or not causal or (cu_k is not None and cu_k is not cu_q and (
+            cu_k.shape != cu_q.shape or not torch.equal(cu_k, cu_q))):
+        raise TamdError("attn_implementation='tamd' takes cu_seq_lens_q/k for one flattened, causal row without a KV cache "
+                        "(equal query and key boundaries)")
+    return ops.q_start_from_cu_seqlens(cu_q, sq)
+
+
 def _key_valid_from_mask(attention_mask, batch: int, kv_len: int) -> Optional[torch.Tensor]:
     if isinstance(attention_mask, TamdMask):  # a fused module path that only knows padding masks
         if attention_mask.q_start is not None:
@@ -199,6 +215,7 @@ def tamd_attention_forward(module, query, key, value, attention_mask, dropout: f
         sk = used  # pre-allocated cache: only the first kv_len key slots are in use (strided views of the cache)
         k, v = k[:, :sk], v[:, :sk]
     key_valid, q_start = split_mask(attention_mask, b, sk)
+    q_start = varlen_q_start(q_start, kwargs, b, sq, sk, causal)
     if q.stride(3) != 1:
         q = q.contiguous()
     if k.stride(3) != 1:

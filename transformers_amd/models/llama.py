@@ -93,6 +93,9 @@ class TamdLlamaAttention(ref.LlamaAttention):
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d)
         from ..attention import split_mask
         key_valid, q_start = split_mask(attention_mask, b, s)
+        if kwargs.get("cu_seq_lens_q") is not None:
+            from ..attention import varlen_q_start
+            q_start = varlen_q_start(q_start, kwargs, b, s, s, bool(self.is_causal) and s > 1)
         o = ops.attention(q, k, v, float(self.scaling), bool(self.is_causal) and s > 1, key_valid,
                           dropout_p=self.attention_dropout if self.training else 0.0, q_start=q_start)
         out = ops.linear(o.view(b, s, hq * d), self.o_proj.weight)
@@ -127,6 +130,9 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
             return hidden_states  # layer 0 replayed the whole stack as one HIP graph: this IS the final hidden state
         from ..attention import split_mask
         key_valid, q_start = split_mask(attention_mask, b, s)
+        if kwargs.get("cu_seq_lens_q") is not None:  # the reference's varlen kwargs for a flattened batch
+            from ..attention import varlen_q_start
+            q_start = varlen_q_start(q_start, kwargs, b, s, s, bool(attn.is_causal) and s > 1)
         if stack is not None and stack[1] == 0 and not self.training:
             out = stack[0].run(hidden_states, cos, sin, key_valid, q_start)
             if out is not None:

@@ -886,6 +886,20 @@ def packed_q_start(seq_ids: torch.Tensor) -> torch.Tensor:
     return torch.stack((start, end)).to(torch.int32).contiguous()
 
 
+def q_start_from_cu_seqlens(cu_seq_lens: torch.Tensor, total: int) -> torch.Tensor:
+    """The reference's varlen description of a flattened batch -- `cu_seq_lens_q` = cumulative sequence lengths [n + 1]
+    (`FlashAttentionKwargs`, modeling_flash_attention_utils.py:575-590; DataCollatorWithFlattening) -- as the two bound
+    planes the kernels take: int32 [2, 1, total] (first / last token of each token's sequence).  Tokens past the last
+    boundary (padding of the flattened row) form one more sequence.  Device-side, no synchronisation."""
+    cu = cu_seq_lens.to(torch.int64).reshape(-1)
+    idx = torch.arange(total, device=cu.device)
+    ends = torch.cat([cu[1:], cu.new_tensor([total])])            # exclusive end of every sequence (+ the padding tail)
+    starts = torch.cat([cu[:-1], cu[-1:].clamp(max=total)])
+    seg = torch.searchsorted(ends, idx, right=True).clamp(max=ends.numel() - 1)
+    start, end = starts[seg], ends[seg] - 1
+    return torch.stack((start, end)).to(torch.int32).view(2, 1, total).contiguous()
+
+
 def embedding(ids, table, padding_idx=None):
     return T.embedding(ids, table, -1 if padding_idx is None else int(padding_idx))
 
