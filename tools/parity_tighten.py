@@ -1,6 +1,7 @@
 """Measured errors of every test gate (tests/conftest.py `Measured`: each `rel_err(...) < limit` comparison records
 itself) from the GPU run (gpurun_out/parity_hip.json) and the CPU-model run (.pytest_cache/parity_emu.json):
-  * writes profiles/r02_parity.json -- measured error, gate, ratio, for both backends;
+  * writes profiles/<round>_parity.json (--round r03, default r02) -- measured error, gate, ratio, for both backends;
+    --hip FILE takes the GPU measurements from a saved copy (profiles/r03c_parity.json) instead of gpurun_out/;
   * with --apply, rewrites a gate's literal in the test source when it is more than 2x the measured error
     (new gate = 2 x measured, rounded up to two significant digits; never below 1e-5; never loosens)."""
 import json
@@ -10,7 +11,12 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-srcs = {"hip": ROOT / "gpurun_out" / "parity_hip.json", "emu": ROOT / ".pytest_cache" / "parity_emu.json"}
+def _arg(flag, default):
+    return sys.argv[sys.argv.index(flag) + 1] if flag in sys.argv else default
+
+
+srcs = {"hip": Path(_arg("--hip", str(ROOT / "gpurun_out" / "parity_hip.json"))),
+        "emu": ROOT / ".pytest_cache" / "parity_emu.json"}
 data = {k: json.loads(p.read_text()) if p.exists() else {} for k, p in srcs.items()}
 gates = {}
 for be, d in data.items():
@@ -40,7 +46,7 @@ for be, d in data.items():
     for grp, v in d.items():
         if grp != "gates":
             out.setdefault("noise_floor_gates_" + be, {})[grp] = v
-(ROOT / "profiles" / "r02_parity.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+(ROOT / "profiles" / f"{_arg('--round', 'r02')}_parity.json").write_text(json.dumps(out, indent=1, sort_keys=True))
 print(f"{len(report)} gates, {len(edits)} looser than 2x the measured error")
 if "--apply" in sys.argv:
     done = 0
