@@ -4,6 +4,8 @@ exec < /dev/null
 # decoder layer / the whole step; the dK/dV kernel's ablations (what its tile feed and barrier cost); LLaVA's kernel profile
 # (the forward is GPU-bound at 28 ms: where); bert-base twice (box variance); the re-set BERT gate.
 # usage: gpurun --timeout 1500 -- bash tools/gpu_r03_d.sh [tag]
+# RECORD of the visit as it ran: the 8-wave kernels, `tools/attn_fwd8_ab.py` and the TAMD_ATTN_FWD8 switch were removed
+# afterwards (not promoted; `git apply profiles/r03d_attn_8wave.patch` on the commit it names brings them back).
 tag=${1:-r03d}
 R=$PWD
 out=$R/gpurun_out
