@@ -39,6 +39,10 @@ namespace {
 #ifdef TAMD_DIAG
 unsigned long long* g_attn_trace = nullptr;
 #endif
+// The forward with 64 query rows per wave (attention_fwd64.hip) where it applies: 0 = never.  The diagnostic library
+// flips it per call (tamd_attn_set_fwd64, A/B runs and the bit-identity test).
+int g_attn_fwd64 = 0;
+int g_attn_fwd64_launches = 0;
 
 template <typename T, int D>
 int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
@@ -134,6 +138,11 @@ extern "C" int tamd_attn_set_trace(void* buf) {
   g_attn_trace = reinterpret_cast<unsigned long long*>(buf);
   return TAMD_OK;
 }
+// 1: tamd_attn_fwd takes the 64-rows-per-wave kernel wherever it applies; returns how many forwards have taken it so far
+extern "C" int tamd_attn_set_fwd64(int on) {
+  g_attn_fwd64 = on;
+  return g_attn_fwd64_launches;
+}
 #endif
 
 extern "C" uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index) {
@@ -145,6 +154,10 @@ extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t str
   if (chk != TAMD_OK) return chk;
   const AttnArgs a = make_args(p);
   hipStream_t s = TAMD_STREAM(stream);
+  if (g_attn_fwd64 && attn_fwd64_applies(a, (int)p->head_dim)) {
+    ++g_attn_fwd64_launches;
+    return attn_fwd64_launch(a, p->causal != 0, (int)p->dtype, s);
+  }
   if (p->head_dim == 128) {
     TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 128>(a, p->causal != 0, s)));
   } else {

@@ -34,6 +34,12 @@ struct AttnArgs {
   unsigned long long* trace;  // diagnostic build: per-phase shader-clock sums of workgroup 0 (tamd_attn_set_trace), else null
 };
 
+// attention_fwd64.hip: the forward with 64 query rows per wave (its own translation unit: compiled WITHOUT
+// -amdgpu-mfma-vgpr-form, it places every MFMA operand itself).  `applies`: head_dim 128, no padding mask / dropout /
+// packed sequences, seq_k a multiple of 64, K and V rows the same distance apart.
+bool attn_fwd64_applies(const AttnArgs& a, int head_dim);
+int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, hipStream_t s);
+
 // Diagnostic build only: phase i of the forward tile loop ends here (s_memtime stamps of workgroup 0, summed per wave)
 #ifdef TAMD_DIAG
 #define TAMD_ATTN_PHASE(i_)                              \
@@ -156,6 +162,25 @@ __device__ __forceinline__ void wait_frag(u32x4& f) {
 #else
   (void)f;
 #endif
+}
+template <int N>
+__device__ __forceinline__ void wait_frag_agpr(u32x4& f) {  // (the fragment lives in AGPRs: lds_read*_abs_agpr)
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(f) : "n"(N) : "memory");
+#else
+  (void)f;
+#endif
+}
+template <int CAP>
+__device__ __forceinline__ void constexpr_wait_frag_agpr(int n, u32x4& f) {
+  static_assert(CAP <= 15, "lgkmcnt is a 4-bit counter");
+  if (n >= CAP) return wait_frag_agpr<CAP>(f);
+#define TAMD_WF(N_) \
+  if (N_ < CAP && n == N_) return wait_frag_agpr<(N_ < CAP ? N_ : 0)>(f);
+  TAMD_WF(14) TAMD_WF(13) TAMD_WF(12) TAMD_WF(11) TAMD_WF(10) TAMD_WF(9) TAMD_WF(8) TAMD_WF(7) TAMD_WF(6) TAMD_WF(5) TAMD_WF(4)
+  TAMD_WF(3) TAMD_WF(2) TAMD_WF(1)
+#undef TAMD_WF
+  wait_frag_agpr<0>(f);
 }
 
 // wait_frag<min(n, CAP)> for a compile-time-foldable n (unrolled loop index arithmetic)
