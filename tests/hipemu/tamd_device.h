@@ -196,6 +196,12 @@ template <typename T>
 inline void mfma32_s(f32x16& d, const u32x4& a, const u32x4& b) { d = mfma32<T>(a, b, d); }
 template <typename T>
 inline void mfma32_o(f32x16& d, const u32x4& a, const u32x4& b) { d = mfma32<T>(a, b, d); }
+template <int N, typename T>
+inline void mfma32_s0_w(const T*, f32x16& d, const u32x4& a, const u32x4& b) { mfma32_s0<T>(d, a, b); }
+template <int N, typename T>
+inline void mfma32_s_w(const T*, f32x16& d, const u32x4& a, const u32x4& b) { mfma32_s<T>(d, a, b); }
+template <int N, typename T>
+inline void mfma32_o_w(const T*, f32x16& d, const u32x4& a, const u32x4& b) { mfma32_o<T>(d, a, b); }
 inline void to_agpr(u32x4&) {}
 inline void to_agpr(f32x16&) {}
 inline void agpr_scale(f32x16& acc, float alpha) {

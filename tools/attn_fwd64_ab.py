@@ -18,27 +18,32 @@ dev = torch.device("cuda:0")
 SHAPES = [("llama3-8b causal", 8, 4096, 32, 8, True), ("llama3-8b bidirectional", 8, 4096, 32, 8, False),
           ("llama2-7b causal (MHA)", 4, 4096, 32, 32, True), ("llava prompt 1088 causal", 1, 1088, 32, 32, True),
           ("seq 2048 causal", 16, 2048, 32, 8, True), ("seq 8192 causal", 2, 8192, 32, 8, True)]
-for name, b, s, hq, hkv, causal in SHAPES:
+for si, (name, b, s, hq, hkv, causal) in enumerate(SHAPES):
+    full = si < 2  # the ablation arms only at the Llama-3-8B shape
     d = 128
     q = torch.randn(b, s, hq, d, device=dev).bfloat16()
     k = torch.randn(b, s, hkv, d, device=dev).bfloat16()
     v = torch.randn(b, s, hkv, d, device=dev).bfloat16()
     scale = 1 / math.sqrt(d)
     fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
-    arms = ["fwd32", "fwd64"]
+    # fwd64 variants of the diagnostic library (attention_fwd64.hip: attn_fwd64_launch); 5-7 are ablations (wrong results)
+    VARIANTS = {"v1": 1, "v2_merge": 2, "v3_merge_late": 3, "v4_merge_late_vpre": 4, "v8_v4_nofence": 8,
+                "abl_no_dma": 5, "abl_no_softmax": 6, "abl_no_dma_no_softmax": 7}
+    arms = ["fwd32"] + [a for a in VARIANTS if full or not a.startswith("abl")]
 
     def select(key):
-        lib.tamd_attn_set_fwd64(int(key == "fwd64"))
+        lib.tamd_attn_set_fwd64(VARIANTS.get(key, 0))
 
     select("fwd32")
     o0, l0 = ops.raw_attn_fwd(q, k, v, scale, causal)
-    select("fwd64")
-    o1, l1 = ops.raw_attn_fwd(q, k, v, scale, causal)
-    same = bool(torch.equal(o0, o1) and torch.equal(l0, l1))
+    same = {}
+    for key in arms[1:]:
+        if key.startswith("abl"):
+            continue
+        select(key)
+        o1, l1 = ops.raw_attn_fwd(q, k, v, scale, causal)
+        same[key] = bool(torch.equal(o0, o1) and torch.equal(l0, l1))
     res = {"shape": name, "bit_identical": same, "ms": {key: [] for key in arms}}
-    if not same:
-        res["max_abs_diff"] = float((o0.float() - o1.float()).abs().max())
-        res["nan"] = bool(torch.isnan(o1.float()).any())
     for rnd in range(3):
         for key in arms:
             select(key)

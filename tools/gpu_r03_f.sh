@@ -10,5 +10,5 @@ mkdir -p $out/$tag
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 timeout 200 python -m pytest tests/test_kernels.py -m gpu -q -k "fwd64" --timeout 180 2>&1 | tail -5 > $out/${tag}_fwd64_test.log
 cat $out/${tag}_fwd64_test.log
-timeout 240 python tools/attn_fwd64_ab.py > $out/${tag}_attn_fwd64_ab.jsonl 2> $out/${tag}_attn_fwd64_ab.err
+timeout 400 python tools/attn_fwd64_ab.py > $out/${tag}_attn_fwd64_ab.jsonl 2> $out/${tag}_attn_fwd64_ab.err
 echo "ab exit $?"; cut -c1-400 $out/${tag}_attn_fwd64_ab.jsonl; tail -3 $out/${tag}_attn_fwd64_ab.err

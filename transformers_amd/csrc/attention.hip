@@ -156,7 +156,7 @@ extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t str
   hipStream_t s = TAMD_STREAM(stream);
   if (g_attn_fwd64 && attn_fwd64_applies(a, (int)p->head_dim)) {
     ++g_attn_fwd64_launches;
-    return attn_fwd64_launch(a, p->causal != 0, (int)p->dtype, s);
+    return attn_fwd64_launch(a, p->causal != 0, (int)p->dtype, g_attn_fwd64, s);
   }
   if (p->head_dim == 128) {
     TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 128>(a, p->causal != 0, s)));

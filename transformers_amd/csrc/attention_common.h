@@ -38,7 +38,7 @@ struct AttnArgs {
 // -amdgpu-mfma-vgpr-form, it places every MFMA operand itself).  `applies`: head_dim 128, no padding mask / dropout /
 // packed sequences, seq_k a multiple of 64, K and V rows the same distance apart.
 bool attn_fwd64_applies(const AttnArgs& a, int head_dim);
-int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, hipStream_t s);
+int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hipStream_t s);
 
 // Diagnostic build only: phase i of the forward tile loop ends here (s_memtime stamps of workgroup 0, summed per wave)
 #ifdef TAMD_DIAG

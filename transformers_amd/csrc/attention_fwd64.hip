@@ -21,8 +21,33 @@ namespace tamd {
 
 constexpr int kQB64 = 256;  // query rows per workgroup (64 per wave)
 
-template <typename T, bool CAUSAL>
+// schedule variants (VAR bits; the diagnostic library instantiates several for A/B runs and ablations)
+constexpr int kF64Merge = 1;    // the lgkmcnt wait of a fragment inside the statement of the MFMA that consumes it
+constexpr int kF64Late = 2;     // LDS-DMA pieces behind MFMAs 25, 27, 29, 31 of a phase (no LDS reads, little VALU there)
+constexpr int kF64VPre = 4;     // the first V fragments of phase Y requested behind the last K requests of phase X
+constexpr int kF64NoDma = 8;    // ABLATION (wrong results): no tile loads in the loop
+constexpr int kF64NoSm = 16;    // ABLATION (wrong results): no softmax arithmetic
+constexpr int kF64NoFence = 32; // no scheduling fences between the MFMA groups
+
+// MFMA kind K (0: S = a.b, 1: S += a.b, 2: O += a.b) behind `s_waitcnt lgkmcnt(min(n, CAP))`, n foldable
+template <typename T, int CAP, int K>
+__device__ __forceinline__ void mfma_after_wait(int n, f32x16& d, const u32x4& a, const u32x4& b) {
+  static_assert(CAP <= 8, "extend the chain");
+#define TAMD_MW(N_)                                                     \
+  if ((n >= CAP ? CAP : n) == N_) {                                     \
+    if (K == 0) mfma32_s0_w<N_>((const T*)nullptr, d, a, b);            \
+    else if (K == 1) mfma32_s_w<N_>((const T*)nullptr, d, a, b);        \
+    else mfma32_o_w<N_>((const T*)nullptr, d, a, b);                    \
+    return;                                                             \
+  }
+  TAMD_MW(8) TAMD_MW(7) TAMD_MW(6) TAMD_MW(5) TAMD_MW(4) TAMD_MW(3) TAMD_MW(2) TAMD_MW(1) TAMD_MW(0)
+#undef TAMD_MW
+}
+
+template <typename T, bool CAUSAL, int VAR>
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a) {
+  constexpr bool MERGE = (VAR & kF64Merge) != 0, LATE = (VAR & kF64Late) != 0, VPRE = (VAR & kF64VPre) != 0;
+  constexpr bool DMA = (VAR & kF64NoDma) == 0, SM = (VAR & kF64NoSm) == 0, FENCE = (VAR & kF64NoFence) == 0;
   constexpr int D = 128, ROWB = D * 2, TILEB = kKB * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
   constexpr int NBUF = 4, LA = NBUF - 1;  // ring depth; tiles requested ahead
   TAMD_DYN_SMEM(smem);
@@ -130,6 +155,12 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
 
   f32x16 s0[2][2], s1[2][2];  // S^T of the current / the next tile: [block][32-key sub-tile]
   u32x4 pf[2][4];             // P^T fragments (MFMA B operand): [block][16-key step]
+  if (!SM) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pf[blk][j] = u32x4{0, 0, 0, 0};
+  }
   constexpr int NF = 2 * KS, KA = 4;   // K fragments of a tile; requested ahead (each feeds two MFMAs)
   constexpr int NV = DT * 4, VA = 4;   // V fragments of a tile (two transposing reads each); requested ahead
 
@@ -146,12 +177,25 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     return u32x4{lo[0], lo[1], h2[0], h2[1]};
   };
   // MFMA step (fragment i, block blk) of sn = K . Q^T: per accumulator the k-steps in order, as in attn_fwd_kernel
-  auto qk_step = [&](f32x16 (&sn)[2][2], const u32x4& kfrag, int i, int blk) __attribute__((always_inline)) {
+  // (nwait >= 0: the fragment's lgkmcnt wait rides in the MFMA's statement)
+  auto qk_step = [&](f32x16 (&sn)[2][2], const u32x4& kfrag, int i, int blk, int nwait) __attribute__((always_inline)) {
     const int sub = i & 1, ks = i >> 1;
-    if (ks == 0)
+    if (nwait >= 0) {
+      if (ks == 0)
+        mfma_after_wait<T, 8, 0>(nwait, sn[blk][sub], kfrag, qf[blk][ks]);
+      else
+        mfma_after_wait<T, 8, 1>(nwait, sn[blk][sub], kfrag, qf[blk][ks]);
+    } else if (ks == 0) {
       mfma32_s0<T>(sn[blk][sub], kfrag, qf[blk][ks]);
-    else
+    } else {
       mfma32_s<T>(sn[blk][sub], kfrag, qf[blk][ks]);
+    }
+  };
+  // gap m of a phase -> the piece (0..3) issued behind that MFMA, or -1
+  auto piece_of_gap = [&](int m) __attribute__((always_inline)) -> int {
+    if (!DMA) return -1;
+    if (LATE) return (m >= 25 && (m & 1)) ? (m - 25) >> 1 : -1;
+    return (m & 7) == 5 ? m >> 3 : -1;
   };
 
   // one key tile of a wave that still computes: sc = S(t) (ready), sn = S(t+1) (computed here).  The pieces of tile
@@ -163,7 +207,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     const int kt0 = t * kKB;
     const unsigned kbn = lds0 + (unsigned)((t + 1) % NBUF) * 2u * TILEB;       // K(t+1)
     const unsigned vb = lds0 + (unsigned)(t % NBUF) * 2u * TILEB + TILEB;      // V(t)
-    if (CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform): key kp visible to row q iff kp <= q + off
+    if (SM && CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform): key kp visible to row q iff kp <= q + off
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         const int lim = qw0 + blk * 32 + l31 + off - kt0 - 4 * hi;  // key index inside the tile, less the lane's 4 * hi
@@ -208,7 +252,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
       if (q == 15) l_run[blk] += psum[blk];
     };
     // ---- phase X: 32 MFMAs of S(t+1); behind MFMA m: block A: max 0-1, finish 2, exponentials 3-18; block B: max
-    // 19-20, finish 21, the exponentials of its first 8 values (P fragment 0) 22-25; pieces 0-3 behind 5, 13, 21, 29
+    // 19-20, finish 21, the exponentials of its first 8 values (P fragment 0) 22-25; four pieces (piece_of_gap)
+    u32x4 vr[VA + 1];
     {
       u32x4 kr[KA + 1];
 #pragma unroll
@@ -216,39 +261,49 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
 #pragma unroll
       for (int i = 0; i < NF; ++i) {
         if (i + KA < NF) kr[(i + KA) % (KA + 1)] = kreq(kbn, i + KA);
-        constexpr_wait_frag_agpr<KA>(NF - 1 - i, kr[i % (KA + 1)]);
+        if (VPRE && i >= NF - VA) vr[i - (NF - VA)] = vreq(vb, i - (NF - VA));
+        // reads issued after fragment i's: the later K fragments, and the V fragments requested so far
+        const int after = (NF - 1 - i < KA ? NF - 1 - i : KA) + ((VPRE && i >= NF - VA) ? 2 * (i - (NF - VA) + 1) : 0);
+        if (!MERGE) constexpr_wait_frag_agpr<8>(after, kr[i % (KA + 1)]);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
           const int m = 2 * i + blk;
-          qk_step(sn, kr[i % (KA + 1)], i, blk);
-          if (m < 2) sm_max(0, m);
-          else if (m == 2) sm_fin(0);
-          else if (m < 19) sm_exp(0, m - 3);
-          else if (m < 21) sm_max(1, m - 19);
-          else if (m == 21) sm_fin(1);
-          else if (m < 26) sm_exp(1, m - 22);
-          if ((m & 7) == 5) issue_piece(tp, tpb, m >> 3);
-          sched_fence();
+          qk_step(sn, kr[i % (KA + 1)], i, blk, (MERGE && blk == 0) ? after : -1);
+          if (SM) {
+            if (m < 2) sm_max(0, m);
+            else if (m == 2) sm_fin(0);
+            else if (m < 19) sm_exp(0, m - 3);
+            else if (m < 21) sm_max(1, m - 19);
+            else if (m == 21) sm_fin(1);
+            else if (m < 26) sm_exp(1, m - 22);
+          }
+          if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, piece_of_gap(m));
+          if (FENCE) sched_fence();
         }
       }
     }
     // ---- phase Y: 32 MFMAs of O^T += V^T . P^T (16-key step outer, d-tile inner, per fragment block A then B);
-    // block B's exponentials 4-15 behind MFMAs 0-11 (P fragment j of B is first read by MFMA 8 j + 1); pieces 4-7
+    // block B's exponentials 4-15 behind MFMAs 0-11 (P fragment j of B is first read by MFMA 8 j + 1); four pieces
     {
-      u32x4 vr[VA + 1];
+      if (!VPRE) {
 #pragma unroll
-      for (int i = 0; i < VA; ++i) vr[i] = vreq(vb, i);
+        for (int i = 0; i < VA; ++i) vr[i] = vreq(vb, i);
+      }
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         if (i + VA < NV) vr[(i + VA) % (VA + 1)] = vreq(vb, i + VA);
-        constexpr_wait_frag<2 * VA>(2 * (NV - 1 - i), vr[i % (VA + 1)]);
+        const int after = 2 * (NV - 1 - i < VA ? NV - 1 - i : VA);
+        if (!MERGE) constexpr_wait_frag<2 * VA>(after, vr[i % (VA + 1)]);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
           const int m = 2 * i + blk;
-          mfma32_o<T>(oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
-          if (m < 12) sm_exp(1, m + 4);
-          if ((m & 7) == 5) issue_piece(tp, tpb, NI + (m >> 3));
-          sched_fence();
+          if (MERGE && blk == 0)
+            mfma_after_wait<T, 8, 2>(after, oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
+          else
+            mfma32_o<T>(oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
+          if (SM && m < 12) sm_exp(1, m + 4);
+          if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, NI + piece_of_gap(m));
+          if (FENCE) sched_fence();
         }
       }
     }
@@ -267,8 +322,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     for (int i = 0; i < NF; ++i) {
       if (i + KA < NF) kr[(i + KA) % (KA + 1)] = kreq(kb0, i + KA);
       constexpr_wait_frag_agpr<KA>(NF - 1 - i, kr[i % (KA + 1)]);
-      qk_step(s0, kr[i % (KA + 1)], i, 0);
-      qk_step(s0, kr[i % (KA + 1)], i, 1);
+      qk_step(s0, kr[i % (KA + 1)], i, 0, -1);
+      qk_step(s0, kr[i % (KA + 1)], i, 1, -1);
     }
     nop_states<16>();  // (S(0) is read by the VALU a few instructions into tile 0)
   }
@@ -279,8 +334,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
   // past its last tile the wave only loads: its share of the pieces of the tiles the other waves still need
   for (int t = tw + 1; t < nkt; ++t) {
     const int tp = (t + LA < nkt) ? t + LA : nkt - 1;
+    if (DMA) {
 #pragma unroll
-    for (int n = 0; n < NP; ++n) issue_piece(tp, (t + LA) % NBUF, n);
+      for (int n = 0; n < NP; ++n) issue_piece(tp, (t + LA) % NBUF, n);
+    }
     wait_vmcnt<NP>();
     raw_barrier();
   }
@@ -321,16 +378,15 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
   }
 }
 
-// (declared in attention_common.h) true if the launch was taken
-template <typename T>
+template <typename T, int VAR>
 static int fwd64_launch_t(const AttnArgs& a, bool causal, hipStream_t s) {
   const int nqt64 = (a.seq_q + kQB64 - 1) / kQB64;
   dim3 grid((unsigned)(nqt64 * a.heads_q * a.batch)), block(kAttnThreads);
   const size_t smem = (size_t)4 * 2 * kKB * 128 * 2;  // 4 x (K + V) = 128 KiB (covers the O staging: 8 x 32 x 272 B)
   if (causal)
-    hipLaunchKernelGGL((attn_fwd64_kernel<T, true>), grid, block, smem, s, a);
+    hipLaunchKernelGGL((attn_fwd64_kernel<T, true, VAR>), grid, block, smem, s, a);
   else
-    hipLaunchKernelGGL((attn_fwd64_kernel<T, false>), grid, block, smem, s, a);
+    hipLaunchKernelGGL((attn_fwd64_kernel<T, false, VAR>), grid, block, smem, s, a);
   return launch_status();
 }
 
@@ -339,8 +395,26 @@ bool attn_fwd64_applies(const AttnArgs& a, int head_dim) {
          a.kss == a.vss && TileFeed<128>::usable(a.kss);
 }
 
-int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, hipStream_t s) {
-  TAMD_DISPATCH_HALF(dtype, return fwd64_launch_t<T>(a, causal, s));
+constexpr int kF64Default = 0;  // the product schedule
+
+// `variant`: 1 = the product schedule; the diagnostic library has more (tamd_attn_set_fwd64, bf16 only)
+int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hipStream_t s) {
+#ifdef TAMD_DIAG
+  if (variant > 1 && dtype == TAMD_BF16) {
+    switch (variant) {
+      case 2: return fwd64_launch_t<bf16_t, kF64Merge>(a, causal, s);
+      case 3: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late>(a, causal, s);
+      case 4: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre>(a, causal, s);
+      case 5: return fwd64_launch_t<bf16_t, kF64NoDma>(a, causal, s);
+      case 6: return fwd64_launch_t<bf16_t, kF64NoSm>(a, causal, s);
+      case 7: return fwd64_launch_t<bf16_t, kF64NoDma | kF64NoSm>(a, causal, s);
+      case 8: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64NoFence>(a, causal, s);
+      default: return TAMD_E_ARG;
+    }
+  }
+#endif
+  (void)variant;
+  TAMD_DISPATCH_HALF(dtype, return (fwd64_launch_t<T, kF64Default>(a, causal, s)));
   return TAMD_E_DTYPE;
 }
 

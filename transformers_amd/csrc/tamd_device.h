@@ -128,6 +128,24 @@ __device__ __forceinline__ void mfma32_o(f32x16& d, const u32x4& a, const u32x4&
 TAMD_MFMA32_ASM_(bf16_t, "v_mfma_f32_32x32x16_bf16")
 TAMD_MFMA32_ASM_(f16_t, "v_mfma_f32_32x32x16_f16")
 #undef TAMD_MFMA32_ASM_
+// ... with `s_waitcnt lgkmcnt(N)` in front of the MFMA in the SAME statement: operand `a` was filled by an untracked LDS
+// read; a separate wait statement costs the compiler's boundary pad (an s_nop) before the MFMA that reads its operand
+#define TAMD_MFMA32_WASM_(T_, MNEM_)                                                                          \
+  template <int N>                                                                                            \
+  __device__ __forceinline__ void mfma32_s0_w(const T_*, f32x16& d, const u32x4& a, const u32x4& b) {        \
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" MNEM_ " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b), "n"(N));    \
+  }                                                                                                           \
+  template <int N>                                                                                            \
+  __device__ __forceinline__ void mfma32_s_w(const T_*, f32x16& d, const u32x4& a, const u32x4& b) {         \
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" MNEM_ " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b), "n"(N));    \
+  }                                                                                                           \
+  template <int N>                                                                                            \
+  __device__ __forceinline__ void mfma32_o_w(const T_*, f32x16& d, const u32x4& a, const u32x4& b) {         \
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" MNEM_ " %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b), "n"(N));    \
+  }
+TAMD_MFMA32_WASM_(bf16_t, "v_mfma_f32_32x32x16_bf16")
+TAMD_MFMA32_WASM_(f16_t, "v_mfma_f32_32x32x16_f16")
+#undef TAMD_MFMA32_WASM_
 __device__ __forceinline__ void to_agpr(u32x4& v) { asm volatile("" : "+a"(v)); }
 __device__ __forceinline__ void to_agpr(f32x16& v) { asm volatile("" : "+a"(v)); }
 // acc (held in AGPRs) *= alpha, element by element through one VGPR: the accumulator stays where it is on both sides of
