@@ -209,6 +209,7 @@ inline void agpr_scale(f32x16& acc, float alpha) {
 }
 inline void pin_here(unsigned&, float&) {}
 inline void pin_here(float&) {}
+inline void pin_here(float&, float&) {}
 template <int N>
 inline void nop_states() {}
 template <typename T>

@@ -28,6 +28,7 @@ constexpr int kF64VPre = 4;     // the first V fragments of phase Y requested be
 constexpr int kF64NoDma = 8;    // ABLATION (wrong results): no tile loads in the loop
 constexpr int kF64NoSm = 16;    // ABLATION (wrong results): no softmax arithmetic
 constexpr int kF64NoFence = 32; // no scheduling fences between the MFMA groups
+constexpr int kF64Pipe = 64;    // the exponentials as a 3-stage pipeline over the gaps: no instruction of a gap reads a result of that gap
 
 // MFMA kind K (0: S = a.b, 1: S += a.b, 2: O += a.b) behind `s_waitcnt lgkmcnt(min(n, CAP))`, n foldable
 template <typename T, int CAP, int K>
@@ -48,6 +49,7 @@ template <typename T, bool CAUSAL, int VAR>
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a) {
   constexpr bool MERGE = (VAR & kF64Merge) != 0, LATE = (VAR & kF64Late) != 0, VPRE = (VAR & kF64VPre) != 0;
   constexpr bool DMA = (VAR & kF64NoDma) == 0, SM = (VAR & kF64NoSm) == 0, FENCE = (VAR & kF64NoFence) == 0;
+  constexpr bool PIPE = (VAR & kF64Pipe) != 0;
   constexpr int D = 128, ROWB = D * 2, TILEB = kKB * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
   constexpr int NBUF = 4, LA = NBUF - 1;  // ring depth; tiles requested ahead
   TAMD_DYN_SMEM(smem);
@@ -222,8 +224,18 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     float mx[2] = {0.f, 0.f}, mref[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
     auto sm_max = [&](int blk, int sub) __attribute__((always_inline)) {
       float m = sub == 0 ? sc[blk][0][0] : mx[blk];
+      if (PIPE) {  // two chains (max is exact in any order)
+        float m2 = sc[blk][sub][8];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[blk][sub][r]);
+        for (int r = 0; r < 8; ++r) {
+          m = fmaxf(m, sc[blk][sub][r]);
+          m2 = fmaxf(m2, sc[blk][sub][8 + r]);
+        }
+        m = fmaxf(m, m2);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[blk][sub][r]);
+      }
       pin_here(m);
       mx[blk] = m;
     };
@@ -251,6 +263,35 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
       pf[blk][sub * 2 + (r >> 3)][(r & 7) >> 1] = w;
       if (q == 15) l_run[blk] += psum[blk];
     };
+    // The same exponentials as a pipeline: step st of a block does stage 1 (the two fused multiply-adds) of value pair st,
+    // stage 2 (the two exp2) of pair st - 1 and stage 3 (row sum, rounding to the storage type) of pair st - 2, so that
+    // every input of a gap was produced in an earlier gap -- the wave issues in order, and fma -> exp2 -> add -> cvt
+    // of ONE pair inside a gap is a chain of result latencies that no MFMA hides.  Steps 0 .. 17 per block; the row sum
+    // still adds the values in their order.
+    float xs[2][32], es[2][32];
+    auto sm_step = [&](int blk, int st) __attribute__((always_inline)) {
+      if (st >= 2) psum[blk] += es[blk][2 * (st - 2)];
+      if (st < 16) {
+        const int sub = st >> 3, r = 2 * (st & 7);
+        xs[blk][2 * st] = __builtin_fmaf(sc[blk][sub][r], a.scale_log2, -mref[blk]);
+        xs[blk][2 * st + 1] = __builtin_fmaf(sc[blk][sub][r + 1], a.scale_log2, -mref[blk]);
+        pin_here(xs[blk][2 * st], xs[blk][2 * st + 1]);
+      }
+      if (st >= 1 && st <= 16) {
+        const int q = st - 1;
+        es[blk][2 * q] = fast_exp2(xs[blk][2 * q]);
+        es[blk][2 * q + 1] = fast_exp2(xs[blk][2 * q + 1]);
+        pin_here(es[blk][2 * q], es[blk][2 * q + 1]);
+      }
+      if (st >= 2) {
+        const int q = st - 2, sub = q >> 3, r = 2 * (q & 7);
+        psum[blk] += es[blk][2 * q + 1];
+        unsigned w = pack2<T>(es[blk][2 * q], es[blk][2 * q + 1]);
+        pin_here(w, psum[blk]);
+        pf[blk][sub * 2 + (r >> 3)][(r & 7) >> 1] = w;
+        if (q == 15) l_run[blk] += psum[blk];
+      }
+    };
     // ---- phase X: 32 MFMAs of S(t+1); behind MFMA m: block A: max 0-1, finish 2, exponentials 3-18; block B: max
     // 19-20, finish 21, the exponentials of its first 8 values (P fragment 0) 22-25; four pieces (piece_of_gap)
     u32x4 vr[VA + 1];
@@ -269,13 +310,21 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
         for (int blk = 0; blk < 2; ++blk) {
           const int m = 2 * i + blk;
           qk_step(sn, kr[i % (KA + 1)], i, blk, (MERGE && blk == 0) ? after : -1);
-          if (SM) {
+          if (SM && !PIPE) {
             if (m < 2) sm_max(0, m);
             else if (m == 2) sm_fin(0);
             else if (m < 19) sm_exp(0, m - 3);
             else if (m < 21) sm_max(1, m - 19);
             else if (m == 21) sm_fin(1);
             else if (m < 26) sm_exp(1, m - 22);
+          }
+          if (SM && PIPE) {  // block A: max 0-1, finish 2, steps 0-17 behind 3-20; block B: max 21-22, finish 23, steps 0-7
+            if (m < 2) sm_max(0, m);
+            else if (m == 2) sm_fin(0);
+            else if (m < 21) sm_step(0, m - 3);
+            else if (m < 23) sm_max(1, m - 21);
+            else if (m == 23) sm_fin(1);
+            else sm_step(1, m - 24);
           }
           if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, piece_of_gap(m));
           if (FENCE) sched_fence();
@@ -301,7 +350,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
             mfma_after_wait<T, 8, 2>(after, oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
           else
             mfma32_o<T>(oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
-          if (SM && m < 12) sm_exp(1, m + 4);
+          if (SM && !PIPE && m < 12) sm_exp(1, m + 4);
+          if (SM && PIPE && m < 10) sm_step(1, m + 8);  // (P fragment 1 of B is complete before Y starts, 2 at gap 5, 3 at 9)
           if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, NI + piece_of_gap(m));
           if (FENCE) sched_fence();
         }
@@ -409,6 +459,8 @@ int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hi
       case 6: return fwd64_launch_t<bf16_t, kF64NoSm>(a, causal, s);
       case 7: return fwd64_launch_t<bf16_t, kF64NoDma | kF64NoSm>(a, causal, s);
       case 8: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64NoFence>(a, causal, s);
+      case 9: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64Pipe>(a, causal, s);
+      case 10: return fwd64_launch_t<bf16_t, kF64Pipe>(a, causal, s);
       default: return TAMD_E_ARG;
     }
   }

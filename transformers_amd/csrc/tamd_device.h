@@ -165,6 +165,7 @@ __device__ __forceinline__ void agpr_scale(f32x16& acc, float alpha) {
 // arithmetic below it)
 __device__ __forceinline__ void pin_here(unsigned& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pin_here(float& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin_here(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 template <int N>
 __device__ __forceinline__ void nop_states() { asm volatile("s_nop %0" ::"n"(N - 1)); }  // N <= 16 wait states
 
