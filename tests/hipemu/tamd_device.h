@@ -210,6 +210,10 @@ inline void agpr_scale(f32x16& acc, float alpha) {
 inline void pin_here(unsigned&, float&) {}
 inline void pin_here(float&) {}
 inline void pin_here(float&, float&) {}
+inline void pin_here(float&, float&, float&) {}
+#define TAMD_PIN1(a_) ((void)0)
+#define TAMD_PIN2(a_, b_) ((void)0)
+#define TAMD_PIN3(a_, b_, c_) ((void)0)
 template <int N>
 inline void nop_states() {}
 template <typename T>

@@ -28,6 +28,7 @@ constexpr int kF64VPre = 4;     // the first V fragments of phase Y requested be
 constexpr int kF64NoDma = 8;    // ABLATION (wrong results): no tile loads in the loop
 constexpr int kF64NoSm = 16;    // ABLATION (wrong results): no softmax arithmetic
 constexpr int kF64NoFence = 32; // no scheduling fences between the MFMA groups
+constexpr int kF64Uniform = 128; // one value of the softmax per MFMA gap over BOTH phases, the row maximum of S(t+1) under P.V of tile t
 constexpr int kF64Pipe = 64;    // the exponentials as a 3-stage pipeline over the gaps: no instruction of a gap reads a result of that gap
 
 // MFMA kind K (0: S = a.b, 1: S += a.b, 2: O += a.b) behind `s_waitcnt lgkmcnt(min(n, CAP))`, n foldable
@@ -49,7 +50,7 @@ template <typename T, bool CAUSAL, int VAR>
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a) {
   constexpr bool MERGE = (VAR & kF64Merge) != 0, LATE = (VAR & kF64Late) != 0, VPRE = (VAR & kF64VPre) != 0;
   constexpr bool DMA = (VAR & kF64NoDma) == 0, SM = (VAR & kF64NoSm) == 0, FENCE = (VAR & kF64NoFence) == 0;
-  constexpr bool PIPE = (VAR & kF64Pipe) != 0;
+  constexpr bool PIPE = (VAR & kF64Pipe) != 0, UNI = (VAR & kF64Uniform) != 0;
   constexpr int D = 128, ROWB = D * 2, TILEB = kKB * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
   constexpr int NBUF = 4, LA = NBUF - 1;  // ring depth; tiles requested ahead
   TAMD_DYN_SMEM(smem);
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     return (m & 7) == 5 ? m >> 3 : -1;
   };
 
+  float mxc[2] = {0.f, 0.f};  // UNI: the raw maximum of S(t) per block (this lane's keys), computed under P.V of tile t-1
   // one key tile of a wave that still computes: sc = S(t) (ready), sn = S(t+1) (computed here).  The pieces of tile
   // t + LA go out unconditionally: past the workgroup's last tile the index is clamped (the last tile is fetched again
   // into a free ring slot -- no branches and one vmcnt count in the loop, for three redundant tile loads per workgroup)
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     const int kt0 = t * kKB;
     const unsigned kbn = lds0 + (unsigned)((t + 1) % NBUF) * 2u * TILEB;       // K(t+1)
     const unsigned vb = lds0 + (unsigned)(t % NBUF) * 2u * TILEB + TILEB;      // V(t)
-    if (SM && CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform): key kp visible to row q iff kp <= q + off
+    if (SM && !UNI && CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform): key kp visible to row q iff kp <= q + off
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         const int lim = qw0 + blk * 32 + l31 + off - kt0 - 4 * hi;  // key index inside the tile, less the lane's 4 * hi
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
       }
     }
     // ---- the online softmax of sc in slices (the arithmetic of attn_fwd_kernel in its order)
-    float mx[2] = {0.f, 0.f}, mref[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
+    float mx[2] = {mxc[0], mxc[1]}, mref[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
     auto sm_max = [&](int blk, int sub) __attribute__((always_inline)) {
       float m = sub == 0 ? sc[blk][0][0] : mx[blk];
       if (PIPE) {  // two chains (max is exact in any order)
@@ -292,6 +294,51 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
         if (q == 15) l_run[blk] += psum[blk];
       }
     };
+    // UNI: the exponentials as ONE stream of 64 values (block A's 32, then block B's) in three pipeline stages, step k =
+    // stage 1 of value k, stage 2 of value k - 1, stage 3 of value k - 2 (k = 0 .. 65): 42 steps in phase X (P of block A
+    // and the first fragment of B complete), one per gap in phase Y (value 47 -- B's fragment 1 -- at gap 7, read by MFMA
+    // 9; fragment 2 at 15 / 17, fragment 3 at 23 / 25).  At most ~5 instructions beside every MFMA in both phases.
+    float xv[64], ev[64];
+    auto vstep = [&](int k) __attribute__((always_inline)) {
+      // (the inputs of the step pass through an empty volatile statement: it stays BEHIND the gap's MFMA statement, so
+      // the arithmetic cannot be hoisted in front of that MFMA -- which would put two gaps' work into one)
+      if (k >= 2 && k < 64) TAMD_PIN3(ev[k - 2], xv[k - 1], sc[(k & 63) >> 5][(k & 31) >> 4][k & 15]);
+      else if (k == 1) TAMD_PIN2(xv[k - 1], sc[0][0][1]);
+      else if (k == 0) TAMD_PIN1(sc[0][0][0]);
+      else if (k == 64) TAMD_PIN2(ev[k - 2], xv[k - 1]);
+      else TAMD_PIN1(ev[k - 2]);
+      if (k >= 2) {
+        const int v = k - 2, blk = v >> 5, idx = v & 31, sub = idx >> 4, r = idx & 15;
+        psum[blk] += ev[v];
+        if (r & 1) {
+          unsigned w = pack2<T>(ev[v - 1], ev[v]);
+          pin_here(w, psum[blk]);
+          pf[blk][sub * 2 + (r >> 3)][(r & 7) >> 1] = w;
+        } else {
+          pin_here(psum[blk]);
+        }
+        if (idx == 31) l_run[blk] += psum[blk];
+      }
+      if (k < 64) {
+        const int blk = k >> 5, idx = k & 31, sub = idx >> 4, r = idx & 15;
+        xv[k] = __builtin_fmaf(sc[blk][sub][r], a.scale_log2, -mref[blk]);
+        pin_here(xv[k]);
+      }
+      if (k >= 1 && k <= 64) {
+        ev[k - 1] = fast_exp2(xv[k - 1]);
+        pin_here(ev[k - 1]);
+      }
+    };
+    // UNI: the raw maximum of sn = S(t+1), two values behind each MFMA of phase Y (block g >> 4, sub-tile (g >> 3) & 1)
+    float mxn[2] = {0.f, 0.f};
+    auto next_max = [&](int g) __attribute__((always_inline)) {
+      const int blk = g >> 4, sub = (g >> 3) & 1, r = 2 * (g & 7);
+      TAMD_PIN2(sn[blk][sub][r], sn[blk][sub][r + 1]);  // (behind the gap's MFMA, as in vstep)
+      const float m0 = (g & 15) == 0 ? sn[blk][sub][r] : mxn[blk];
+      float m = fmaxf(fmaxf(m0, sn[blk][sub][r]), sn[blk][sub][r + 1]);
+      pin_here(m);
+      mxn[blk] = m;
+    };
     // ---- phase X: 32 MFMAs of S(t+1); behind MFMA m: block A: max 0-1, finish 2, exponentials 3-18; block B: max
     // 19-20, finish 21, the exponentials of its first 8 values (P fragment 0) 22-25; four pieces (piece_of_gap)
     u32x4 vr[VA + 1];
@@ -310,7 +357,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
         for (int blk = 0; blk < 2; ++blk) {
           const int m = 2 * i + blk;
           qk_step(sn, kr[i % (KA + 1)], i, blk, (MERGE && blk == 0) ? after : -1);
-          if (SM && !PIPE) {
+          if (SM && !PIPE && !UNI) {
             if (m < 2) sm_max(0, m);
             else if (m == 2) sm_fin(0);
             else if (m < 19) sm_exp(0, m - 3);
@@ -318,7 +365,15 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
             else if (m == 21) sm_fin(1);
             else if (m < 26) sm_exp(1, m - 22);
           }
-          if (SM && PIPE) {  // block A: max 0-1, finish 2, steps 0-17 behind 3-20; block B: max 21-22, finish 23, steps 0-7
+          if (SM && UNI) {  // finish of both blocks (their maxima are there), then 42 steps of the value stream over 30 gaps
+            if (m < 2) sm_fin(m);
+            else {
+              const int k0 = ((m - 2) * 42) / 30, k1 = ((m - 1) * 42) / 30;  // (one or two steps)
+              vstep(k0);
+              if (k1 - k0 > 1) vstep(k0 + 1);
+            }
+          }
+          if (SM && PIPE && !UNI) {  // block A: max 0-1, finish 2, steps 0-17 behind 3-20; block B: max 21-22, finish 23, steps 0-7
             if (m < 2) sm_max(0, m);
             else if (m == 2) sm_fin(0);
             else if (m < 21) sm_step(0, m - 3);
@@ -338,6 +393,19 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
 #pragma unroll
         for (int i = 0; i < VA; ++i) vr[i] = vreq(vb, i);
       }
+      if (SM && UNI && CAUSAL && (kt0 + 2 * kKB - 1 > qw0 + off)) {  // tile t+1 is a diagonal tile of this wave: mask S(t+1)
+        nop_states<16>();                                              // (its last MFMAs were issued a moment ago)
+        nop_states<16>();
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const int lim = qw0 + blk * 32 + l31 + off - (kt0 + kKB) - 4 * hi;
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              sn[blk][sub][r] = (sub * 32 + (r & 3) + 8 * (r >> 2) <= lim) ? sn[blk][sub][r] : -INFINITY;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         if (i + VA < NV) vr[(i + VA) % (VA + 1)] = vreq(vb, i + VA);
@@ -350,12 +418,20 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
             mfma_after_wait<T, 8, 2>(after, oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
           else
             mfma32_o<T>(oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
-          if (SM && !PIPE && m < 12) sm_exp(1, m + 4);
-          if (SM && PIPE && m < 10) sm_step(1, m + 8);  // (P fragment 1 of B is complete before Y starts, 2 at gap 5, 3 at 9)
+          if (SM && UNI) {
+            if (m < 24) vstep(42 + m);
+            next_max(m);
+          }
+          if (SM && !PIPE && !UNI && m < 12) sm_exp(1, m + 4);
+          if (SM && PIPE && !UNI && m < 10) sm_step(1, m + 8);  // (P fragment 1 of B is complete before Y starts, 2 at gap 5, 3 at 9)
           if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, NI + piece_of_gap(m));
           if (FENCE) sched_fence();
         }
       }
+    }
+    if (UNI) {
+      mxc[0] = mxn[0];
+      mxc[1] = mxn[1];
     }
     // hand-off: tile t+2 has landed (the pieces just issued may stay in flight); every wave is done with V(t) and K(t+1)
     wait_vmcnt<NP>();
@@ -376,6 +452,29 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
       qk_step(s0, kr[i % (KA + 1)], i, 1, -1);
     }
     nop_states<16>();  // (S(0) is read by the VALU a few instructions into tile 0)
+    if (UNI && SM) {
+      nop_states<16>();
+      if (CAUSAL && (kKB - 1 > qw0 + off)) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const int lim = qw0 + blk * 32 + l31 + off - 4 * hi;
+#pragma unroll
+          for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              s0[blk][sub][r] = (sub * 32 + (r & 3) + 8 * (r >> 2) <= lim) ? s0[blk][sub][r] : -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        float m = s0[blk][0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, s0[blk][sub][r]);
+        mxc[blk] = m;
+      }
+    }
   }
   for (int t = 0; t <= tw; t += 2) {
     tile(t, s0, s1);
@@ -461,6 +560,8 @@ int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hi
       case 8: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64NoFence>(a, causal, s);
       case 9: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64Pipe>(a, causal, s);
       case 10: return fwd64_launch_t<bf16_t, kF64Pipe>(a, causal, s);
+      case 11: return fwd64_launch_t<bf16_t, kF64Uniform>(a, causal, s);
+      case 12: return fwd64_launch_t<bf16_t, kF64Uniform | kF64Merge | kF64Late | kF64VPre>(a, causal, s);
       default: return TAMD_E_ARG;
     }
   }

@@ -166,6 +166,11 @@ __device__ __forceinline__ void agpr_scale(f32x16& acc, float alpha) {
 __device__ __forceinline__ void pin_here(unsigned& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pin_here(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin_here(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void pin_here(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+// (macro forms: an operand may be a vector element, which cannot bind to a reference)
+#define TAMD_PIN1(a_) asm volatile("" : "+v"(a_))
+#define TAMD_PIN2(a_, b_) asm volatile("" : "+v"(a_), "+v"(b_))
+#define TAMD_PIN3(a_, b_, c_) asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_))
 template <int N>
 __device__ __forceinline__ void nop_states() { asm volatile("s_nop %0" ::"n"(N - 1)); }  // N <= 16 wait states
 
