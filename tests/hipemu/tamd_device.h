@@ -208,6 +208,7 @@ inline void agpr_scale(f32x16& acc, float alpha) {
   for (int r = 0; r < 16; ++r) acc[r] *= alpha;
 }
 inline void pin_here(unsigned&, float&) {}
+inline float max3_f32(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 inline void pin_here(float&) {}
 inline void pin_here(float&, float&) {}
 inline void pin_here(float&, float&, float&) {}

@@ -27,8 +27,9 @@ for si, (name, b, s, hq, hkv, causal) in enumerate(SHAPES):
     scale = 1 / math.sqrt(d)
     fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
     # fwd64 variants of the diagnostic library (attention_fwd64.hip: attn_fwd64_launch); 5-7 are ablations (wrong results)
-    VARIANTS = {"v1": 1, "v2_merge": 2, "v3_merge_late": 3, "v4_merge_late_vpre": 4, "v8_v4_nofence": 8, "v9_v4_pipe": 9, "v10_pipe": 10, "v11_uniform": 11, "v12_v4_uniform": 12,
-                "abl_no_dma": 5, "abl_no_softmax": 6, "abl_no_dma_no_softmax": 7}
+    VARIANTS = {"v1": 1, "v4_merge_late_vpre": 4, "g2": 20,
+                "abl_no_dma": 5, "abl_no_softmax": 6, "abl_no_dma_no_softmax": 7,
+                "abl_g2_no_dma": 21, "abl_g2_no_softmax": 22, "abl_g2_no_dma_no_softmax": 23}
     arms = ["fwd32"] + [a for a in VARIANTS if full or not a.startswith("abl")]
 
     def select(key):

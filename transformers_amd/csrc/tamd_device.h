@@ -167,6 +167,12 @@ __device__ __forceinline__ void pin_here(unsigned& a, float& b) { asm volatile("
 __device__ __forceinline__ void pin_here(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin_here(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pin_here(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+// max(max(a, b), c) as the one instruction (fmaxf on values the compiler cannot prove canonical costs a v_max(x, x) each)
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 // (macro forms: an operand may be a vector element, which cannot bind to a reference)
 #define TAMD_PIN1(a_) asm volatile("" : "+v"(a_))
 #define TAMD_PIN2(a_, b_) asm volatile("" : "+v"(a_), "+v"(b_))
