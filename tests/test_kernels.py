@@ -405,6 +405,7 @@ def ref_attention(q, k, v, scale, causal, key_valid, keep=None, drop_p=0.0):
 ATTN_CASES_SMALL = [
     # b, sq, sk, hq, hkv, d, causal, mask
     (1, 128, 128, 2, 1, 128, True, False),
+    (1, 320, 320, 4, 2, 128, True, False),   # dK/dV: tiles without the mask test, then the diagonal ones, per wave
     (2, 200, 200, 4, 2, 64, False, True),
     (1, 130, 130, 2, 2, 128, False, False),
     (1, 577, 577, 1, 1, 64, False, False),   # CLIP-L/336: 577 tokens, no tile multiple

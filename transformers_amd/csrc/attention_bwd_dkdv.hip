@@ -52,7 +52,7 @@ __device__ __forceinline__ void wait_frags(u32x4& f0, u32x4& f1, u32x4& f2, u32x
 }
 
 // DBG (diagnostic instantiations, built only with -DTAMD_DIAG into libtamd_diag.so; TAMD_DKDV_DBG=n, wrong results): 1 no softmax arithmetic, 2 no LDS fragment reads,
-// 4 no MFMA, 8 no tile loads after the prologue, 16 no barrier
+// 4 no MFMA, 8 no tile loads after the prologue, 16 no barrier; 32 (correct results) every tile through the loop body WITH the mask test
 // order-only dependency: the registers are "produced" here, after every earlier volatile asm (the waits)
 __device__ __forceinline__ void after_wait(u32x4& x0, u32x4& x1) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -266,7 +266,14 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   if (niter > 0) load_rows(fa, 0u, (unsigned)TILEB, 0, 0);
   const int niter2 = (niter + 1) & ~1;  // even: an odd count gets one all-zero padding tile
   int cmp_h = 0, cmp_qt = nqt64 - 1;    // (head, q-tile) of the tile being computed
-  for (int it0 = 0; it0 < niter2; it0 += 2) {
+  // Two copies of the loop body.  PLAIN: the tile needs no mask for any key of this wave (every key of the wave valid,
+  // and, causal, the tile's first query row sees the wave's last key): no mask test -- 2 VALU per element, 64 of the
+  // ~420 instructions beside the 64 MFMAs of a tile, on a loop that is bound by instruction issue (4-5 instructions hide
+  // beside an MFMA: profiles/r03k_mfma_filler_probe.jsonl).  Tiles are walked from the last query tile down, so a
+  // wave's plain tiles come first: two straight-line loops, no branch inside a body (the count is wave-uniform; waves
+  // of one workgroup switch loops at different tiles, their barriers still pair up one per tile).
+  auto tile_pair = [&](auto plain_c, int it0) __attribute__((always_inline)) {
+   constexpr bool PLAIN = decltype(plain_c)::value != 0;
 #pragma unroll
    for (int cur = 0; cur < 2; ++cur) {
     const int it = it0 + cur;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         // element on every tile (mask_lim is -2^30 on tiles that need no mask)
         if (PACKED)
           x = (mask_lim <= ql + e && ql + e <= mask_hi) ? x : -INFINITY;
-        else
+        else if (!PLAIN)
           x = (mask_lim <= ql + e) ? x : -INFINITY;
         const float pe = fast_exp2(__builtin_fmaf(x, a.scale_log2, -u32_as_f32(l4[e])));
         float keep = 1.f;
@@ -448,7 +455,23 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       }
     }
    }
+  };
+  int it_plain = 0;  // (even) leading tiles of this wave that take the body without the mask test
+  if (!PACKED && !(DBG & 32) && ballot64(key_ok) == ~0ull) {
+    int n = niter2;
+    if (CAUSAL) {
+      const int need = kw0 + 31 - off;                       // first query row that sees the wave's last key
+      const int qmin = need > 0 ? (need + kQT - 1) / kQT : 0;  // first query tile all of whose rows see it
+      const int tiles = nqt64 > qmin ? nqt64 - qmin : 0;
+      n = tiles * group < niter2 ? tiles * group : niter2;
+    }
+    it_plain = n & ~1;
   }
+  int it0 = 0;
+  if (!(DROP && D > 64)) {  // (two bodies of the dropout variant at head_dim 128 do not fit the registers)
+    for (; it0 < it_plain; it0 += 2) tile_pair(IntC<1>{}, it0);
+  }
+  for (; it0 < niter2; it0 += 2) tile_pair(IntC<0>{}, it0);
   // the last hand-off left nothing in flight; every wave is past its LDS reads only after a barrier
   wait_vmcnt0();
   block_sync();
@@ -498,7 +521,7 @@ static int dkdv_launch(const AttnBwdArgs& g, bool causal, hipStream_t s) {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, false, false, N_>), grid, block, smem, s, g, nkvt);  \
     return launch_status();                                                                                   \
   }
-    TAMD_KVD(1) TAMD_KVD(2) TAMD_KVD(4) TAMD_KVD(8) TAMD_KVD(16) TAMD_KVD(3) TAMD_KVD(7) TAMD_KVD(6)
+    TAMD_KVD(1) TAMD_KVD(2) TAMD_KVD(4) TAMD_KVD(8) TAMD_KVD(16) TAMD_KVD(3) TAMD_KVD(7) TAMD_KVD(6) TAMD_KVD(32)
 #undef TAMD_KVD
 #endif
     TAMD_KV(true, false, false);

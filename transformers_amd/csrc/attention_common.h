@@ -9,6 +9,12 @@
 
 namespace tamd {
 
+// a compile-time integer as a function argument (generic lambdas: `decltype(c)::value`)
+template <int N>
+struct IntC {
+  static constexpr int value = N;
+};
+
 constexpr int kAttnThreads = 256;
 constexpr int kQB = 128;   // query rows per workgroup (32 per wave)
 constexpr int kKB = 64;    // keys per tile

@@ -539,11 +539,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
 // of phase Y -- no phase starts by waiting for LDS; the eight pieces of tile t+3 go out in phase Y behind the MFMAs that
 // have no softmax work.
 constexpr int kG2NoDma = 1, kG2NoSm = 2;  // ablations (wrong results)
-template <int N>
-struct IntC {
-  static constexpr int value = N;
-};
-
 template <typename T, bool CAUSAL, int VAR>
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a) {
   constexpr bool DMA = (VAR & kG2NoDma) == 0, SM = (VAR & kG2NoSm) == 0;
