@@ -27,7 +27,7 @@ for si, (name, b, s, hq, hkv, causal) in enumerate(SHAPES):
     scale = 1 / math.sqrt(d)
     fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
     # fwd64 variants of the diagnostic library (attention_fwd64.hip: attn_fwd64_launch); 5-7 are ablations (wrong results)
-    VARIANTS = {"v1": 1, "v4_merge_late_vpre": 4, "g2": 20,
+    VARIANTS = {"v1": 1, "v4_merge_late_vpre": 4, "g2": 20, "g2_split": 24,
                 "abl_no_dma": 5, "abl_no_softmax": 6, "abl_no_dma_no_softmax": 7,
                 "abl_g2_no_dma": 21, "abl_g2_no_softmax": 22, "abl_g2_no_dma_no_softmax": 23}
     arms = ["fwd32"] + [a for a in VARIANTS if full or not a.startswith("abl")]

@@ -539,9 +539,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
 // of phase Y -- no phase starts by waiting for LDS; the eight pieces of tile t+3 go out in phase Y behind the MFMAs that
 // have no softmax work.
 constexpr int kG2NoDma = 1, kG2NoSm = 2;  // ablations (wrong results)
+constexpr int kG2Split = 4;  // the V pieces of tile t+2 in phase X (odd gaps 1-7), the K pieces of tile t+3 in phase Y (odd gaps 25-31)
 template <typename T, bool CAUSAL, int VAR>
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a) {
-  constexpr bool DMA = (VAR & kG2NoDma) == 0, SM = (VAR & kG2NoSm) == 0;
+  constexpr bool DMA = (VAR & kG2NoDma) == 0, SM = (VAR & kG2NoSm) == 0, SPLIT = (VAR & kG2Split) != 0;
   constexpr int D = 128, ROWB = D * 2, TILEB = kKB * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
   constexpr int NBUF = 4, LA = 3;
   TAMD_DYN_SMEM(smem);
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a
     for (int tt = 0; tt < LA; ++tt) {
       const int tc = tt < nkt ? tt : nkt - 1;
 #pragma unroll
-      for (int n = 0; n < NP; ++n) issue_piece(tc, tt, n);
+      for (int n = 0; n < NP; ++n)
+        if (!(SPLIT && tt == LA - 1 && n >= NI)) issue_piece(tc, tt, n);  // (SPLIT: V of tile 2 goes out in phase X of tile 0)
     }
   }
   wait_vmcnt<0>();
@@ -696,6 +698,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a
   auto tile = [&](auto slc, int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) __attribute__((always_inline)) {
     constexpr int SL = decltype(slc)::value;
     const int tp = (t + LA < nkt) ? t + LA : nkt - 1;  // the tile loaded during this one (clamped: attn_fwd64_kernel)
+    const int tpv = (t + 2 < nkt) ? t + 2 : nkt - 1;   // SPLIT: the tile whose V pieces go out in phase X
     const int kt0 = t * kKB;
     if (SM && CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform)
 #pragma unroll
@@ -764,11 +767,17 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a
           else if (m == 21) sm_fin(1);
           else if (m < 26) sm_exp(1, m - 22);
         }
+        if (DMA && SPLIT && m <= 7 && (m & 1)) issue_piece(tpv, (SL + 2) & 3, NI + (m >> 1));
         sched_fence();
       }
     }
     // ---- between the phases: tile t+2 has landed (its pieces went out during tile t-1); every wave is done with slot SL-1
-    wait_vmcnt<0>();
+    // (SPLIT: K of tile t+2 has landed; its V pieces, issued in this phase X, may stay in flight: they are read after the
+    // next barrier between phases, which leaves only the then-newest four in flight)
+    if (SPLIT)
+      wait_vmcnt<NI>();
+    else
+      wait_vmcnt<0>();
     raw_barrier();
     // ---- phase Y: O += V(t)^T P(t); the rest of block B's exponentials behind MFMAs 0-11; the pieces of tile t+3 into
     // slot SL-1 behind the odd MFMAs 13 .. 27; the last four steps request the first K(t+2) fragments
@@ -786,7 +795,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a
         else
           mfma32_o<T>(oacc[blk][i % DT], vr[i % (AH + 1)], pf[blk][i / DT]);
         if (SM && m < 12) sm_exp(1, m + 4);
-        if (DMA && m >= 13 && m <= 27 && (m & 1)) issue_piece(tp, (SL + 3) & 3, (m - 13) >> 1);
+        if (DMA && !SPLIT && m >= 13 && m <= 27 && (m & 1)) issue_piece(tp, (SL + 3) & 3, (m - 13) >> 1);
+        if (DMA && SPLIT && m >= 25 && (m & 1)) issue_piece(tp, (SL + 3) & 3, (m - 25) >> 1);
         sched_fence();
       }
     }
@@ -813,14 +823,22 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a
     if (t + 2 <= tw) tile(IntC<2>{}, t + 2, s0, s1);
     if (t + 3 <= tw) tile(IntC<3>{}, t + 3, s1, s0);
   }
-  // past its last tile the wave only loads (the sequence of a computing wave: wait for its pieces, barrier, next pieces)
+  // past its last tile the wave only loads, in the sequence of a computing wave: (SPLIT: the V pieces of tile t+2,) wait
+  // for its pieces of tile t+2, barrier, the pieces of tile t+3 (SPLIT: their K half)
   for (int t = tw + 1; t < nkt; ++t) {
     const int tp = (t + LA < nkt) ? t + LA : nkt - 1;
-    wait_vmcnt<0>();
+    if (DMA && SPLIT) {
+      const int tpv = (t + 2 < nkt) ? t + 2 : nkt - 1;
+#pragma unroll
+      for (int n = NI; n < NP; ++n) issue_piece(tpv, (t + 2) & 3, n);
+      wait_vmcnt<NI>();
+    } else {
+      wait_vmcnt<0>();
+    }
     raw_barrier();
     if (DMA) {
 #pragma unroll
-      for (int n = 0; n < NP; ++n) issue_piece(tp, (t + LA) & 3, n);
+      for (int n = 0; n < (SPLIT ? NI : NP); ++n) issue_piece(tp, (t + LA) & 3, n);
     }
   }
   wait_vmcnt<0>();  // (nothing may land in the ring once it holds the O tiles; the K fragments requested last are dropped)
@@ -912,6 +930,7 @@ int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hi
       case 21: return fwd64b_launch_t<bf16_t, kG2NoDma>(a, causal, s);
       case 22: return fwd64b_launch_t<bf16_t, kG2NoSm>(a, causal, s);
       case 23: return fwd64b_launch_t<bf16_t, kG2NoDma | kG2NoSm>(a, causal, s);
+      case 24: return fwd64b_launch_t<bf16_t, kG2Split>(a, causal, s);
       default: return TAMD_E_ARG;
     }
   }
