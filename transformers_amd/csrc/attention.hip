@@ -38,11 +38,11 @@ namespace {
 
 #ifdef TAMD_DIAG
 unsigned long long* g_attn_trace = nullptr;
-#endif
-// The forward with 64 query rows per wave (attention_fwd64.hip) where it applies: 0 = never.  The diagnostic library
-// flips it per call (tamd_attn_set_fwd64, A/B runs and the bit-identity test).
+// The forward kernels with 64 query rows per wave (attention_fwd64.hip, diagnostic library only: measured level with
+// attn_fwd_kernel at the Llama-3-8B shape, profiles/r03f..m_attn_fwd64_ab.jsonl): 0 = off, n = variant n where it applies
 int g_attn_fwd64 = 0;
 int g_attn_fwd64_launches = 0;
+#endif
 
 template <typename T, int D>
 int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
@@ -154,10 +154,12 @@ extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t str
   if (chk != TAMD_OK) return chk;
   const AttnArgs a = make_args(p);
   hipStream_t s = TAMD_STREAM(stream);
+#ifdef TAMD_DIAG
   if (g_attn_fwd64 && attn_fwd64_applies(a, (int)p->head_dim)) {
     ++g_attn_fwd64_launches;
     return attn_fwd64_launch(a, p->causal != 0, (int)p->dtype, g_attn_fwd64, s);
   }
+#endif
   if (p->head_dim == 128) {
     TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 128>(a, p->causal != 0, s)));
   } else {

@@ -1,9 +1,11 @@
-// attention_fwd64.hip -- forward attention with 64 query rows per wave (one wave per SIMD, the whole register file):
-// the same arithmetic per query row, in the same order, as attn_fwd_kernel (attention_fwd_kernel.inc) -- outputs and LSE
-// are bit-identical -- restructured so that the matrix pipe and the VALU of a SIMD are driven by ONE instruction stream
-// that interleaves them, instead of by two waves that take turns (MI355X_MICROARCH.md, "one wave per SIMD": at most five
-// single-issue instructions hide in the gap of a 32x32x16 MFMA, and they have to be PLACED there -- a wave issues in
-// order, so a run of 16 MFMAs followed by 150 VALU instructions overlaps nothing).
+// attention_fwd64.hip -- forward attention with 64 query rows per wave (one wave per SIMD, the whole register file).
+// DIAGNOSTIC LIBRARY ONLY (build.py DIAG_SOURCES; selected with tamd_attn_set_fwd64, include/tamd_diag.h): measured level
+// with the product kernel at the product shape, so not promoted -- see "Measured" below.
+//
+// The same arithmetic per query row, in the same order, as attn_fwd_kernel (attention_fwd_kernel.inc): outputs and LSE
+// are bit-identical (tests/test_kernels.py::test_attention_fwd64_matches_fwd on the CPU model; tools/attn_fwd64_ab.py on
+// the silicon).  Restructured so that the matrix pipe and the VALU of a SIMD are driven by ONE instruction stream that
+// interleaves them instead of by two waves that take turns.
 //
 // A workgroup = 4 waves = 256 query rows of one (batch, head); a wave carries two 32-row query blocks A and B.  Per
 // 64-key tile t, two phases of 32 MFMAs:
@@ -11,10 +13,34 @@
 //        interleaved with the online softmax of S(t): block A complete, block B up to its first 16 keys;
 //     Y  O += V(t)^T . P(t)     for both blocks -- every V fragment read once and used twice -- interleaved with the rest
 //        of block B's exponentials (their P fragments are consumed from the 9th MFMA of the phase on);
-// the LDS-DMA pieces of tile t+3 go out four per phase; one barrier per tile; K/V tiles in a 4-deep LDS ring (128 KiB).
-// S is double-buffered in registers (the loop is unrolled by two so that both copies are statically addressed).
+// S is double-buffered in registers (the loop is unrolled so that both copies are statically addressed); K/V tiles in a
+// 4-deep LDS ring (128 KiB), loaded three tiles ahead.  Register files are assigned by hand (tamd_device.h mfma32_s /
+// mfma32_o: inline-asm MFMAs): S in VGPRs (the softmax reads it), O, Q and the K fragments in AGPRs -- with the builtin
+// the compiler puts every accumulator of a >256-register kernel into AGPRs and spills (347 registers in the first try).
+// Every softmax value is pinned behind "its" MFMA (an empty volatile asm on its result): without that the compiler
+// sinks the arithmetic to where P is consumed.
 // Scope: head_dim 128, no padding mask, no dropout, no packed sequences, seq_k % 64 == 0, K and V rows the same distance
 // apart -- tamd_attn_fwd takes attn_fwd_kernel otherwise.
+//
+// Two kernels: attn_fwd64_kernel (first; variants 1-8) and attn_fwd64b_kernel (second generation, below; variants 20-24).
+//
+// Measured (MI355X, bf16, random data, five boxes; profiles/r03f .. r03m_attn_fwd64_ab.jsonl; TFLOP/s):
+//                                   attn_fwd_kernel   fwd64 (best variant)
+//     Llama-3-8B causal   8x4096        961 .. 1039       976 .. 1042      (+0 .. +3 %)
+//     bidirectional       8x4096       1046 .. 1106      1092 .. 1175      (+4 .. +7 %)
+//     causal 2x8192                    1030 .. 1083      1064 .. 1134      (+3 .. +5 %)
+//     causal 16x2048, MHA 4x4096, 1088-token prompt:      -3 .. -17 %  (256-row workgroups: diagonal waste, fewer workgroups)
+//   Ablations (wrong results, timing only): without the softmax arithmetic 1550-1730, without the tile loads +5-15 %,
+//   without both 1600-1990 (80 % of the 2.5 PFLOP/s figure): the MFMA + LDS-read stream is fine, the loop is bound by
+//   instruction ISSUE.  tools/probes/mfma_filler_probe.hip (profiles/r03k_mfma_filler_probe.jsonl): with one wave per SIMD
+//   FOUR VALU instructions hide beside a 32x32x16 MFMA (five with the accumulator in AGPRs), every further one costs ~5
+//   cycles; this loop has ~7.2 beside each MFMA (276 softmax VALU, 48 LDS reads, 17-35 waits, 8 LDS-DMA pieces + their M0
+//   writes, ~40 SALU, ~20 pad nops per 64 MFMAs), for which the probe predicts ~1250 TFLOP/s before barriers.  WHERE the
+//   softmax instructions sit does not matter once every gap is over budget: dense slices, a 3-stage pipeline of the
+//   exponentials (no instruction reads a result of its own gap) and one value per gap over both phases measured within
+//   3 % of each other (the last two: profiles/r03i_attn_fwd64_pipe_uniform.patch).  What is left is instruction COUNT:
+//   the minimum for this arithmetic is ~256 VALU + 48 LDS reads per 64 MFMAs = 4.75 per gap -- MI355X_MICROARCH.md quotes
+//   1.25-1.40 PFLOP/s for exactly that stream.  DESIGN.md section 7.
 #include "attention_common.h"
 
 namespace tamd {
@@ -28,8 +54,6 @@ constexpr int kF64VPre = 4;     // the first V fragments of phase Y requested be
 constexpr int kF64NoDma = 8;    // ABLATION (wrong results): no tile loads in the loop
 constexpr int kF64NoSm = 16;    // ABLATION (wrong results): no softmax arithmetic
 constexpr int kF64NoFence = 32; // no scheduling fences between the MFMA groups
-constexpr int kF64Uniform = 128; // one value of the softmax per MFMA gap over BOTH phases, the row maximum of S(t+1) under P.V of tile t
-constexpr int kF64Pipe = 64;    // the exponentials as a 3-stage pipeline over the gaps: no instruction of a gap reads a result of that gap
 
 // MFMA kind K (0: S = a.b, 1: S += a.b, 2: O += a.b) behind `s_waitcnt lgkmcnt(min(n, CAP))`, n foldable
 template <typename T, int CAP, int K>
@@ -50,7 +74,6 @@ template <typename T, bool CAUSAL, int VAR>
 __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a) {
   constexpr bool MERGE = (VAR & kF64Merge) != 0, LATE = (VAR & kF64Late) != 0, VPRE = (VAR & kF64VPre) != 0;
   constexpr bool DMA = (VAR & kF64NoDma) == 0, SM = (VAR & kF64NoSm) == 0, FENCE = (VAR & kF64NoFence) == 0;
-  constexpr bool PIPE = (VAR & kF64Pipe) != 0, UNI = (VAR & kF64Uniform) != 0;
   constexpr int D = 128, ROWB = D * 2, TILEB = kKB * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
   constexpr int NBUF = 4, LA = NBUF - 1;  // ring depth; tiles requested ahead
   TAMD_DYN_SMEM(smem);
@@ -201,7 +224,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     return (m & 7) == 5 ? m >> 3 : -1;
   };
 
-  float mxc[2] = {0.f, 0.f};  // UNI: the raw maximum of S(t) per block (this lane's keys), computed under P.V of tile t-1
   // one key tile of a wave that still computes: sc = S(t) (ready), sn = S(t+1) (computed here).  The pieces of tile
   // t + LA go out unconditionally: past the workgroup's last tile the index is clamped (the last tile is fetched again
   // into a free ring slot -- no branches and one vmcnt count in the loop, for three redundant tile loads per workgroup)
@@ -211,7 +233,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
     const int kt0 = t * kKB;
     const unsigned kbn = lds0 + (unsigned)((t + 1) % NBUF) * 2u * TILEB;       // K(t+1)
     const unsigned vb = lds0 + (unsigned)(t % NBUF) * 2u * TILEB + TILEB;      // V(t)
-    if (SM && !UNI && CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform): key kp visible to row q iff kp <= q + off
+    if (SM && CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform): key kp visible to row q iff kp <= q + off
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         const int lim = qw0 + blk * 32 + l31 + off - kt0 - 4 * hi;  // key index inside the tile, less the lane's 4 * hi
@@ -223,21 +245,11 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
       }
     }
     // ---- the online softmax of sc in slices (the arithmetic of attn_fwd_kernel in its order)
-    float mx[2] = {mxc[0], mxc[1]}, mref[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
+    float mx[2] = {0.f, 0.f}, mref[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
     auto sm_max = [&](int blk, int sub) __attribute__((always_inline)) {
       float m = sub == 0 ? sc[blk][0][0] : mx[blk];
-      if (PIPE) {  // two chains (max is exact in any order)
-        float m2 = sc[blk][sub][8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          m = fmaxf(m, sc[blk][sub][r]);
-          m2 = fmaxf(m2, sc[blk][sub][8 + r]);
-        }
-        m = fmaxf(m, m2);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[blk][sub][r]);
-      }
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[blk][sub][r]);
       pin_here(m);
       mx[blk] = m;
     };
@@ -265,80 +277,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
       pf[blk][sub * 2 + (r >> 3)][(r & 7) >> 1] = w;
       if (q == 15) l_run[blk] += psum[blk];
     };
-    // The same exponentials as a pipeline: step st of a block does stage 1 (the two fused multiply-adds) of value pair st,
-    // stage 2 (the two exp2) of pair st - 1 and stage 3 (row sum, rounding to the storage type) of pair st - 2, so that
-    // every input of a gap was produced in an earlier gap -- the wave issues in order, and fma -> exp2 -> add -> cvt
-    // of ONE pair inside a gap is a chain of result latencies that no MFMA hides.  Steps 0 .. 17 per block; the row sum
-    // still adds the values in their order.
-    float xs[2][32], es[2][32];
-    auto sm_step = [&](int blk, int st) __attribute__((always_inline)) {
-      if (st >= 2) psum[blk] += es[blk][2 * (st - 2)];
-      if (st < 16) {
-        const int sub = st >> 3, r = 2 * (st & 7);
-        xs[blk][2 * st] = __builtin_fmaf(sc[blk][sub][r], a.scale_log2, -mref[blk]);
-        xs[blk][2 * st + 1] = __builtin_fmaf(sc[blk][sub][r + 1], a.scale_log2, -mref[blk]);
-        pin_here(xs[blk][2 * st], xs[blk][2 * st + 1]);
-      }
-      if (st >= 1 && st <= 16) {
-        const int q = st - 1;
-        es[blk][2 * q] = fast_exp2(xs[blk][2 * q]);
-        es[blk][2 * q + 1] = fast_exp2(xs[blk][2 * q + 1]);
-        pin_here(es[blk][2 * q], es[blk][2 * q + 1]);
-      }
-      if (st >= 2) {
-        const int q = st - 2, sub = q >> 3, r = 2 * (q & 7);
-        psum[blk] += es[blk][2 * q + 1];
-        unsigned w = pack2<T>(es[blk][2 * q], es[blk][2 * q + 1]);
-        pin_here(w, psum[blk]);
-        pf[blk][sub * 2 + (r >> 3)][(r & 7) >> 1] = w;
-        if (q == 15) l_run[blk] += psum[blk];
-      }
-    };
-    // UNI: the exponentials as ONE stream of 64 values (block A's 32, then block B's) in three pipeline stages, step k =
-    // stage 1 of value k, stage 2 of value k - 1, stage 3 of value k - 2 (k = 0 .. 65): 42 steps in phase X (P of block A
-    // and the first fragment of B complete), one per gap in phase Y (value 47 -- B's fragment 1 -- at gap 7, read by MFMA
-    // 9; fragment 2 at 15 / 17, fragment 3 at 23 / 25).  At most ~5 instructions beside every MFMA in both phases.
-    float xv[64], ev[64];
-    auto vstep = [&](int k) __attribute__((always_inline)) {
-      // (the inputs of the step pass through an empty volatile statement: it stays BEHIND the gap's MFMA statement, so
-      // the arithmetic cannot be hoisted in front of that MFMA -- which would put two gaps' work into one)
-      if (k >= 2 && k < 64) TAMD_PIN3(ev[k - 2], xv[k - 1], sc[(k & 63) >> 5][(k & 31) >> 4][k & 15]);
-      else if (k == 1) TAMD_PIN2(xv[k - 1], sc[0][0][1]);
-      else if (k == 0) TAMD_PIN1(sc[0][0][0]);
-      else if (k == 64) TAMD_PIN2(ev[k - 2], xv[k - 1]);
-      else TAMD_PIN1(ev[k - 2]);
-      if (k >= 2) {
-        const int v = k - 2, blk = v >> 5, idx = v & 31, sub = idx >> 4, r = idx & 15;
-        psum[blk] += ev[v];
-        if (r & 1) {
-          unsigned w = pack2<T>(ev[v - 1], ev[v]);
-          pin_here(w, psum[blk]);
-          pf[blk][sub * 2 + (r >> 3)][(r & 7) >> 1] = w;
-        } else {
-          pin_here(psum[blk]);
-        }
-        if (idx == 31) l_run[blk] += psum[blk];
-      }
-      if (k < 64) {
-        const int blk = k >> 5, idx = k & 31, sub = idx >> 4, r = idx & 15;
-        xv[k] = __builtin_fmaf(sc[blk][sub][r], a.scale_log2, -mref[blk]);
-        pin_here(xv[k]);
-      }
-      if (k >= 1 && k <= 64) {
-        ev[k - 1] = fast_exp2(xv[k - 1]);
-        pin_here(ev[k - 1]);
-      }
-    };
-    // UNI: the raw maximum of sn = S(t+1), two values behind each MFMA of phase Y (block g >> 4, sub-tile (g >> 3) & 1)
-    float mxn[2] = {0.f, 0.f};
-    auto next_max = [&](int g) __attribute__((always_inline)) {
-      const int blk = g >> 4, sub = (g >> 3) & 1, r = 2 * (g & 7);
-      TAMD_PIN2(sn[blk][sub][r], sn[blk][sub][r + 1]);  // (behind the gap's MFMA, as in vstep)
-      const float m0 = (g & 15) == 0 ? sn[blk][sub][r] : mxn[blk];
-      float m = fmaxf(fmaxf(m0, sn[blk][sub][r]), sn[blk][sub][r + 1]);
-      pin_here(m);
-      mxn[blk] = m;
-    };
     // ---- phase X: 32 MFMAs of S(t+1); behind MFMA m: block A: max 0-1, finish 2, exponentials 3-18; block B: max
     // 19-20, finish 21, the exponentials of its first 8 values (P fragment 0) 22-25; four pieces (piece_of_gap)
     u32x4 vr[VA + 1];
@@ -357,29 +295,13 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
         for (int blk = 0; blk < 2; ++blk) {
           const int m = 2 * i + blk;
           qk_step(sn, kr[i % (KA + 1)], i, blk, (MERGE && blk == 0) ? after : -1);
-          if (SM && !PIPE && !UNI) {
+          if (SM) {
             if (m < 2) sm_max(0, m);
             else if (m == 2) sm_fin(0);
             else if (m < 19) sm_exp(0, m - 3);
             else if (m < 21) sm_max(1, m - 19);
             else if (m == 21) sm_fin(1);
             else if (m < 26) sm_exp(1, m - 22);
-          }
-          if (SM && UNI) {  // finish of both blocks (their maxima are there), then 42 steps of the value stream over 30 gaps
-            if (m < 2) sm_fin(m);
-            else {
-              const int k0 = ((m - 2) * 42) / 30, k1 = ((m - 1) * 42) / 30;  // (one or two steps)
-              vstep(k0);
-              if (k1 - k0 > 1) vstep(k0 + 1);
-            }
-          }
-          if (SM && PIPE && !UNI) {  // block A: max 0-1, finish 2, steps 0-17 behind 3-20; block B: max 21-22, finish 23, steps 0-7
-            if (m < 2) sm_max(0, m);
-            else if (m == 2) sm_fin(0);
-            else if (m < 21) sm_step(0, m - 3);
-            else if (m < 23) sm_max(1, m - 21);
-            else if (m == 23) sm_fin(1);
-            else sm_step(1, m - 24);
           }
           if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, piece_of_gap(m));
           if (FENCE) sched_fence();
@@ -393,19 +315,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
 #pragma unroll
         for (int i = 0; i < VA; ++i) vr[i] = vreq(vb, i);
       }
-      if (SM && UNI && CAUSAL && (kt0 + 2 * kKB - 1 > qw0 + off)) {  // tile t+1 is a diagonal tile of this wave: mask S(t+1)
-        nop_states<16>();                                              // (its last MFMAs were issued a moment ago)
-        nop_states<16>();
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const int lim = qw0 + blk * 32 + l31 + off - (kt0 + kKB) - 4 * hi;
-#pragma unroll
-          for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              sn[blk][sub][r] = (sub * 32 + (r & 3) + 8 * (r >> 2) <= lim) ? sn[blk][sub][r] : -INFINITY;
-        }
-      }
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         if (i + VA < NV) vr[(i + VA) % (VA + 1)] = vreq(vb, i + VA);
@@ -418,20 +327,11 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
             mfma_after_wait<T, 8, 2>(after, oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
           else
             mfma32_o<T>(oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
-          if (SM && UNI) {
-            if (m < 24) vstep(42 + m);
-            next_max(m);
-          }
-          if (SM && !PIPE && !UNI && m < 12) sm_exp(1, m + 4);
-          if (SM && PIPE && !UNI && m < 10) sm_step(1, m + 8);  // (P fragment 1 of B is complete before Y starts, 2 at gap 5, 3 at 9)
+          if (SM && m < 12) sm_exp(1, m + 4);
           if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, NI + piece_of_gap(m));
           if (FENCE) sched_fence();
         }
       }
-    }
-    if (UNI) {
-      mxc[0] = mxn[0];
-      mxc[1] = mxn[1];
     }
     // hand-off: tile t+2 has landed (the pieces just issued may stay in flight); every wave is done with V(t) and K(t+1)
     wait_vmcnt<NP>();
@@ -452,29 +352,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
       qk_step(s0, kr[i % (KA + 1)], i, 1, -1);
     }
     nop_states<16>();  // (S(0) is read by the VALU a few instructions into tile 0)
-    if (UNI && SM) {
-      nop_states<16>();
-      if (CAUSAL && (kKB - 1 > qw0 + off)) {
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const int lim = qw0 + blk * 32 + l31 + off - 4 * hi;
-#pragma unroll
-          for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              s0[blk][sub][r] = (sub * 32 + (r & 3) + 8 * (r >> 2) <= lim) ? s0[blk][sub][r] : -INFINITY;
-        }
-      }
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        float m = s0[blk][0][0];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, s0[blk][sub][r]);
-        mxc[blk] = m;
-      }
-    }
   }
   for (int t = 0; t <= tw; t += 2) {
     tile(t, s0, s1);
@@ -912,7 +789,6 @@ constexpr int kF64Default = 0;  // the product schedule
 
 // `variant`: 1 = the product schedule; the diagnostic library has more (tamd_attn_set_fwd64, bf16 only)
 int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hipStream_t s) {
-#ifdef TAMD_DIAG
   if (variant > 1 && dtype == TAMD_BF16) {
     switch (variant) {
       case 2: return fwd64_launch_t<bf16_t, kF64Merge>(a, causal, s);
@@ -922,10 +798,6 @@ int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hi
       case 6: return fwd64_launch_t<bf16_t, kF64NoSm>(a, causal, s);
       case 7: return fwd64_launch_t<bf16_t, kF64NoDma | kF64NoSm>(a, causal, s);
       case 8: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64NoFence>(a, causal, s);
-      case 9: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64Pipe>(a, causal, s);
-      case 10: return fwd64_launch_t<bf16_t, kF64Pipe>(a, causal, s);
-      case 11: return fwd64_launch_t<bf16_t, kF64Uniform>(a, causal, s);
-      case 12: return fwd64_launch_t<bf16_t, kF64Uniform | kF64Merge | kF64Late | kF64VPre>(a, causal, s);
       case 20: return fwd64b_launch_t<bf16_t, 0>(a, causal, s);
       case 21: return fwd64b_launch_t<bf16_t, kG2NoDma>(a, causal, s);
       case 22: return fwd64b_launch_t<bf16_t, kG2NoSm>(a, causal, s);
@@ -934,8 +806,6 @@ int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hi
       default: return TAMD_E_ARG;
     }
   }
-#endif
-  (void)variant;
   TAMD_DISPATCH_HALF(dtype, return (fwd64_launch_t<T, kF64Default>(a, causal, s)));
   return TAMD_E_DTYPE;
 }
