@@ -22,17 +22,34 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _build_model():
+def _build_model(kind="llama"):
     from transformers import LlamaConfig, LlamaForCausalLM
 
     torch.manual_seed(0)
+    if kind == "bert":  # the fused BertLayer op, the padded-vocabulary MLM head and loss (dropout off: the check below
+        from transformers import BertConfig, BertForMaskedLM  # recomputes the per-rank gradients in this process)
+
+        cfg = BertConfig(vocab_size=250, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                         max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                         attn_implementation="eager")
+        return BertForMaskedLM(cfg).bfloat16().train(), cfg
     cfg = LlamaConfig(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
                       num_attention_heads=2, num_key_value_heads=1, head_dim=64, max_position_embeddings=128,
                       rms_norm_eps=1e-5, attn_implementation="eager")
     return LlamaForCausalLM(cfg).bfloat16().train(), cfg
 
 
-def _worker(rank, world, port, out_dir):
+def _batch(cfg, rank, kind):
+    g = torch.Generator().manual_seed(100 + rank)
+    ids = torch.randint(0, cfg.vocab_size, (2, 48), generator=g)
+    if kind != "bert":
+        return dict(input_ids=ids, labels=ids, use_cache=False)
+    labels = ids.clone()
+    labels[torch.rand(ids.shape, generator=g) > 0.3] = -100  # MLM: most positions carry no label
+    return dict(input_ids=ids, labels=labels)
+
+
+def _worker(rank, world, port, out_dir, kind="llama"):
     for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
         sys.path.insert(0, str(p))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
@@ -43,13 +60,11 @@ def _worker(rank, world, port, out_dir):
     from torch.nn.parallel import DistributedDataParallel as DDP
 
     with emu_backend():
-        model, cfg = _build_model()
+        model, cfg = _build_model(kind)
         transformers_amd.accelerate(model)
         ddp = DDP(model, bucket_cap_mb=1, gradient_as_bucket_view=True, broadcast_buffers=False,
                   find_unused_parameters=False, static_graph=True)
-        g = torch.Generator().manual_seed(100 + rank)
-        ids = torch.randint(0, cfg.vocab_size, (2, 48), generator=g)
-        out = ddp(input_ids=ids, labels=ids, use_cache=False)
+        out = ddp(**_batch(cfg, rank, kind))
         out.loss.backward()
         grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
         assert all(p.grad is not None for p in model.parameters())
@@ -63,9 +78,10 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_ddp_world2_gloo(tmp_path):
+@pytest.mark.parametrize("kind", ["llama", "bert"])
+def test_ddp_world2_gloo(tmp_path, kind):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), kind), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
     # (3) replicas identical
     for n in r[0]["weights"]:
@@ -80,11 +96,9 @@ def test_ddp_world2_gloo(tmp_path):
     per_rank = []
     with emu_backend():
         for rank in range(world):
-            model, cfg = _build_model()
+            model, cfg = _build_model(kind)
             transformers_amd.accelerate(model)
-            g = torch.Generator().manual_seed(100 + rank)
-            ids = torch.randint(0, cfg.vocab_size, (2, 48), generator=g)
-            model(input_ids=ids, labels=ids, use_cache=False).loss.backward()
+            model(**_batch(cfg, rank, kind)).loss.backward()
             per_rank.append({n: p.grad.detach().float() for n, p in model.named_parameters()})
     for n, gd in r[0]["grads"].items():
         want = (per_rank[0][n] + per_rank[1][n]) / 2
