@@ -208,13 +208,8 @@ inline void agpr_scale(f32x16& acc, float alpha) {
   for (int r = 0; r < 16; ++r) acc[r] *= alpha;
 }
 inline void pin_here(unsigned&, float&) {}
-inline float max3_f32(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 inline void pin_here(float&) {}
 inline void pin_here(float&, float&) {}
-inline void pin_here(float&, float&, float&) {}
-#define TAMD_PIN1(a_) ((void)0)
-#define TAMD_PIN2(a_, b_) ((void)0)
-#define TAMD_PIN3(a_, b_, c_) ((void)0)
 template <int N>
 inline void nop_states() {}
 template <typename T>
@@ -438,10 +433,6 @@ inline void setprio_hi() {}
 inline void setprio_lo() {}
 inline unsigned long long device_clock() { return 0ull; }
 inline unsigned long long device_realtime() { return 0ull; }
-// cross-workgroup arrival counters: blocks run on OS threads, so real atomics and a real yield
-inline unsigned atomic_add_agent(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
-inline unsigned atomic_load_agent(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
-inline void short_sleep() { std::this_thread::yield(); }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_log2(float x) { return log2f(x); }

@@ -166,17 +166,6 @@ __device__ __forceinline__ void agpr_scale(f32x16& acc, float alpha) {
 __device__ __forceinline__ void pin_here(unsigned& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void pin_here(float& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin_here(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void pin_here(float& a, float& b, float& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
-// max(max(a, b), c) as the one instruction (fmaxf on values the compiler cannot prove canonical costs a v_max(x, x) each)
-__device__ __forceinline__ float max3_f32(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-// (macro forms: an operand may be a vector element, which cannot bind to a reference)
-#define TAMD_PIN1(a_) asm volatile("" : "+v"(a_))
-#define TAMD_PIN2(a_, b_) asm volatile("" : "+v"(a_), "+v"(b_))
-#define TAMD_PIN3(a_, b_, c_) asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_))
 template <int N>
 __device__ __forceinline__ void nop_states() { asm volatile("s_nop %0" ::"n"(N - 1)); }  // N <= 16 wait states
 
@@ -327,14 +316,6 @@ __device__ __forceinline__ unsigned long long device_clock() { return __builtin_
 // constant-rate (100 MHz) counter: shader-clock ticks / real-time ticks = the clock a kernel actually ran at
 __device__ __forceinline__ unsigned long long device_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 
-// cross-workgroup arrival counters (gemm.hip, persistent walk): agent-scope atomics on global memory and a short nap
-__device__ __forceinline__ unsigned atomic_add_agent(unsigned* p, unsigned v) {
-  return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned atomic_load_agent(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void short_sleep() { __builtin_amdgcn_s_sleep(8); }
 
 // fast transcendental pieces
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
