@@ -604,8 +604,7 @@ def test_attention_fwd64_matches_fwd(env):
         v = torch.randn(b, sk, hkv, d).to(dtype).to(dev)
         if ci == 0:
             k[0, sk - 20, 0] = q[0, 5, 0] * 8  # a huge score late in the row: the rescale path
-        # 1: the product schedule; 4: schedule variant of the first kernel, 20: the second-generation kernel of the diagnostic library's schedule variants (bf16), same arithmetic
-        variants = (1, 4, 20, 24) if ci == 0 else ((1, 20, 24) if dtype == torch.bfloat16 else (1,))
+        variants = (1, 2) if dtype == torch.bfloat16 else (1,)
         for causal in (True, False):
             o_ref, lse_ref = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal)
             for variant in variants:

@@ -26,10 +26,9 @@ for si, (name, b, s, hq, hkv, causal) in enumerate(SHAPES):
     v = torch.randn(b, s, hkv, d, device=dev).bfloat16()
     scale = 1 / math.sqrt(d)
     fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
-    # fwd64 variants of the diagnostic library (attention_fwd64.hip: attn_fwd64_launch); 5-7 are ablations (wrong results)
-    VARIANTS = {"v1": 1, "v4_merge_late_vpre": 4, "g2": 20, "g2_split": 24,
-                "abl_no_dma": 5, "abl_no_softmax": 6, "abl_no_dma_no_softmax": 7,
-                "abl_g2_no_dma": 21, "abl_g2_no_softmax": 22, "abl_g2_no_dma_no_softmax": 23}
+    # variants of attn_fwd64_launch (attention_fwd64.hip); 5-7 are ablations (wrong results).  The records r03f..m were
+    # taken with the first kernel and its schedule variants still in the library (arms v1..v12, g2 = today's fwd64)
+    VARIANTS = {"fwd64": 1, "fwd64_split": 2, "abl_no_dma": 5, "abl_no_softmax": 6, "abl_no_dma_no_softmax": 7}
     arms = ["fwd32"] + [a for a in VARIANTS if full or not a.startswith("abl")]
 
     def select(key):

@@ -13,16 +13,14 @@
 //        interleaved with the online softmax of S(t): block A complete, block B up to its first 16 keys;
 //     Y  O += V(t)^T . P(t)     for both blocks -- every V fragment read once and used twice -- interleaved with the rest
 //        of block B's exponentials (their P fragments are consumed from the 9th MFMA of the phase on);
-// S is double-buffered in registers (the loop is unrolled so that both copies are statically addressed); K/V tiles in a
-// 4-deep LDS ring (128 KiB), loaded three tiles ahead.  Register files are assigned by hand (tamd_device.h mfma32_s /
-// mfma32_o: inline-asm MFMAs): S in VGPRs (the softmax reads it), O, Q and the K fragments in AGPRs -- with the builtin
+// S is double-buffered in registers, K/V tiles sit in a 4-deep LDS ring (128 KiB) loaded three tiles ahead, and the loop is
+// unrolled by four so that both S copies and the ring slot are statically addressed.  Register files are assigned by hand
+// (tamd_device.h mfma32_s / mfma32_o: inline-asm MFMAs): S in VGPRs (the softmax reads it), O, Q and the K fragments in AGPRs -- with the builtin
 // the compiler puts every accumulator of a >256-register kernel into AGPRs and spills (347 registers in the first try).
 // Every softmax value is pinned behind "its" MFMA (an empty volatile asm on its result): without that the compiler
 // sinks the arithmetic to where P is consumed.
 // Scope: head_dim 128, no padding mask, no dropout, no packed sequences, seq_k % 64 == 0, K and V rows the same distance
 // apart -- tamd_attn_fwd takes attn_fwd_kernel otherwise.
-//
-// Two kernels: attn_fwd64_kernel (first; variants 1-8) and attn_fwd64b_kernel (second generation, below; variants 20-24).
 //
 // Measured (MI355X, bf16, random data, five boxes; profiles/r03f .. r03m_attn_fwd64_ab.jsonl; TFLOP/s):
 //                                   attn_fwd_kernel   fwd64 (best variant)
@@ -38,7 +36,7 @@
 //   writes, ~40 SALU, ~20 pad nops per 64 MFMAs), for which the probe predicts ~1250 TFLOP/s before barriers.  WHERE the
 //   softmax instructions sit does not matter once every gap is over budget: dense slices, a 3-stage pipeline of the
 //   exponentials (no instruction reads a result of its own gap) and one value per gap over both phases measured within
-//   3 % of each other (the last two: profiles/r03i_attn_fwd64_pipe_uniform.patch).  What is left is instruction COUNT:
+//   3 % of each other (patches: profiles/r03i_attn_fwd64_pipe_uniform.patch, r03j_attn_fwd64_gen1.patch).  What is left is instruction COUNT:
 //   the minimum for this arithmetic is ~256 VALU + 48 LDS reads per 64 MFMAs = 4.75 per gap -- MI355X_MICROARCH.md quotes
 //   1.25-1.40 PFLOP/s for exactly that stream.  DESIGN.md section 7.
 #include "attention_common.h"
@@ -46,14 +44,6 @@
 namespace tamd {
 
 constexpr int kQB64 = 256;  // query rows per workgroup (64 per wave)
-
-// schedule variants (VAR bits; the diagnostic library instantiates several for A/B runs and ablations)
-constexpr int kF64Merge = 1;    // the lgkmcnt wait of a fragment inside the statement of the MFMA that consumes it
-constexpr int kF64Late = 2;     // LDS-DMA pieces behind MFMAs 25, 27, 29, 31 of a phase (no LDS reads, little VALU there)
-constexpr int kF64VPre = 4;     // the first V fragments of phase Y requested behind the last K requests of phase X
-constexpr int kF64NoDma = 8;    // ABLATION (wrong results): no tile loads in the loop
-constexpr int kF64NoSm = 16;    // ABLATION (wrong results): no softmax arithmetic
-constexpr int kF64NoFence = 32; // no scheduling fences between the MFMA groups
 
 // MFMA kind K (0: S = a.b, 1: S += a.b, 2: O += a.b) behind `s_waitcnt lgkmcnt(min(n, CAP))`, n foldable
 template <typename T, int CAP, int K>
@@ -70,346 +60,11 @@ __device__ __forceinline__ void mfma_after_wait(int n, f32x16& d, const u32x4& a
 #undef TAMD_MW
 }
 
-template <typename T, bool CAUSAL, int VAR>
-__global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a) {
-  constexpr bool MERGE = (VAR & kF64Merge) != 0, LATE = (VAR & kF64Late) != 0, VPRE = (VAR & kF64VPre) != 0;
-  constexpr bool DMA = (VAR & kF64NoDma) == 0, SM = (VAR & kF64NoSm) == 0, FENCE = (VAR & kF64NoFence) == 0;
-  constexpr int D = 128, ROWB = D * 2, TILEB = kKB * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
-  constexpr int NBUF = 4, LA = NBUF - 1;  // ring depth; tiles requested ahead
-  TAMD_DYN_SMEM(smem);
-  const int lane = threadIdx.x & 63;
-  const int wave = wave_id_uniform();
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int group = a.heads_q / a.heads_kv;
-  const int nqt = (a.seq_q + kQB64 - 1) / kQB64;
-  int b, h, qt;
-  {
-    const int bid = blockIdx.x;
-    const int per_grp = nqt * group;
-    int g, within;
-    if (a.xcd_map) {
-      const int xcd = bid & 7, j = bid >> 3;
-      g = (j / per_grp) * 8 + xcd;
-      within = j % per_grp;
-    } else {
-      g = bid / per_grp;
-      within = bid % per_grp;
-    }
-    b = g / a.heads_kv;
-    const int hkv_ = g % a.heads_kv;
-    h = hkv_ * group + within % group;
-    qt = nqt - 1 - within / group;  // heavy (late) causal tiles first
-  }
-  const int hkv = h / group;
-  const int q0 = qt * kQB64;
-  const int off = a.seq_k - a.seq_q;
-  const T* Q = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.qsb + (int64_t)h * a.qsh;
-  const T* K = reinterpret_cast<const T*>(a.k) + (int64_t)b * a.ksb + (int64_t)hkv * a.ksh;
-  const T* V = reinterpret_cast<const T*>(a.v) + (int64_t)b * a.vsb + (int64_t)hkv * a.vsh;
-
-  // query blocks A (rows qw0 .. +31) and B (rows qw0 + 32 .. +63) of this wave
-  const int qw0 = q0 + wave * 64;
-  u32x4 qf[2][KS];
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    const int qrow = qw0 + blk * 32 + l31;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      qf[blk][ks] = (qrow < a.seq_q) ? ld16(Q + (int64_t)qrow * a.qss + ks * 16 + hi * 8) : u32x4{0, 0, 0, 0};
-  }
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) to_agpr(qf[blk][ks]);
-  f32x16 oacc[2][DT];
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[blk][dt][r] = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) to_agpr(oacc[blk][dt]);
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-
-  int kend = a.seq_k;
-  if (CAUSAL) {
-    const int lim = q0 + kQB64 + off;  // keys visible to the last query row of the workgroup
-    kend = lim < kend ? lim : kend;
-    if (kend < 0) kend = 0;
-  }
-  const int nkt = (kend + kKB - 1) / kKB;
-  // the last tile THIS wave needs (causal: the one holding the last key its last row sees); later tiles of the workgroup
-  // it only helps to load.  Tiles up to it are computed for both blocks: where block A is wholly above the diagonal its
-  // probabilities are exp2(-inf) = 0 and leave its running maximum, sum and accumulators as they are.
-  int tw = nkt - 1;
-  if (CAUSAL) {
-    const int last = qw0 + 63 + off;
-    const int twv = last < 0 ? -1 : last / kKB;
-    tw = twv < tw ? twv : tw;
-  }
-
-  TileOffsets<D> toff;
-  toff.init(lane);
-  const unsigned lds0 = lds_base_u32(smem);
-  constexpr float kDeferThr = 6.f;
-  TileFeed<D> feed;
-  feed.init(a.kss, wave, lane);
-  constexpr int NI = TileFeed<D>::NI, NP = 2 * NI;  // pieces per wave and tile: 4 of K, 4 of V
-  auto issue_piece = [&](int t, int slot, int n) __attribute__((always_inline)) {  // piece n of tile t into ring slot `slot`
-    const unsigned k_off = (unsigned)slot * 2u * TILEB, v_off = k_off + TILEB;
-    if (n < NI)
-      feed.issue_one(K + (int64_t)t * kKB * a.kss, smem, k_off, wave, n);
-    else
-      feed.issue_one(V + (int64_t)t * kKB * a.vss, smem, v_off, wave, n - NI);
-  };
-  // prologue: tiles 0 .. LA-1 on their way, tiles 0 and 1 landed
-  // (tiles past the last one are the last one again: the loop's vmcnt arithmetic assumes LA tiles in flight)
-  if (nkt > 0) {
-#pragma unroll
-    for (int tt = 0; tt < LA; ++tt) {
-      const int tc = tt < nkt ? tt : nkt - 1;
-#pragma unroll
-      for (int n = 0; n < NP; ++n) issue_piece(tc, tt, n);
-    }
-  }
-  wait_vmcnt<NP>();
-  raw_barrier();
-
-  f32x16 s0[2][2], s1[2][2];  // S^T of the current / the next tile: [block][32-key sub-tile]
-  u32x4 pf[2][4];             // P^T fragments (MFMA B operand): [block][16-key step]
-  if (!SM) {
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pf[blk][j] = u32x4{0, 0, 0, 0};
-  }
-  constexpr int NF = 2 * KS, KA = 4;   // K fragments of a tile; requested ahead (each feeds two MFMAs)
-  constexpr int NV = DT * 4, VA = 4;   // V fragments of a tile (two transposing reads each); requested ahead
-
-  // K fragment i = (k-step i >> 1, 32-key sub-tile i & 1) of the tile at LDS address kb
-  auto kreq = [&](unsigned kb, int i) __attribute__((always_inline)) -> u32x4 {
-    return lds_read16_abs_agpr(kb + toff.row[i >> 1], (i & 1) * 32 * ROWB);
-  };
-  // V fragment i = (16-key step i / DT, d-tile i % DT)
-  auto vreq = [&](unsigned vb, int i) __attribute__((always_inline)) -> u32x4 {
-    const int dt = i % DT, j = i / DT;
-    const int rb = ((j >> 1) * 32 + (j & 1) * 16) * ROWB;
-    const u32x2 lo = lds_read8_tr16_abs(vb + toff.tr[dt][0], rb);
-    const u32x2 h2 = lds_read8_tr16_abs(vb + toff.tr[dt][1], rb);
-    return u32x4{lo[0], lo[1], h2[0], h2[1]};
-  };
-  // MFMA step (fragment i, block blk) of sn = K . Q^T: per accumulator the k-steps in order, as in attn_fwd_kernel
-  // (nwait >= 0: the fragment's lgkmcnt wait rides in the MFMA's statement)
-  auto qk_step = [&](f32x16 (&sn)[2][2], const u32x4& kfrag, int i, int blk, int nwait) __attribute__((always_inline)) {
-    const int sub = i & 1, ks = i >> 1;
-    if (nwait >= 0) {
-      if (ks == 0)
-        mfma_after_wait<T, 8, 0>(nwait, sn[blk][sub], kfrag, qf[blk][ks]);
-      else
-        mfma_after_wait<T, 8, 1>(nwait, sn[blk][sub], kfrag, qf[blk][ks]);
-    } else if (ks == 0) {
-      mfma32_s0<T>(sn[blk][sub], kfrag, qf[blk][ks]);
-    } else {
-      mfma32_s<T>(sn[blk][sub], kfrag, qf[blk][ks]);
-    }
-  };
-  // gap m of a phase -> the piece (0..3) issued behind that MFMA, or -1
-  auto piece_of_gap = [&](int m) __attribute__((always_inline)) -> int {
-    if (!DMA) return -1;
-    if (LATE) return (m >= 25 && (m & 1)) ? (m - 25) >> 1 : -1;
-    return (m & 7) == 5 ? m >> 3 : -1;
-  };
-
-  // one key tile of a wave that still computes: sc = S(t) (ready), sn = S(t+1) (computed here).  The pieces of tile
-  // t + LA go out unconditionally: past the workgroup's last tile the index is clamped (the last tile is fetched again
-  // into a free ring slot -- no branches and one vmcnt count in the loop, for three redundant tile loads per workgroup)
-  auto tile = [&](int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2]) __attribute__((always_inline)) {
-    const int tp = (t + LA < nkt) ? t + LA : nkt - 1;   // tile whose pieces go out now ...
-    const int tpb = (t + LA) % NBUF;                     // ... into this ring slot
-    const int kt0 = t * kKB;
-    const unsigned kbn = lds0 + (unsigned)((t + 1) % NBUF) * 2u * TILEB;       // K(t+1)
-    const unsigned vb = lds0 + (unsigned)(t % NBUF) * 2u * TILEB + TILEB;      // V(t)
-    if (SM && CAUSAL && (kt0 + kKB - 1 > qw0 + off)) {  // diagonal tile (wave-uniform): key kp visible to row q iff kp <= q + off
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const int lim = qw0 + blk * 32 + l31 + off - kt0 - 4 * hi;  // key index inside the tile, less the lane's 4 * hi
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            sc[blk][sub][r] = (sub * 32 + (r & 3) + 8 * (r >> 2) <= lim) ? sc[blk][sub][r] : -INFINITY;
-      }
-    }
-    // ---- the online softmax of sc in slices (the arithmetic of attn_fwd_kernel in its order)
-    float mx[2] = {0.f, 0.f}, mref[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
-    auto sm_max = [&](int blk, int sub) __attribute__((always_inline)) {
-      float m = sub == 0 ? sc[blk][0][0] : mx[blk];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[blk][sub][r]);
-      pin_here(m);
-      mx[blk] = m;
-    };
-    auto sm_fin = [&](int blk) __attribute__((always_inline)) {
-      const float m = fmaxf(mx[blk], swap32_f32(mx[blk]));  // the other half-wave holds the other 32 keys of the row
-      const float m_tile = m * a.scale_log2;
-      if (ballot64(m_tile - m_run[blk] > kDeferThr) != 0ull) {  // deferred rescale
-        const float m_new = fmaxf(m_run[blk], m_tile);
-        const float alpha = (m_new == -INFINITY) ? 1.f : fast_exp2(m_run[blk] - m_new);
-        m_run[blk] = m_new;
-        l_run[blk] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) agpr_scale(oacc[blk][dt], alpha);
-      }
-      mref[blk] = (m_run[blk] == -INFINITY) ? 0.f : m_run[blk];
-    };
-    auto sm_exp = [&](int blk, int q) __attribute__((always_inline)) {  // values 2q, 2q+1 of the row -> one packed word
-      const int sub = q >> 3, r = 2 * (q & 7);
-      const float p0 = fast_exp2(__builtin_fmaf(sc[blk][sub][r], a.scale_log2, -mref[blk]));
-      const float p1 = fast_exp2(__builtin_fmaf(sc[blk][sub][r + 1], a.scale_log2, -mref[blk]));
-      psum[blk] += p0;
-      psum[blk] += p1;
-      unsigned w = pack2<T>(p0, p1);
-      pin_here(w, psum[blk]);  // (the compiler otherwise sinks the slice to where P is consumed: out of the MFMA gaps)
-      pf[blk][sub * 2 + (r >> 3)][(r & 7) >> 1] = w;
-      if (q == 15) l_run[blk] += psum[blk];
-    };
-    // ---- phase X: 32 MFMAs of S(t+1); behind MFMA m: block A: max 0-1, finish 2, exponentials 3-18; block B: max
-    // 19-20, finish 21, the exponentials of its first 8 values (P fragment 0) 22-25; four pieces (piece_of_gap)
-    u32x4 vr[VA + 1];
-    {
-      u32x4 kr[KA + 1];
-#pragma unroll
-      for (int i = 0; i < KA; ++i) kr[i] = kreq(kbn, i);
-#pragma unroll
-      for (int i = 0; i < NF; ++i) {
-        if (i + KA < NF) kr[(i + KA) % (KA + 1)] = kreq(kbn, i + KA);
-        if (VPRE && i >= NF - VA) vr[i - (NF - VA)] = vreq(vb, i - (NF - VA));
-        // reads issued after fragment i's: the later K fragments, and the V fragments requested so far
-        const int after = (NF - 1 - i < KA ? NF - 1 - i : KA) + ((VPRE && i >= NF - VA) ? 2 * (i - (NF - VA) + 1) : 0);
-        if (!MERGE) constexpr_wait_frag_agpr<8>(after, kr[i % (KA + 1)]);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const int m = 2 * i + blk;
-          qk_step(sn, kr[i % (KA + 1)], i, blk, (MERGE && blk == 0) ? after : -1);
-          if (SM) {
-            if (m < 2) sm_max(0, m);
-            else if (m == 2) sm_fin(0);
-            else if (m < 19) sm_exp(0, m - 3);
-            else if (m < 21) sm_max(1, m - 19);
-            else if (m == 21) sm_fin(1);
-            else if (m < 26) sm_exp(1, m - 22);
-          }
-          if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, piece_of_gap(m));
-          if (FENCE) sched_fence();
-        }
-      }
-    }
-    // ---- phase Y: 32 MFMAs of O^T += V^T . P^T (16-key step outer, d-tile inner, per fragment block A then B);
-    // block B's exponentials 4-15 behind MFMAs 0-11 (P fragment j of B is first read by MFMA 8 j + 1); four pieces
-    {
-      if (!VPRE) {
-#pragma unroll
-        for (int i = 0; i < VA; ++i) vr[i] = vreq(vb, i);
-      }
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        if (i + VA < NV) vr[(i + VA) % (VA + 1)] = vreq(vb, i + VA);
-        const int after = 2 * (NV - 1 - i < VA ? NV - 1 - i : VA);
-        if (!MERGE) constexpr_wait_frag<2 * VA>(after, vr[i % (VA + 1)]);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const int m = 2 * i + blk;
-          if (MERGE && blk == 0)
-            mfma_after_wait<T, 8, 2>(after, oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
-          else
-            mfma32_o<T>(oacc[blk][i % DT], vr[i % (VA + 1)], pf[blk][i / DT]);
-          if (SM && m < 12) sm_exp(1, m + 4);
-          if (piece_of_gap(m) >= 0) issue_piece(tp, tpb, NI + piece_of_gap(m));
-          if (FENCE) sched_fence();
-        }
-      }
-    }
-    // hand-off: tile t+2 has landed (the pieces just issued may stay in flight); every wave is done with V(t) and K(t+1)
-    wait_vmcnt<NP>();
-    wait_lgkmcnt0();
-    raw_barrier();
-  };
-
-  if (tw >= 0) {  // S(0)
-    const unsigned kb0 = lds0;
-    u32x4 kr[KA + 1];
-#pragma unroll
-    for (int i = 0; i < KA; ++i) kr[i] = kreq(kb0, i);
-#pragma unroll
-    for (int i = 0; i < NF; ++i) {
-      if (i + KA < NF) kr[(i + KA) % (KA + 1)] = kreq(kb0, i + KA);
-      constexpr_wait_frag_agpr<KA>(NF - 1 - i, kr[i % (KA + 1)]);
-      qk_step(s0, kr[i % (KA + 1)], i, 0, -1);
-      qk_step(s0, kr[i % (KA + 1)], i, 1, -1);
-    }
-    nop_states<16>();  // (S(0) is read by the VALU a few instructions into tile 0)
-  }
-  for (int t = 0; t <= tw; t += 2) {
-    tile(t, s0, s1);
-    if (t + 1 <= tw) tile(t + 1, s1, s0);
-  }
-  // past its last tile the wave only loads: its share of the pieces of the tiles the other waves still need
-  for (int t = tw + 1; t < nkt; ++t) {
-    const int tp = (t + LA < nkt) ? t + LA : nkt - 1;
-    if (DMA) {
-#pragma unroll
-      for (int n = 0; n < NP; ++n) issue_piece(tp, (t + LA) % NBUF, n);
-    }
-    wait_vmcnt<NP>();
-    raw_barrier();
-  }
-  wait_vmcnt<0>();  // (the redundant tail loads: nothing may land in the ring once it holds the O tiles)
-  raw_barrier();
-  nop_states<16>();  // (the last MFMAs' results are read by the VALU next)
-  // ---- finalise both blocks: normalise, LSE, stage O through LDS, row-wise stores
-  T* O = reinterpret_cast<T*>(a.o) + (int64_t)b * a.osb + (int64_t)h * a.osh;
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    const int qb0 = qw0 + blk * 32, qrow = qb0 + l31;
-    float l = l_run[blk];
-    l += swap32_f32(l);
-    const float inv_l = (l > 0.f) ? 1.f / l : 0.f;
-    if (a.lse != nullptr && hi == 0 && qrow < a.seq_q) {
-      const float lse = (l > 0.f) ? (m_run[blk] + fast_log2(l)) * 0.69314718055994530942f : INFINITY;
-      a.lse[((int64_t)b * a.heads_q + h) * a.seq_q + qrow] = lse;
-    }
-    const unsigned st_off = (unsigned)(wave * 2 + blk) * (32u * OROWB);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const int d0 = dt * 32 + 8 * qd + 4 * hi;
-        const u32x2 pk = {pack2<T>(oacc[blk][dt][qd * 4 + 0] * inv_l, oacc[blk][dt][qd * 4 + 1] * inv_l),
-                          pack2<T>(oacc[blk][dt][qd * 4 + 2] * inv_l, oacc[blk][dt][qd * 4 + 3] * inv_l)};
-        lds_write8(smem, st_off + (unsigned)l31 * OROWB + (unsigned)d0 * 2u, pk);
-      }
-    wave_lockstep_point();
-    constexpr int SLOTS = ROWB / 16, RPI = 64 / SLOTS;
-#pragma unroll
-    for (int it = 0; it < 32 / RPI; ++it) {
-      const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
-      const int qr = qb0 + row;
-      const u32x4 v = lds_read16(smem, st_off + (unsigned)row * OROWB + (unsigned)slot * 16u);
-      if (qr < a.seq_q) st16(O + (int64_t)qr * a.oss + slot * 8, v);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ second generation
-// What the measurements of the first kernel said (profiles/r03g..i_attn_fwd64_ab.jsonl): without the softmax arithmetic
-// the loop runs at 1550-1730 TFLOP/s, with it at 1090-1175, and WHERE its instructions sit (dense slices, a 3-stage
-// pipeline, one value per gap) changes nothing -- the loop is bound by instruction ISSUE: ~475 instructions beside the 64
-// MFMAs of a tile, 7.4 per gap where ~5 hide.  So this version removes instructions and exposed latency instead of moving
-// them: the tile loop is unrolled by four so that the LDS ring slot is static (slot offsets ride in the ds_read
+// The kernel (second generation; the first -- dynamic ring slots, one barrier at the end of a tile, per-fragment waits, and
+// its schedule variants -- is profiles/r03j_attn_fwd64_gen1.patch).  What the measurements of the first one said: without
+// the softmax arithmetic the loop runs at 1550-1730 TFLOP/s, with it at 1090-1175, and WHERE its instructions sit changes
+// nothing -- the loop is bound by instruction ISSUE, ~475 instructions beside the 64 MFMAs of a tile.  So this version
+// removes instructions and exposed latency instead of moving them: the tile loop is unrolled by four so that the LDS ring slot is static (slot offsets ride in the ds_read
 // immediates: no address adds); fragments are waited for in pairs; the barrier
 // sits BETWEEN the phases, where the first V fragments of phase Y (requested behind the last K fragments of phase X)
 // are already in flight, and the first K fragments of the next tile's phase X are requested behind the last V fragments
@@ -418,7 +73,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a)
 constexpr int kG2NoDma = 1, kG2NoSm = 2;  // ablations (wrong results)
 constexpr int kG2Split = 4;  // the V pieces of tile t+2 in phase X (odd gaps 1-7), the K pieces of tile t+3 in phase Y (odd gaps 25-31)
 template <typename T, bool CAUSAL, int VAR>
-__global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a) {
+__global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64_kernel(AttnArgs a) {
   constexpr bool DMA = (VAR & kG2NoDma) == 0, SM = (VAR & kG2NoSm) == 0, SPLIT = (VAR & kG2Split) != 0;
   constexpr int D = 128, ROWB = D * 2, TILEB = kKB * ROWB, KS = D / 16, DT = D / 32, OROWB = ROWB + 16;
   constexpr int NBUF = 4, LA = 3;
@@ -757,22 +412,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_fwd64b_kernel(AttnArgs a
 }
 
 template <typename T, int VAR>
-static int fwd64b_launch_t(const AttnArgs& a, bool causal, hipStream_t s) {
-  const int nqt64 = (a.seq_q + kQB64 - 1) / kQB64;
-  dim3 grid((unsigned)(nqt64 * a.heads_q * a.batch)), block(kAttnThreads);
-  const size_t smem = (size_t)4 * 2 * kKB * 128 * 2;
-  if (causal)
-    hipLaunchKernelGGL((attn_fwd64b_kernel<T, true, VAR>), grid, block, smem, s, a);
-  else
-    hipLaunchKernelGGL((attn_fwd64b_kernel<T, false, VAR>), grid, block, smem, s, a);
-  return launch_status();
-}
-
-template <typename T, int VAR>
 static int fwd64_launch_t(const AttnArgs& a, bool causal, hipStream_t s) {
   const int nqt64 = (a.seq_q + kQB64 - 1) / kQB64;
   dim3 grid((unsigned)(nqt64 * a.heads_q * a.batch)), block(kAttnThreads);
-  const size_t smem = (size_t)4 * 2 * kKB * 128 * 2;  // 4 x (K + V) = 128 KiB (covers the O staging: 8 x 32 x 272 B)
+  const size_t smem = (size_t)4 * 2 * kKB * 128 * 2;
   if (causal)
     hipLaunchKernelGGL((attn_fwd64_kernel<T, true, VAR>), grid, block, smem, s, a);
   else
@@ -785,28 +428,19 @@ bool attn_fwd64_applies(const AttnArgs& a, int head_dim) {
          a.kss == a.vss && TileFeed<128>::usable(a.kss);
 }
 
-constexpr int kF64Default = 0;  // the product schedule
-
-// `variant`: 1 = the product schedule; the diagnostic library has more (tamd_attn_set_fwd64, bf16 only)
+// `variant` (tamd_attn_set_fwd64): 1 the kernel; 2 with the LDS-DMA split over the phases; 5 / 6 / 7 ablations (WRONG
+// results, timing only): no tile loads / no softmax arithmetic / neither.  fp16: variant 1 only.
 int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hipStream_t s) {
   if (variant > 1 && dtype == TAMD_BF16) {
     switch (variant) {
-      case 2: return fwd64_launch_t<bf16_t, kF64Merge>(a, causal, s);
-      case 3: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late>(a, causal, s);
-      case 4: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre>(a, causal, s);
-      case 5: return fwd64_launch_t<bf16_t, kF64NoDma>(a, causal, s);
-      case 6: return fwd64_launch_t<bf16_t, kF64NoSm>(a, causal, s);
-      case 7: return fwd64_launch_t<bf16_t, kF64NoDma | kF64NoSm>(a, causal, s);
-      case 8: return fwd64_launch_t<bf16_t, kF64Merge | kF64Late | kF64VPre | kF64NoFence>(a, causal, s);
-      case 20: return fwd64b_launch_t<bf16_t, 0>(a, causal, s);
-      case 21: return fwd64b_launch_t<bf16_t, kG2NoDma>(a, causal, s);
-      case 22: return fwd64b_launch_t<bf16_t, kG2NoSm>(a, causal, s);
-      case 23: return fwd64b_launch_t<bf16_t, kG2NoDma | kG2NoSm>(a, causal, s);
-      case 24: return fwd64b_launch_t<bf16_t, kG2Split>(a, causal, s);
+      case 2: return fwd64_launch_t<bf16_t, kG2Split>(a, causal, s);
+      case 5: return fwd64_launch_t<bf16_t, kG2NoDma>(a, causal, s);
+      case 6: return fwd64_launch_t<bf16_t, kG2NoSm>(a, causal, s);
+      case 7: return fwd64_launch_t<bf16_t, kG2NoDma | kG2NoSm>(a, causal, s);
       default: return TAMD_E_ARG;
     }
   }
-  TAMD_DISPATCH_HALF(dtype, return (fwd64_launch_t<T, kF64Default>(a, causal, s)));
+  TAMD_DISPATCH_HALF(dtype, return (fwd64_launch_t<T, 0>(a, causal, s)));
   return TAMD_E_DTYPE;
 }
 
