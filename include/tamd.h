@@ -302,7 +302,7 @@ struct tamd_attn_bwd_params {
   void* dq;                    /* strides = q strides */
   void* dk;                    /* strides = k strides */
   void* dv;                    /* strides = v strides */
-  float* delta;                /* workspace, 2 x [batch, heads_q, seq_q] fp32: rowsum(dO*O), then lse*log2(e) */
+  float* delta;                /* workspace, 2 x [batch, heads_q, seq_q] fp32: -rowsum(dO*O), then -lse*log2(e) */
   /* optional (ABI 5): q and k were rotated by apply_rotary_pos_emb before the attention -- dq and dk leave through the
    * transposed rotation (bit-identical to tamd_rope_inplace(conj) on the stored gradients).  cos / sin
    * [rope_cos_batch, seq, 128] in the storage dtype, rope_cos_batch 1 or batch; head_dim 128, seq_q == seq_k;

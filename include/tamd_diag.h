@@ -32,12 +32,6 @@ int tamd_gemm_set_dbg(int dbg);
  * (0 tile-load issue, 1 K.Q^T, 2 mask + softmax, 3 P.V, 4 vmcnt wait, 5 barrier).  NULL switches it off. */
 int tamd_attn_set_trace(void* buf);
 
-/* The forward attention kernel with 64 query rows per wave (csrc/attention_fwd64.hip): while on, tamd_attn_fwd uses it
- * for head_dim 128 without padding mask / dropout / packed sequences and seq_k % 64 == 0; results are bit-identical to
- * the 32-rows-per-wave kernel (tests/test_kernels.py::test_attention_fwd64_matches_fwd, tools/attn_fwd64_ab.py).
- * Returns the number of forwards that have taken it so far. */
-int tamd_attn_set_fwd64(int on);
-
 /* Hardware-semantics probe (one wave): which = 0 mfma32, 1 mfma16, 2 ds_read_b64_tr_b16, 3 lane exchanges,
  * 4 direct-to-LDS load.  in: 4096 u32, in2: 64 u32, out: 4096 u32.  Used by tests/test_gpu_probe.py to
  * check the CPU execution model in tests/hipemu against the silicon; not on any product path. */

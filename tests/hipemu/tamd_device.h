@@ -185,33 +185,6 @@ inline f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
   for (int i = 0; i < 16; ++i) d[i] = co[i];
   return d;
 }
-// the register-file-explicit forms of attention_fwd64.hip: the same arithmetic
-template <typename T>
-inline void mfma32_s0(f32x16& d, const u32x4& a, const u32x4& b) {
-  f32x16 z;
-  for (int i = 0; i < 16; ++i) z[i] = 0.f;
-  d = mfma32<T>(a, b, z);
-}
-template <typename T>
-inline void mfma32_s(f32x16& d, const u32x4& a, const u32x4& b) { d = mfma32<T>(a, b, d); }
-template <typename T>
-inline void mfma32_o(f32x16& d, const u32x4& a, const u32x4& b) { d = mfma32<T>(a, b, d); }
-template <int N, typename T>
-inline void mfma32_s0_w(const T*, f32x16& d, const u32x4& a, const u32x4& b) { mfma32_s0<T>(d, a, b); }
-template <int N, typename T>
-inline void mfma32_s_w(const T*, f32x16& d, const u32x4& a, const u32x4& b) { mfma32_s<T>(d, a, b); }
-template <int N, typename T>
-inline void mfma32_o_w(const T*, f32x16& d, const u32x4& a, const u32x4& b) { mfma32_o<T>(d, a, b); }
-inline void to_agpr(u32x4&) {}
-inline void to_agpr(f32x16&) {}
-inline void agpr_scale(f32x16& acc, float alpha) {
-  for (int r = 0; r < 16; ++r) acc[r] *= alpha;
-}
-inline void pin_here(unsigned&, float&) {}
-inline void pin_here(float&) {}
-inline void pin_here(float&, float&) {}
-template <int N>
-inline void nop_states() {}
 template <typename T>
 inline f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
   float ci[4], co[4];
@@ -330,7 +303,6 @@ inline u32x4 lds_read16_untracked(const char* smem, unsigned off, int imm) {
 }
 inline unsigned lds_base_u32(const char* smem) { return (unsigned)(smem - hipemu::g_blk->dyn_smem); }
 inline u32x4 lds_read16_abs(unsigned addr, int imm) { return lds_read16(hipemu::g_blk->dyn_smem, addr + (unsigned)imm); }
-inline u32x4 lds_read16_abs_agpr(unsigned addr, int imm) { return lds_read16_abs(addr, imm); }
 inline u32x2 lds_read8_tr16_abs(unsigned addr, int imm) {
   return lds_read8_tr16(hipemu::g_blk->dyn_smem, addr + (unsigned)imm);
 }

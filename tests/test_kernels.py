@@ -582,41 +582,6 @@ def test_attention_spike_forces_rescale(env):
     assert torch.isfinite(o.float()).all()
 
 
-def test_attention_fwd64_matches_fwd(env):
-    """The forward kernel with 64 query rows per wave (csrc/attention_fwd64.hip: one wave per SIMD, MFMA and softmax
-    interleaved in one instruction stream, S(t+1) computed under the softmax of S(t)) is bit-identical to the
-    32-rows-per-wave kernel: causal and bidirectional, GQA, query counts that are not multiples of 256, more keys than
-    queries (KV offset), a single key tile, a late dominant key (the deferred rescale), fp16; outputs and LSE."""
-    import math
-
-    lib = ops.backend().lib
-    if not hasattr(lib, "tamd_attn_set_fwd64"):
-        pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
-    torch.manual_seed(53)
-    dev = env.device
-    cases = ([(2, 1024, 1024, 8, 2), (1, 700, 704, 4, 4), (1, 4096, 4096, 2, 1), (1, 64, 64, 1, 1)] if env.big else
-             [(1, 320, 320, 2, 1), (1, 100, 192, 2, 2), (2, 256, 256, 1, 1), (1, 40, 64, 1, 1)])
-    for ci, (b, sq, sk, hq, hkv) in enumerate(cases):
-        d = 128
-        dtype = torch.float16 if ci == 2 else torch.bfloat16
-        q = torch.randn(b, sq, hq, d).to(dtype).to(dev)
-        k = torch.randn(b, sk, hkv, d).to(dtype).to(dev)
-        v = torch.randn(b, sk, hkv, d).to(dtype).to(dev)
-        if ci == 0:
-            k[0, sk - 20, 0] = q[0, 5, 0] * 8  # a huge score late in the row: the rescale path
-        variants = (1, 2) if dtype == torch.bfloat16 else (1,)
-        for causal in (True, False):
-            o_ref, lse_ref = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal)
-            for variant in variants:
-                before = lib.tamd_attn_set_fwd64(variant)
-                try:
-                    o, lse = ops.raw_attn_fwd(q, k, v, 1 / math.sqrt(d), causal)
-                finally:
-                    after = lib.tamd_attn_set_fwd64(0)
-                assert after == before + 1, "the 64-row kernel was not taken"
-                assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref), (b, sq, sk, hq, hkv, causal, variant)
-
-
 def test_attention_fully_masked_rows_are_zero(env):
     dev = env.device
     q = torch.randn(1, 64, 1, 64).bfloat16().to(dev)

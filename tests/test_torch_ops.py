@@ -138,7 +138,7 @@ def test_torch_ops_gradients_match_fp32_autograd(env):
     sc = sc.masked_fill(torch.ones(s, s, dtype=torch.bool, device=sc.device).triu(1), float("-inf"))
     of = torch.einsum("bhqk,bkhd->bqhd", sc.softmax(-1), vv)
     assert rel_err(o, of) < 4e-3
-    assert rel_err(lse, sc.logsumexp(-1)) < 1e-05
+    assert rel_err(lse, sc.logsumexp(-1)) < 4e-4   # (q enters the kernel multiplied by scale*log2(e) and re-rounded)
     go = torch.randn_like(of)
     o.backward(go.to(o.dtype))
     of.backward(go.to(o.dtype).float())

@@ -1,5 +1,6 @@
 #!/bin/bash
 exec < /dev/null
+# (RECORD of past visits: the kernel and tools/attn_fwd64_ab.py were removed, profiles/r03o_attn_fwd64_removed.patch)
 # Round 3, GPU visit 6+: the 64-rows-per-wave attention forward (csrc/attention_fwd64.hip) against the 32-rows-per-wave
 # kernel: bit-identity test on the silicon, stand-alone A/B over shapes, kernel stats of one arm each.
 # usage: gpurun --timeout 600 -- bash tools/gpu_r03_f.sh [tag]

@@ -85,7 +85,6 @@ DIAG_SIGNATURES = {
     "tamd_gemm_set_clock_buffer": (c_int, [P]),
     "tamd_gemm_set_dbg": (c_int, [c_int]),
     "tamd_attn_set_trace": (c_int, [P]),
-    "tamd_attn_set_fwd64": (c_int, [c_int]),
     "tamd_mfma_power": (c_int, [P, c_int, c_int, c_int, P, P, P]),
     "tamd_probe": (c_int, [P, P, P, c_int, c_int, P]),
     "tamd_bw_probe": (c_int, [P, c_size_t, c_int, c_size_t, c_int, c_int, c_int, P, P]),

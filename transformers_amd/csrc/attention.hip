@@ -1,5 +1,5 @@
 // attention.hip -- flash-style scaled-dot-product attention for gfx950: forward kernel (text: attention_fwd_kernel.inc), C-ABI entry points; the
-// backward's delta / dQ kernels come from attention_bwd.inc, the dK/dV kernel is attention_bwd_dkdv.hip, shared
+// backward's dQ kernel (which also computes delta) comes from attention_bwd.inc, the dK/dV kernel is attention_bwd_dkdv.hip, shared
 // device code (tile loads, swizzles, dropout hash, packed-sequence bounds) is attention_common.h.
 //
 // Replaces, behind AttentionInterface (src/transformers/modeling_utils.py:5092-5130):
@@ -38,10 +38,6 @@ namespace {
 
 #ifdef TAMD_DIAG
 unsigned long long* g_attn_trace = nullptr;
-// The forward kernels with 64 query rows per wave (attention_fwd64.hip, diagnostic library only: measured level with
-// attn_fwd_kernel at the Llama-3-8B shape, profiles/r03f..m_attn_fwd64_ab.jsonl): 0 = off, n = variant n where it applies
-int g_attn_fwd64 = 0;
-int g_attn_fwd64_launches = 0;
 #endif
 
 template <typename T, int D>
@@ -138,11 +134,6 @@ extern "C" int tamd_attn_set_trace(void* buf) {
   g_attn_trace = reinterpret_cast<unsigned long long*>(buf);
   return TAMD_OK;
 }
-// 1: tamd_attn_fwd takes the 64-rows-per-wave kernel wherever it applies; returns how many forwards have taken it so far
-extern "C" int tamd_attn_set_fwd64(int on) {
-  g_attn_fwd64 = on;
-  return g_attn_fwd64_launches;
-}
 #endif
 
 extern "C" uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index) {
@@ -154,12 +145,6 @@ extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t str
   if (chk != TAMD_OK) return chk;
   const AttnArgs a = make_args(p);
   hipStream_t s = TAMD_STREAM(stream);
-#ifdef TAMD_DIAG
-  if (g_attn_fwd64 && attn_fwd64_applies(a, (int)p->head_dim)) {
-    ++g_attn_fwd64_launches;
-    return attn_fwd64_launch(a, p->causal != 0, (int)p->dtype, g_attn_fwd64, s);
-  }
-#endif
   if (p->head_dim == 128) {
     TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 128>(a, p->causal != 0, s)));
   } else {

@@ -21,6 +21,11 @@
 //   * every LDS read of the loop is issued untracked (tamd_device.h) and tied to counted s_waitcnt lgkmcnt(N)
 //     through register dependencies: the compiler drains vmcnt in front of every ds_read_b64_tr_b16 it can see
 //     while LDS-DMA is in flight, and its own lgkmcnt(0) for one tracked read would drain the reads issued ahead;
+//   * the S and dP accumulator chains START from the statistics: K is multiplied by scale*log2(e) once per workgroup
+//     (scale_frag, attention_common.h) and the dQ kernel stores -lse*log2(e) and -delta, whose LDS rows are read (16
+//     bytes = 4 consecutive query rows = 4 C-layout registers) straight into the accumulator tuples; the MFMAs then
+//     deliver S'' = log2 p and dP - delta, and an element costs exp2 + mul + its share of two conversions: 3 VALU
+//     instructions instead of 5 (the dropout variants fold the lse only: (dP*keep - delta) is not linear in dP);
 //   * softmax-backward arithmetic of sub-tile s (4 chunks of 4 query rows) is interleaved with the MFMAs of the
 //     next phase (sched_group_barrier), branch-free (the mask test costs 2 VALU per element on every tile, a
 //     branch would cut the interleave), packed-f32 VALU off (-fno-slp-vectorize: an anti-lever beside MFMAs);
@@ -35,8 +40,8 @@
 
 namespace tamd {
 
-__device__ __attribute__((aligned(16))) static const unsigned int g_pinf32[4] = {0x7f800000u, 0x7f800000u, 0x7f800000u,
-                                                                                0x7f800000u};
+__device__ __attribute__((aligned(16))) static const unsigned int g_ninf32[4] = {0xff800000u, 0xff800000u, 0xff800000u,
+                                                                                0xff800000u};
 
 // s_waitcnt lgkmcnt(N) that the four fragments depend on: MFMAs consuming them cannot be scheduled above it
 template <int N>
@@ -71,6 +76,15 @@ __device__ __forceinline__ void after_wait1(u32x4& x0) {
   asm volatile("" : "+v"(x0)::"memory");
 #else
   (void)x0;
+#endif
+}
+// ... for two accumulator tuples filled by untracked LDS reads (the statistics rows that start the S / dP chains)
+__device__ __forceinline__ void after_wait_acc(f32x16& x0, f32x16& x1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x0), "+v"(x1)::"memory");
+#else
+  (void)x0;
+  (void)x1;
 #endif
 }
 
@@ -116,6 +130,11 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     kf[ks] = ok ? ld16(K + (int64_t)krow * a.kss + ks * 16 + hi * 8) : u32x4{0, 0, 0, 0};
     vf[ks] = ok ? ld16(V + (int64_t)krow * a.vss + ks * 16 + hi * 8) : u32x4{0, 0, 0, 0};
   }
+  if (!(DBG & 1)) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = scale_frag<T, true>(kf[ks], a.scale_log2);  // S leaves the MFMAs in the exp2 domain
+  }
+  constexpr bool FOLD_DELTA = !DROP;  // dP's chain starts from -delta (dropout: (dP*keep - delta) is not linear in dP)
   bool key_ok = krow < a.seq_k;
   if (HAS_MASK && a.key_valid != nullptr)
     key_ok = key_ok && a.key_valid[(int64_t)b * a.seq_k + (krow < a.seq_k ? krow : 0)] != 0;
@@ -202,11 +221,11 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         glds16(ok ? (const void*)(bo + po[i]) : (const void*)g_zero16a, smem, do_off + (unsigned)(wave * NI + i) * 1024u);
       }
     }
-    if (wave < 2) {  // wave 0: lse of the tile's 64 rows, wave 1: delta; rows past seq_q read +inf / 0 (p = 0)
+    if (wave < 2) {  // wave 0: -lse*log2(e) of the tile's 64 rows, wave 1: -delta; rows past seq_q read -inf / 0 (p = 0)
       const int qr = qt * kQT + lane;
       const float* src = (const float*)g.delta + (wave ? 0 : (int64_t)a.batch * a.heads_q * a.seq_q) +
-                         ((int64_t)b * a.heads_q + h) * a.seq_q + qr;  // wave 0: lse*log2(e) (second half)
-      const void* p = (qr < a.seq_q) ? (const void*)src : (wave ? (const void*)g_zero16a : (const void*)g_pinf32);
+                         ((int64_t)b * a.heads_q + h) * a.seq_q + qr;  // wave 0: -lse*log2(e) (second half)
+      const void* p = (qr < a.seq_q) ? (const void*)src : (wave ? (const void*)g_zero16a : (const void*)g_ninf32);
       glds4(p, smem, st_off + (unsigned)wave * (kQT * 4));
     }
   };
@@ -256,6 +275,25 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     f[3] = tr_frag(q_off, 2 * dtp + 1, j);
   };
 
+  // the S / dP accumulators of sub-tile `sub` of the tile in LDS buffer `buf`, loaded with the negated statistics of their
+  // 16 query rows (C layout: registers 4j .. 4j+3 = rows 8j + 4*hi .. +3 = one 16-byte read)
+  auto load_stats = [&](f32x16& s_, f32x16& dp_, int buf, int sub) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32x4 l4 = {0u, 0u, 0u, 0u}, d4 = {0u, 0u, 0u, 0u};
+      if (!(DBG & 1)) {
+        l4 = lds_read16_abs(stataddr[buf], (sub * 32 + 8 * j) * 4);
+        if (FOLD_DELTA) d4 = lds_read16_abs(stataddr[buf], (sub * 32 + 8 * j) * 4 + kQT * 4);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s_[4 * j + e] = u32_as_f32(l4[e]);
+        dp_[4 * j + e] = u32_as_f32(d4[e]);
+      }
+    }
+  };
+  constexpr int NSTAT = (DBG & 1) ? 0 : (FOLD_DELTA ? 8 : 4);  // LDS reads of one load_stats
+
   if (niter > 0) issue(0, 0);
   if (niter > 0) issue(1, 1);  // (a padding tile when niter == 1)
   wait_vmcnt0();
@@ -263,7 +301,16 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   // Straight-line loop body (no per-wave skip of fully masked tiles: the causal mask zeroes them, and the two
   // waves it concerns lose one tile per head; any divergent path through the body makes the compiler shuffle the
   // 128 accumulator registers at every back edge).  Group 0's fragments are requested one tile ahead, into fa.
-  if (niter > 0) load_rows(fa, 0u, (unsigned)TILEB, 0, 0);
+  f32x16 sn, dpn;  // S / dP of sub-tile 0 of the NEXT tile: statistics requested one tile ahead, like group 0's fragments
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    sn[r] = 0.f;
+    dpn[r] = 0.f;
+  }
+  if (niter > 0) {
+    load_rows(fa, 0u, (unsigned)TILEB, 0, 0);
+    load_stats(sn, dpn, 0, 0);
+  }
   const int niter2 = (niter + 1) & ~1;  // even: an odd count gets one all-zero padding tile
   int cmp_h = 0, cmp_qt = nqt64 - 1;    // (head, q-tile) of the tile being computed
   // Two copies of the loop body.  PLAIN: the tile needs no mask for any key of this wave (every key of the wave valid,
@@ -304,13 +351,14 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     // softmax backward of 4 consecutive query rows (chunk qd) of sub-tile `sub`: C-layout registers qd*4 .. +3 of
     // P and dS, rounded and packed at once into B operand sub*2 + (qd>>1), dwords (qd&1)*2 .. +1
     // lse / delta of 4 consecutive query rows of chunk qd (16 bytes each; lane part of the address = 16*hi)
-    auto stat_reads = [&](int sub, int qd, u32x4& l4, u32x4& d4) {
-      if (DBG & 1) return;
+    // (only the dropout variants still read -delta beside the arithmetic; NSR = reads per chunk)
+    constexpr int NSR = ((DBG & 1) || FOLD_DELTA) ? 0 : 1;
+    auto stat_reads = [&](int sub, int qd, u32x4& d4) {
+      if (NSR == 0) return;
       const int imm = (sub * 32 + 8 * qd) * 4;  // (st_off of the second buffer does not fit the 16-bit offset field)
-      l4 = lds_read16_abs(stataddr[cur], imm);
       d4 = lds_read16_abs(stataddr[cur], imm + kQT * 4);
     };
-    auto softmax_chunk = [&](int sub, int qd, const u32x4& l4, const u32x4& d4) {
+    auto softmax_chunk = [&](int sub, int qd, const u32x4& d4) {
       if (DBG & 1) {
         const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
         pf[op][w] = f32_as_u32(s[sub][qd * 4]);
@@ -331,7 +379,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           x = (mask_lim <= ql + e && ql + e <= mask_hi) ? x : -INFINITY;
         else if (!PLAIN)
           x = (mask_lim <= ql + e) ? x : -INFINITY;
-        const float pe = fast_exp2(__builtin_fmaf(x, a.scale_log2, -u32_as_f32(l4[e])));
+        const float pe = fast_exp2(x);  // x = S*scale*log2(e) - lse*log2(e): the chain started from -lse*log2(e)
         float keep = 1.f;
         if (DROP) {
           const int qg = qt0 + ql + e;  // global query row
@@ -340,7 +388,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           keep = drop.factor(base, krow < a.seq_k ? krow : 0);
         }
         p[e] = pe * keep;  // dV uses the dropped probabilities
-        ds[e] = pe * (dp[sub][r] * keep - u32_as_f32(d4[e]));
+        ds[e] = FOLD_DELTA ? pe * dp[sub][r] : pe * (dp[sub][r] * keep + u32_as_f32(d4[e]));  // (d4 = -delta)
       }
       const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
       pf[op][w] = pack2<T>(p[0], p[1]);
@@ -361,25 +409,23 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       }
     };
     // ---- phases A0, A1: S and dP of the two 32-row sub-tiles; A1 carries the softmax backward of sub-tile 0
+    s[0] = sn;  // (requested behind the previous tile's hand-off)
+    dp[0] = dpn;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[sub][r] = 0.f;
-        dp[sub][r] = 0.f;
-      }
 #pragma unroll
       for (int ga = 0; ga < NGA; ++ga) {
         const int gidx = sub * NGA + ga;  // group index inside the tile (parity picks the ring half)
         u32x4(&fc)[4] = (gidx & 1) ? fb : fa;
         u32x4(&fn)[4] = (gidx & 1) ? fa : fb;
         constexpr int NCH_A = 4 / NGA;  // softmax chunks carried by one A1 group
-        u32x4 l4[NCH_A], d4[NCH_A];
+        u32x4 d4[NCH_A];
         // every LDS read of the loop is untracked; issue order = completion order:
-        //   statistics of this group's chunks | next group's fragments | (wait: all but the newest batch)
+        //   (dropout: -delta of this group's chunks) | next group's fragments | (first group of the tile: the statistics
+        //   that start sub-tile 1's chains) | wait: all but the newest batch
         if (sub == 1) {
 #pragma unroll
-          for (int c = 0; c < NCH_A; ++c) stat_reads(0, ga * NCH_A + c, l4[c], d4[c]);
+          for (int c = 0; c < NCH_A; ++c) stat_reads(0, ga * NCH_A + c, d4[c]);
         }
         if (ga + 1 < NGA)
           load_rows(fn, q_off, do_off, sub, ga + 1);
@@ -387,14 +433,19 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           load_rows(fn, q_off, do_off, 1, 0);
         else
           load_tr(fn, q_off, do_off, 0, 0);
+        if (sub == 0 && ga == 0) load_stats(s[1], dp[1], cur, 1);
         sched_fence();
         if (sub == 1 && ga == NGA - 1)
           wait_frags<8>(fc[0], fc[1], fc[2], fc[3]);
+        else if (sub == 0 && ga == 0)
+          wait_frags<4 + NSTAT>(fc[0], fc[1], fc[2], fc[3]);  // (everything older has landed: sub-tile 0's statistics too)
         else
           wait_frags<4>(fc[0], fc[1], fc[2], fc[3]);
-        if (sub == 1) {
+        if (sub == 0 && ga == 0) after_wait_acc(s[0], dp[0]);
+        if (sub == 0 && ga == 1) after_wait_acc(s[1], dp[1]);  // (NGA >= 2: covered by this group's wait)
+        if (sub == 1 && NSR) {
 #pragma unroll
-          for (int c = 0; c < NCH_A; ++c) after_wait(l4[c], d4[c]);
+          for (int c = 0; c < NCH_A; ++c) after_wait1(d4[c]);
         }
         sched_fence();
         s[sub] = mm(fc[0], kf[2 * ga], s[sub]);
@@ -403,7 +454,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         dp[sub] = mm(fc[3], vf[2 * ga + 1], dp[sub]);
         if (sub == 1) {  // softmax backward of sub-tile 0 in the shadow of these MFMAs (NGA = 2: two chunks)
 #pragma unroll
-          for (int c = 0; c < NCH_A; ++c) softmax_chunk(0, ga * NCH_A + c, l4[c], d4[c]);
+          for (int c = 0; c < NCH_A; ++c) softmax_chunk(0, ga * NCH_A + c, d4[c]);
           mfma_valu_interleave();
         }
         sched_fence();
@@ -421,14 +472,15 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         u32x4(&fn)[4] = (gidx & 1) ? fa : fb;
         const bool last = (half == 1 && gc == NGC - 1);
         constexpr int NCH_C = 4 / NGC;
-        u32x4 l4[NCH_C], d4[NCH_C];
+        u32x4 d4[NCH_C];
         if (half == 0) {
 #pragma unroll
-          for (int c = 0; c < NCH_C; ++c) stat_reads(1, gc * NCH_C + c, l4[c], d4[c]);
+          for (int c = 0; c < NCH_C; ++c) stat_reads(1, gc * NCH_C + c, d4[c]);
         }
         if (last) {
           hand_off();  // waits lgkmcnt(0): this group's fragments are in registers
           load_rows(fn, nq_off, ndo_off, 0, 0);  // group 0 of tile it+1 (stale but harmless after the last tile)
+          load_stats(sn, dpn, cur ^ 1, 0);       // ... and the statistics that start its first S / dP chains
           sched_fence();
           wait_frags<15>(fc[0], fc[1], fc[2], fc[3]);  // dependency only (nothing left to wait for)
         } else {
@@ -437,9 +489,9 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           sched_fence();
           wait_frags<8>(fc[0], fc[1], fc[2], fc[3]);  // all but the 8 reads just issued
         }
-        if (half == 0) {
+        if (half == 0 && NSR) {
 #pragma unroll
-          for (int c = 0; c < NCH_C; ++c) after_wait(l4[c], d4[c]);
+          for (int c = 0; c < NCH_C; ++c) after_wait1(d4[c]);
         }
         sched_fence();
         dvacc[2 * dtp] = mm(fc[0], pf[j], dvacc[2 * dtp]);
@@ -448,7 +500,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         dkacc[2 * dtp + 1] = mm(fc[3], dsf[j], dkacc[2 * dtp + 1]);
         if (half == 0) {  // softmax backward of sub-tile 1 in the shadow of these MFMAs
 #pragma unroll
-          for (int c = 0; c < NCH_C; ++c) softmax_chunk(1, gc * NCH_C + c, l4[c], d4[c]);
+          for (int c = 0; c < NCH_C; ++c) softmax_chunk(1, gc * NCH_C + c, d4[c]);
           mfma_valu_interleave();
         }
         sched_fence();

@@ -40,12 +40,6 @@ struct AttnArgs {
   unsigned long long* trace;  // diagnostic build: per-phase shader-clock sums of workgroup 0 (tamd_attn_set_trace), else null
 };
 
-// attention_fwd64.hip: the forward with 64 query rows per wave (its own translation unit: compiled WITHOUT
-// -amdgpu-mfma-vgpr-form, it places every MFMA operand itself).  `applies`: head_dim 128, no padding mask / dropout /
-// packed sequences, seq_k a multiple of 64, K and V rows the same distance apart.
-bool attn_fwd64_applies(const AttnArgs& a, int head_dim);
-int attn_fwd64_launch(const AttnArgs& a, bool causal, int dtype, int variant, hipStream_t s);
-
 // Diagnostic build only: phase i of the forward tile loop ends here (s_memtime stamps of workgroup 0, summed per wave)
 #ifdef TAMD_DIAG
 #define TAMD_ATTN_PHASE(i_)                              \
@@ -169,26 +163,6 @@ __device__ __forceinline__ void wait_frag(u32x4& f) {
   (void)f;
 #endif
 }
-template <int N>
-__device__ __forceinline__ void wait_frag_agpr(u32x4& f) {  // (the fragment lives in AGPRs: lds_read*_abs_agpr)
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(f) : "n"(N) : "memory");
-#else
-  (void)f;
-#endif
-}
-template <int CAP>
-__device__ __forceinline__ void constexpr_wait_frag_agpr(int n, u32x4& f) {
-  static_assert(CAP <= 15, "lgkmcnt is a 4-bit counter");
-  if (n >= CAP) return wait_frag_agpr<CAP>(f);
-#define TAMD_WF(N_) \
-  if (N_ < CAP && n == N_) return wait_frag_agpr<(N_ < CAP ? N_ : 0)>(f);
-  TAMD_WF(14) TAMD_WF(13) TAMD_WF(12) TAMD_WF(11) TAMD_WF(10) TAMD_WF(9) TAMD_WF(8) TAMD_WF(7) TAMD_WF(6) TAMD_WF(5) TAMD_WF(4)
-  TAMD_WF(3) TAMD_WF(2) TAMD_WF(1)
-#undef TAMD_WF
-  wait_frag_agpr<0>(f);
-}
-
 // wait_frag<min(n, CAP)> for a compile-time-foldable n (unrolled loop index arithmetic)
 template <int CAP>
 __device__ __forceinline__ void constexpr_wait_frag(int n, u32x4& f) {
@@ -270,6 +244,42 @@ __device__ __forceinline__ void pack_c_to_b(const float* p, u32x4* out2) {
   for (int st = 0; st < 2; ++st)
     out2[st] = u32x4{pack2<T>(p[8 * st + 0], p[8 * st + 1]), pack2<T>(p[8 * st + 2], p[8 * st + 3]),
                      pack2<T>(p[8 * st + 4], p[8 * st + 5]), pack2<T>(p[8 * st + 6], p[8 * st + 7])};
+}
+
+// A resident MFMA operand multiplied by a constant and rounded again (once per workgroup): with the fragment of Q (forward,
+// dQ kernel) or of K (dK/dV kernel) carrying scale*log2(e), S leaves the matrix pipe in the exp2 domain, and with the
+// accumulator chain STARTED from -m (the forward's running row maximum) or -lse*log2(e) (the backward kernels) -- the
+// MFMA's srcC operand, free -- the softmax numerator is ONE instruction per element, exp2(S''), instead of fma + exp2.
+// The attention loops are bound by instruction issue (4-5 instructions hide beside an MFMA), so an
+// instruction less per element is time.  Cost: one more rounding of the operand to the storage dtype (relative 2^-9 in
+// bf16; the reference's own bf16 path rounds S itself to bf16).
+template <typename T, bool IN_AGPR = false>  // IN_AGPR: the one-wave-per-SIMD kernels keep their resident operands in AGPRs
+__device__ __forceinline__ u32x4 scale_frag(u32x4 f, float c) {
+  float x[8];
+  unpack16<T>(f, x);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] *= c;
+  u32x4 r = pack16<T>(x);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one 128-bit value from here on, born in the register file its MFMAs read it from (left as four dwords, or pinned in
+  // VGPRs, the dK/dV kernel's tuples were re-assembled by 28 v_accvgpr_mov per tile in front of the MFMAs)
+  if (IN_AGPR)
+    asm volatile("" : "+a"(r));
+  else
+    asm volatile("" : "+v"(r));
+#endif
+  return r;
+}
+// 16 equal accumulator registers (a per-lane constant as the srcC tuple of the first MFMA of a chain); opaque to the
+// compiler so that it stays ONE resident tuple instead of 16 moves in front of every chain
+__device__ __forceinline__ f32x16 splat16(float v) {
+  f32x16 t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(t));
+#endif
+  return t;
 }
 
 // first visible key of query row `qrow` (0 when sequences are not packed) and its wave-wide max / min

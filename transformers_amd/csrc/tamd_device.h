@@ -97,78 +97,6 @@ __device__ __forceinline__ f32x4 mfma16<f16_t>(u32x4 a, u32x4 b, f32x4 c) {
                                                 0);
 }
 
-// The 32x32x16 MFMA with the register FILE of every operand chosen by the caller (inline asm; the builtin leaves the
-// choice to the compiler, which for a kernel that needs more than 256 registers puts every accumulator into AGPRs and
-// copies each element the VALU touches).  For attention_fwd64.hip: S accumulates in VGPRs (the softmax reads it), O in
-// AGPRs (only MFMAs touch it), Q fragments sit in AGPRs, K / V / P fragments in VGPRs.  hipcc pads no hazards around
-// inline asm (cdna_hip_programming.md 5.7 item 2): the callers keep every VALU reader of a result, and every VALU writer
-// of an operand, several instructions away from the MFMA.
-//   mfma32_s0   d(VGPR)  = a(AGPR) . b(AGPR)          mfma32_s   d(VGPR) += a(AGPR) . b(AGPR)
-//   mfma32_o    d(AGPR) += a(VGPR) . b(VGPR)
-//   to_agpr     the value in AGPRs from here on (one copy; later "a" uses take it in place)
-#define TAMD_MFMA32_ASM_(T_, MNEM_)                                                                          \
-  template <>                                                                                                \
-  __device__ __forceinline__ void mfma32_s0<T_>(f32x16 & d, const u32x4& a, const u32x4& b) {               \
-    asm volatile(MNEM_ " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));                                       \
-  }                                                                                                          \
-  template <>                                                                                                \
-  __device__ __forceinline__ void mfma32_s<T_>(f32x16 & d, const u32x4& a, const u32x4& b) {                \
-    asm volatile(MNEM_ " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));                                       \
-  }                                                                                                          \
-  template <>                                                                                                \
-  __device__ __forceinline__ void mfma32_o<T_>(f32x16 & d, const u32x4& a, const u32x4& b) {                \
-    asm volatile(MNEM_ " %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));                                       \
-  }
-template <typename T>
-__device__ __forceinline__ void mfma32_s0(f32x16& d, const u32x4& a, const u32x4& b);
-template <typename T>
-__device__ __forceinline__ void mfma32_s(f32x16& d, const u32x4& a, const u32x4& b);
-template <typename T>
-__device__ __forceinline__ void mfma32_o(f32x16& d, const u32x4& a, const u32x4& b);
-TAMD_MFMA32_ASM_(bf16_t, "v_mfma_f32_32x32x16_bf16")
-TAMD_MFMA32_ASM_(f16_t, "v_mfma_f32_32x32x16_f16")
-#undef TAMD_MFMA32_ASM_
-// ... with `s_waitcnt lgkmcnt(N)` in front of the MFMA in the SAME statement: operand `a` was filled by an untracked LDS
-// read; a separate wait statement costs the compiler's boundary pad (an s_nop) before the MFMA that reads its operand
-#define TAMD_MFMA32_WASM_(T_, MNEM_)                                                                          \
-  template <int N>                                                                                            \
-  __device__ __forceinline__ void mfma32_s0_w(const T_*, f32x16& d, const u32x4& a, const u32x4& b) {        \
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" MNEM_ " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b), "n"(N));    \
-  }                                                                                                           \
-  template <int N>                                                                                            \
-  __device__ __forceinline__ void mfma32_s_w(const T_*, f32x16& d, const u32x4& a, const u32x4& b) {         \
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" MNEM_ " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b), "n"(N));    \
-  }                                                                                                           \
-  template <int N>                                                                                            \
-  __device__ __forceinline__ void mfma32_o_w(const T_*, f32x16& d, const u32x4& a, const u32x4& b) {         \
-    asm volatile("s_waitcnt lgkmcnt(%3)\n\t" MNEM_ " %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b), "n"(N));    \
-  }
-TAMD_MFMA32_WASM_(bf16_t, "v_mfma_f32_32x32x16_bf16")
-TAMD_MFMA32_WASM_(f16_t, "v_mfma_f32_32x32x16_f16")
-#undef TAMD_MFMA32_WASM_
-__device__ __forceinline__ void to_agpr(u32x4& v) { asm volatile("" : "+a"(v)); }
-__device__ __forceinline__ void to_agpr(f32x16& v) { asm volatile("" : "+a"(v)); }
-// acc (held in AGPRs) *= alpha, element by element through one VGPR: the accumulator stays where it is on both sides of
-// the branch that guards the (rare) rescale -- written as `acc[r] *= alpha` the compiler reads all of it into VGPRs ahead
-// of the branch, on every tile
-__device__ __forceinline__ void agpr_scale(f32x16& acc, float alpha) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float t;
-    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 %0, %1"
-                 : "+a"(acc[r]), "=&v"(t)
-                 : "v"(alpha));
-  }
-}
-// the values are computed by this point of the instruction stream (an empty volatile asm that "modifies" them: it keeps
-// its place among the other volatile statements -- the MFMAs, the LDS reads -- and IR-level sinking cannot move the
-// arithmetic below it)
-__device__ __forceinline__ void pin_here(unsigned& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void pin_here(float& a) { asm volatile("" : "+v"(a)); }
-__device__ __forceinline__ void pin_here(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
-template <int N>
-__device__ __forceinline__ void nop_states() { asm volatile("s_nop %0" ::"n"(N - 1)); }  // N <= 16 wait states
-
 // ---------------------------------------------------------------- LDS
 // All LDS addressing in the MFMA kernels is by BYTE OFFSET into one dynamic
 // array (cdna_hip_programming.md G17: a single 16-byte aligned extern array).
@@ -237,14 +165,6 @@ __device__ __forceinline__ u32x2 lds_read8_tr16_abs(unsigned addr, int imm) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(imm) : "memory");
   return v;
 }
-// ... and with the destination in AGPRs (MFMA A / B operands may be AGPRs: fragments that only MFMAs read need no VGPR)
-__device__ __forceinline__ u32x4 lds_read16_abs_agpr(unsigned addr, int imm) {
-  u32x4 v;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(v) : "v"(addr), "i"(imm) : "memory");
-  return v;
-}
-// (no AGPR form of the transposing 8-byte read: a fragment assembled from two of them is put together by compiler copies,
-// which read the halves before they have landed)
 // Direct-to-LDS 16-byte load: the wave writes 64 x 16 B = 1 KiB contiguous at
 // `smem + wave_base_off` (must be wave-uniform); each lane supplies its own
 // global source address.  Completion is tracked by vmcnt.
