@@ -201,9 +201,11 @@ int tamd_cross_entropy_bwd(const void* logits, const int64_t* labels, const floa
 enum tamd_gemm_flags {
   TAMD_GEMM_A_KM = 1, /* A stored [K, M] (k-major rows) instead of [M, K] */
   TAMD_GEMM_B_KN = 2, /* B stored [K, N] instead of [N, K]               */
-  /* diagnostic schedule hints (A/B measurements, tests); 0 = library default (full-line kernel when K % 64 == 0,
-   * else ping-pong).  A hint that does not apply to K is ignored. */
+  /* diagnostic schedule hints (A/B measurements, tests); 0 = library default (full-line kernel when K % 64 == 0 --
+   * the small tile for small row-major grids -- else ping-pong).  A hint that does not apply to K is ignored. */
   TAMD_GEMM_SCHED_PP = 1 << 8, /* 8-wave ping-pong kernel, 32-deep stages (every layout, any K)                */
+  TAMD_GEMM_SCHED_SM = 2 << 8, /* 128 x 128 tile, two workgroups per CU (row-major operands, K % 64 == 0): the  */
+                               /* default for grids of few 256 x 256 tiles that split-K does not take           */
   TAMD_GEMM_SCHED_FL = 3 << 8  /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
 };
 enum tamd_gemm_epilogue {

@@ -44,6 +44,7 @@ def test_packed_bounds_match_the_oracle(rows, seed):
 def test_split_k_policy_mirror(m, n, k, epi):
     lib = _cabi.TamdLib(build.build())
     assert ops.gemm_workspace_bytes(m, n, k, epi) == lib.tamd_gemm_workspace_bytes(m, n, k, 0, epi)
+    assert ops.gemm_workspace_bytes(m, n, k, epi, 2) == lib.tamd_gemm_workspace_bytes(m, n, k, 2, epi)
 
 
 def test_mask_function_decoder():

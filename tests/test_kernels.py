@@ -263,10 +263,11 @@ def test_gemm_layouts(env, layout):
         assert rel_err(c, ref) < 0.0034, (layout, m, n, k)  # bf16 output rounding only (fp32 accumulation)
 
 
-@pytest.mark.parametrize("sched", ["pp", "fl", None])
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm", None])
 def test_gemm_schedules_agree(env, sched):
-    """The two GEMM kernels (ping-pong with 32-deep stages; one-wave-per-SIMD with 64-deep full-line stages) and the
-    default dispatch agree bit for bit on ragged M/N, stage counts around the ring size, every layout and epilogue."""
+    """The three GEMM kernels (ping-pong with 32-deep stages; one-wave-per-SIMD with 64-deep full-line stages; the 128 x 128
+    tile for small forward grids) and the default dispatch agree bit for bit on ragged M/N, stage counts around the ring
+    size, every layout (the small tile: row-major operands) and epilogue."""
     torch.manual_seed(19)
     dev = env.device
     shapes = ([(4096, 4096, 4096), (1000, 1032, 320), (4100, 264, 832), (256, 256, 64)] if env.big else
@@ -280,7 +281,7 @@ def test_gemm_schedules_agree(env, sched):
         if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
             continue  # the default dispatch splits K for this grid: fp32 summation order differs (test_gemm_split_k)
         assert torch.equal(c, ops.raw_gemm(x, w, sched="pp")), (sched, m, n, k)  # same fp32 k-order per output
-    if sched != "pp":  # k-major operands (the backward products)
+    if sched not in ("pp", "sm"):  # k-major operands (the backward products)
         for (m, n, k) in ([(4096, 1024, 4096), (1000, 1032, 320), (264, 4104, 832)] if env.big else
                           [(256, 256, 64), (264, 248, 128), (136, 520, 192), (72, 264, 320), (304, 136, 384)]):
             if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
@@ -316,7 +317,9 @@ def test_gemm_split_k(env):
     torch.manual_seed(23)
     dev = env.device
     lib = ops.backend().lib
-    shapes = [(768, 3072, 16384), (768, 768, 8192), (264, 520, 4096)] if env.big else [(256, 256, 2048), (264, 136, 2560)]
+    shapes = [(768, 3072, 16384), (768, 768, 8192), (264, 520, 4096)] if env.big else [(256, 256, 4096), (264, 136, 4160)]
+    assert lib.tamd_gemm_workspace_bytes(256, 256, 2048, 0, ops.EPI_NONE) == 0  # forward layout, < 64 stages: the 128 x 128 tile
+    assert lib.tamd_gemm_workspace_bytes(256, 256, 2048, 3, ops.EPI_NONE) > 0   # the same product as a weight gradient: split
     for (m, n, k) in shapes:
         assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE) > 0
         assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_BIAS) == 0      # only plain / accumulate split
@@ -338,6 +341,7 @@ def test_gemm_split_k(env):
                       (30522, 768, 16384), (264, 136, 2560), (128, 4, 4096), (1000, 1000, 1000)]:
         for epi in (ops.EPI_NONE, ops.EPI_ACCUM, ops.EPI_BIAS):  # the host-side mirror of the policy stays in step
             assert ops.gemm_workspace_bytes(m, n, k, epi) == lib.tamd_gemm_workspace_bytes(m, n, k, 0, epi), (m, n, k, epi)
+            assert ops.gemm_workspace_bytes(m, n, k, epi, 3) == lib.tamd_gemm_workspace_bytes(m, n, k, 3, epi), (m, n, k, epi)
 
 
 def test_gemm_epilogues(env):
@@ -729,7 +733,7 @@ def test_residual_epilogue_on_a_small_grid_goes_through_split_k(env):
     sums of the K ranges are added in a different order)."""
     torch.manual_seed(47)
     dev = env.device
-    for (m, n, k) in ([(1088, 4096, 11008), (577, 1024, 4096)] if env.big else [(200, 264, 2048)]):
+    for (m, n, k) in ([(1088, 4096, 11008), (577, 1024, 4096)] if env.big else [(200, 264, 4096)]):
         x = torch.randn(m, k).bfloat16().to(dev)
         w = (torch.randn(n, k) * 0.05).bfloat16().to(dev)
         r = torch.randn(m, n).bfloat16().to(dev)

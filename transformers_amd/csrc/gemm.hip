@@ -26,11 +26,13 @@
 //     wave's tile in LDS and writes full row segments (bias / activation / residual / accumulate fused there);
 //   * workgroup ids are remapped XCD-aware (8 XCDs, private L2s): each XCD owns a contiguous chunk of a grouped
 //     (8 M-tiles wide) tile order, so concurrently resident tiles share A/B panels in L2 (84.6 % hits measured).
-// Two kernels (profiles/r01_gemm_variants.md has the measurements that led here):
+// Three kernels (profiles/r01_gemm_variants.md has the measurements that led to the first two):
 //   gemm_fl_kernel  4 waves x (128 x 128), one wave per SIMD, 512 registers, 64-deep "full-line" stages: every
 //                   layout when K % 64 == 0 (all Llama / BERT / CLIP / GPT-2 products, forward and backward)
 //   gemm_pp_kernel  8 waves, 2 groups one phase apart (ping-pong), 32-deep stages: any K (ragged token counts in
 //                   dW, odd hidden sizes)
+//   gemm_sm_kernel  128 x 128 tile, 4 waves x (64 x 64), two workgroups per CU: forward products whose 256 x 256 grid
+//                   cannot spread over the GPU (a CLIP tower's 577 tokens)
 #include <stdlib.h>
 
 #include "common.h"
@@ -784,6 +786,108 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   }
 }
 
+// ============================================================================================ small tile
+// 128 x 128 tile for grids the 256 x 256 tile cannot spread over the GPU: a CLIP-L tower runs its 577 tokens through
+// projections of 1024 .. 4096 features -- 12 .. 48 workgroups of 256 x 256 on 256 CUs, and the bias / activation
+// epilogues rule split-K out (8 ms of a 29 ms LLaVA-1.5-7B forward for 0.9 TFLOP, profiles/r03d_llava_kernel_stats.csv).
+// Forward layout only (A [M,K] and B [N,K] row-major), K % 64 == 0.  4 waves x (64 x 64) on v_mfma_f32_32x32x16 ("swapped",
+// accumulator layout of gemm_epilogue), 64-deep stages of 16 KiB per operand, double-buffered: 64 KiB, so two workgroups
+// share a CU and one's operand latency, hand-off and epilogue hide behind the other's MFMAs -- a kernel for problems
+// whose K loops are too short to amortise a deep pipeline.  Per stage and wave: 8 LDS-DMA pieces (per-lane row
+// pointers are loop invariants, rows past M / N clamped to the last valid one), 16 fragment reads, 16 MFMAs; one barrier
+// per stage.  LDS image of an operand stage = gemm_fl_kernel's row-major one: row r at r*128, 16-byte chunk c at slot
+// c ^ ((r>>1)&7) (swizzle on the LDS-DMA source address, undone on the fragment read, conflict-free both ways).
+constexpr int kSmTile = 128;
+constexpr int kSmThreads = 256;
+constexpr unsigned kSmOperand = (unsigned)kSmTile * kXK * 2u;  // 16 KiB
+constexpr unsigned kSmStage = 2u * kSmOperand;                 // A + B
+constexpr int kSmSmem = 2 * (int)kSmStage;                     // 64 KiB (covers the epilogue staging: 4 x 64 x 144 B)
+constexpr unsigned kSmStageWave = 64u * (64u * 2u + 16u);
+// grids of at most this many 256 x 256 tiles take the small tile (host dispatch): ahead of the 256 x 256 kernel up to 128
+// tiles (37 vs 42 us at 128, 21 vs 37 at 32), behind it from 192 on (57 vs 46 us) -- profiles/r03q_gemm_sm_ab.jsonl
+constexpr int kSmMaxBigTiles = 128;
+
+template <typename T, int EPI, int ACT>
+__global__ __launch_bounds__(kSmThreads, 2) void gemm_sm_kernel(GemmArgs g) {
+  TAMD_DYN_SMEM(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id_uniform();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  int tile_m, tile_n;
+  gemm_tile_of_block(g, (int)blockIdx.x, &tile_m, &tile_n);
+  const int64_t m0 = (int64_t)tile_m * kSmTile, n0 = (int64_t)tile_n * kSmTile;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+
+  f32x16 acc[2][2];  // [ni][mi]
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
+
+  // this wave's 4 + 4 pieces of an operand stage: piece i = rows (wave*4+i)*8 .. +7, lane -> (row = lane>>3, LDS slot =
+  // lane&7 holding chunk slot ^ ((row>>1)&7)); the stage-to-stage step is +128 bytes
+  const char* pa[4];
+  const char* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int64_t ra = (m0 + r < g.M) ? m0 + r : g.M - 1, rb = (n0 + r < g.N) ? n0 + r : g.N - 1;
+    pa[i] = reinterpret_cast<const char*>(A + ra * g.lda + c * 8);
+    pb[i] = reinterpret_cast<const char*>(B + rb * g.ldb + c * 8);
+  }
+  auto issue = [&](int st, unsigned buf_off) {
+    const int64_t kb = (int64_t)st * (kXK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(pa[i] + kb, smem, buf_off + (unsigned)(wave * 4 + i) * 1024u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(pb[i] + kb, smem, buf_off + kSmOperand + (unsigned)(wave * 4 + i) * 1024u);
+  };
+  // fragment offsets of this lane inside an operand stage (rows wm/wn * 64 + blk * 32 + l31; k-step ks adds chunk 2*ks)
+  unsigned fa[2], fb[2];
+  const unsigned swz = (unsigned)((l31 >> 1) & 7);  // ((row >> 1) & 7) of every row this lane reads (block bases are multiples of 32)
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    fa[blk] = (unsigned)(wm * 64 + blk * 32 + l31) * 128u;
+    fb[blk] = kSmOperand + (unsigned)(wn * 64 + blk * 32 + l31) * 128u;
+  }
+  const int nst = (int)(g.K / kXK);
+  issue(0, 0u);
+  for (int st = 0; st < nst; ++st) {
+    const unsigned cur = (unsigned)(st & 1) * kSmStage;
+    wait_vmcnt0();   // this wave's pieces of stage st have landed ...
+    raw_barrier();   // ... everyone's have, and everyone is done reading the other buffer (stage st-1)
+    if (st + 1 < nst) issue(st + 1, cur ^ kSmStage);
+    // fragments of k-step ks+1 are requested before the MFMAs of k-step ks issue (two register sets)
+    u32x4 xa[2][2], wb[2][2];
+    auto frags = [&](int ks, int set) {
+      const unsigned ch = (((unsigned)(ks * 2 + hi)) ^ swz) * 16u;
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        xa[set][blk] = lds_read16(smem, cur + fa[blk] + ch);
+        wb[set][blk] = lds_read16(smem, cur + fb[blk] + ch);
+      }
+    };
+    frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) frags(ks + 1, (ks + 1) & 1);
+      sched_fence();
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = mfma32<T>(wb[ks & 1][ni], xa[ks & 1][mi], acc[ni][mi]);
+      sched_fence();
+    }
+  }
+  block_sync();  // every wave is past its fragment reads: the staging regions overlay the operand buffers
+  gemm_epilogue<T, EPI, ACT, 2, 2>(g, acc, smem, (unsigned)wave * kSmStageWave, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
 // out[m][n] = round(sum_s ws[s][m][n] (+ out[m][n] if ACCUM)): 4 columns per thread (16-byte reads, 8-byte stores)
 template <typename T, bool ACCUM>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
@@ -933,6 +1037,19 @@ static int gemm_fl_launch(const GemmArgs& g, int flags, int epilogue, int act, h
   return gemm_fl_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
+// the 128 x 128 kernel (row-major operands, K % 64 == 0): tiles_m / tiles_n re-counted for its tile
+template <typename T>
+static int gemm_sm_launch(GemmArgs g, int epilogue, int act, hipStream_t s) {
+  g.tiles_m = (int)ceil_div(g.M, kSmTile);
+  g.tiles_n = (int)ceil_div(g.N, kSmTile);
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kSmThreads);
+#define TAMD_G(E_, A_)                                                                    \
+  hipLaunchKernelGGL((gemm_sm_kernel<T, E_, A_>), grid, block, (size_t)kSmSmem, s, g); \
+  return launch_status();
+  TAMD_EPI_SWITCH(TAMD_G)
+#undef TAMD_G
+}
+
 }  // namespace tamd
 
 using namespace tamd;
@@ -1004,11 +1121,15 @@ extern "C" int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M,
 // q|k|v projection: 384 tiles = 1.5 rounds of 256 CUs, 25 % of the machine idle) is cut in 2..4 when the rounds saved
 // outweigh writing and re-reading the fp32 partial tiles:
 //     cost(s) = ceil(tiles * s / 256) / s * stages * 1.4 us  +  (s > 1) * s * M * N * 8 B / 4 TB/s   (s = 1..4)
-static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int epilogue, int* stages_per_split) {
+//     (forward products -- both operands row-major -- of fewer than 64 stages are not split: the 128 x 128 kernel spreads them
+//     over the GPU without partial tiles, 20-37 us against 25-50 for K = 2048 over 8 .. 128 tiles; from 64 stages on
+//     split-K wins, 58 vs 65 us at K = 4096 and 105 vs 158 at 11008: profiles/r03q_gemm_sm_ab.jsonl)
+static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int flags, int epilogue, int* stages_per_split) {
   *stages_per_split = 0;
   if (K % kXK != 0 || (N % 4) != 0 || (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM)) return 1;
   const int64_t tiles = ceil_div(M, kBM) * ceil_div(N, kBN), nst = K / kXK;
   if (nst < 32) return 1;
+  if ((flags & (TAMD_GEMM_A_KM | TAMD_GEMM_B_KN)) == 0 && tiles <= kSmMaxBigTiles && nst < 64) return 1;
   int64_t s = 1;
   if (tiles <= 128) {
     s = 256 / tiles;
@@ -1028,9 +1149,8 @@ static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int epilogue, int
 }
 
 extern "C" size_t tamd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags, int epilogue) {
-  (void)flags;
   int sps;
-  const int splits = gemm_choose_splits(M, N, K, epilogue, &sps);
+  const int splits = gemm_choose_splits(M, N, K, flags, epilogue, &sps);
   return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
@@ -1062,19 +1182,25 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
   // environment or a TAMD_GEMM_SCHED_* hint in `flags` forces one (A/B measurements, tests).
   static const int forced = [] {
     const char* e = getenv("TAMD_GEMM");
-    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : 0));
+    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 's' ? 2 : 0)));
   }();
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
   if (sched != 1 && workspace != nullptr) {
     int sps;
-    const int splits = gemm_choose_splits(M, N, K, epilogue, &sps);
+    const int splits = gemm_choose_splits(M, N, K, flags, epilogue, &sps);
     if (splits > 1 && workspace_bytes >= (size_t)splits * (size_t)M * (size_t)N * sizeof(float) && aligned16(workspace)) {
       g.ws = reinterpret_cast<float*>(workspace);
       g.splits = splits;
       g.stages_per_split = sps;
       TAMD_DISPATCH_HALF(dtype, return (gemm_fl_splitk_launch<T>(g, flags, epilogue, TAMD_STREAM(stream))));
     }
+  }
+  // 128 x 128 tiles when the 256 x 256 grid would leave most of the GPU idle (and split-K, above, did not take the
+  // problem: bias / activation / residual epilogues, short K): row-major operands only.  Threshold from the A/B of the two
+  // kernels over tile counts, profiles/r03q_gemm_sm_ab.jsonl
+  if (K % kXK == 0 && flags == 0 && (sched == 2 || (sched == 0 && (int64_t)g.tiles_m * g.tiles_n <= kSmMaxBigTiles))) {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_sm_launch<T>(g, epilogue, act, TAMD_STREAM(stream))));
   }
   if (K % kXK == 0 && sched != 1) {
     TAMD_DISPATCH_HALF(dtype, return (gemm_fl_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));

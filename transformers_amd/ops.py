@@ -213,7 +213,7 @@ def gemm_supported(m, n, k, dtype) -> bool:
     return dtype in (torch.bfloat16, torch.float16) and k % 8 == 0 and n % 8 == 0 and m > 0
 
 
-def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int) -> int:
+def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int, flags: int = 0) -> int:
     """Host-side mirror of tamd_gemm_workspace_bytes (csrc/gemm.hip gemm_choose_splits): one ctypes round trip per
     GEMM is ~10 us, which small-model steps (hundreds of 30-us kernels) cannot hide.  tests/test_kernels.py keeps the
     two in step."""
@@ -221,6 +221,8 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int) -> int:
         return 0
     tiles, nst = -(-m // 256) * -(-n // 256), k // 64
     if nst < 32:
+        return 0
+    if (flags & 3) == 0 and tiles <= 128 and nst < 64:  # forward product, short K: the 128 x 128 kernel, no split
         return 0
     s = 1
     if tiles <= 128:
@@ -237,10 +239,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int) -> int:
     return -(-nst // sps) * m * n * 4
 
 
-GEMM_SCHED = {None: 0, "pp": 1 << 8, "fl": 3 << 8, "fl_persist": 4 << 8, "fl_persist_sync": 5 << 8}  # include/tamd.h
-
-
-GEMM_SCHED = {None: 0, "pp": 1, "fl": 3}  # TAMD_GEMM_SCHED_* >> 8 (include/tamd.h)
+GEMM_SCHED = {None: 0, "pp": 1, "sm": 2, "fl": 3}  # TAMD_GEMM_SCHED_* >> 8 (include/tamd.h)
 
 
 def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None,
