@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 6
+#define TAMD_ABI_VERSION 7
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -114,10 +114,14 @@ int tamd_layernorm_dropout_bwd(const void* dy, const void* h, const void* w, con
  * projection output: q heads then k heads), with the reference's intermediate roundings:
  *   out = round(round(x*cos) + round(rotate_half(x)*sin)).
  * cos/sin: [cos_batch, seq, head_dim] in `dtype` (cos_batch is 1 or tokens/seq).
- * conj != 0 applies the transposed rotation (the backward, SURVEY §8a "Rope"). */
+ * conj != 0 applies the transposed rotation (the backward, SURVEY §8a "Rope").
+ * ABI 7: the first `q_heads` heads (the query heads) are multiplied by `q_scale` BEFORE the final rounding,
+ *   out = round((round(x*cos) + round(rotate_half(x)*sin)) * q_scale)
+ * -- one rounding, like the reference's own; with q_scale = softmax scale * log2(e) they are the pre-scaled queries of
+ * tamd_attn_params.q_prescaled.  q_heads = 0 (or q_scale = 1): the reference's bits.  Forward rotation only. */
 int tamd_rope_inplace(void* x, const void* cos, const void* sin, int64_t tokens, int64_t seq, int64_t row_stride,
-                      int64_t nheads, int64_t head_dim, int64_t cos_batch, int conj, int dtype,
-                      tamd_stream_t stream);
+                      int64_t nheads, int64_t head_dim, int64_t cos_batch, int conj, int64_t q_heads, float q_scale,
+                      int dtype, tamd_stream_t stream);
 
 /* ------------------------------------------------------------------ embedding */
 
@@ -293,6 +297,12 @@ struct tamd_attn_params {
    *   plane 1  k_end[b, k]   = index of the last token of key k's sequence
    * key k is visible to query q iff q_start[b,q] <= k <= q (equivalently k <= q <= k_end[b,k]). */
   const int32_t* q_start;
+  /* ABI 7.  The kernels take the scores in the exp2 domain: they multiply their resident operand by scale*log2(e) and
+   * round it again to the storage dtype (0).  A producer that rounds q once anyway can apply the factor before its own
+   * rounding (tamd_rope_inplace's q_scale): q_prescaled = 1 says q already carries scale*log2(e) -- same speed, no second
+   * rounding.  `scale` stays the softmax scale of the UNSCALED q; the backward's dq / dk are gradients with respect to
+   * the unscaled q and to k. */
+  int32_t q_prescaled;
 };
 int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream);
 

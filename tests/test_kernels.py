@@ -406,6 +406,84 @@ def ref_attention(q, k, v, scale, causal, key_valid, keep=None, drop_p=0.0):
     return (pr @ vf).permute(0, 2, 1, 3)
 
 
+def test_attention_takes_prescaled_queries_from_the_rotary_kernel(env):
+    """ABI 7 (include/tamd.h): tamd_rope_inplace multiplies the query heads by scale*log2(e) BEFORE its one rounding, and
+    the attention kernels, told so (q_prescaled), skip their own scale-and-re-round of the resident operand.  Checked
+    through the C ABI: the scaled rotary kernel's bits; forward and backward of both forms against the fp32 model (rotary
+    embedding and eager attention in fp32); the pre-scaled form is the more accurate one (no second rounding of q)."""
+    import ctypes
+    from transformers_amd import _cabi
+    be = ops.backend()
+    lib, dev = be.lib, env.device
+    torch.manual_seed(61)
+    b, s, hq, hkv, d = (2, 1024, 8, 2, 128) if env.big else (1, 200, 4, 2, 128)
+    row = (hq + 2 * hkv) * d
+    qkv = torch.randn(b, s, row).bfloat16().to(dev)
+    inv = 1.0 / (500000.0 ** (torch.arange(0, d, 2).float() / d))
+    fr = torch.arange(s).float()[:, None] * inv[None]
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos().bfloat16().to(dev).contiguous(), emb.sin().bfloat16().to(dev).contiguous()
+    scale = 1 / math.sqrt(d)
+    c = scale * 1.4426950408889634
+    plain, scaled = qkv.clone(), qkv.clone()
+    st = be.stream(qkv)
+    stream = ctypes.c_void_p(st) if st else None
+    for buf, qh, qs in ((plain, 0, 1.0), (scaled, hq, c)):
+        lib.check(lib.tamd_rope_inplace(buf.data_ptr(), cos.data_ptr(), sin.data_ptr(), b * s, s, row, hq + hkv, d, 1, 0,
+                                        qh, qs, _cabi.TAMD_BF16, stream), "rope")
+    # the scaled query heads: round((round(x cos) + round(rot(x) sin)) * c); key heads and values as before
+    x = qkv[..., :hq * d].view(b, s, hq, d).float()
+    rot = torch.cat((-x[..., d // 2:], x[..., :d // 2]), -1)
+    cs, sn = cos.float()[None, :, None], sin.float()[None, :, None]
+    want = (((x * cs).bfloat16().float() + (rot * sn).bfloat16().float()) * torch.tensor(c, dtype=torch.float32)).bfloat16()
+    assert torch.equal(scaled[..., :hq * d].view(b, s, hq, d), want)
+    assert torch.equal(scaled[..., hq * d:], plain[..., hq * d:])
+
+    def views(buf):
+        return (buf[..., :hq * d].view(b, s, hq, d), buf[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d),
+                buf[..., (hq + hkv) * d:].view(b, s, hkv, d))
+
+    do = torch.randn(b, s, hq, d).bfloat16().to(dev)
+    # the yardstick is the fp32 model: the rotary embedding WITHOUT roundings, then fp32 eager attention (against the
+    # reference's rounded q the pre-scaled form would count two roundings -- its own and the yardstick's -- the
+    # kernel-scaled form one)
+    xk = qkv[..., hq * d:(hq + hkv) * d].view(b, s, hkv, d).float()
+    rotk = torch.cat((-xk[..., d // 2:], xk[..., :d // 2]), -1)
+    qr = (x * cs + rot * sn).requires_grad_(True)
+    kr = (xk * cs + rotk * sn).requires_grad_(True)
+    vr = views(plain)[2].detach().clone().float().requires_grad_(True)
+    ref = ref_attention(qr, kr, vr, scale, True, None)
+    ref.backward(do.float())
+    errs = {}
+    for tag, buf, flag in (("kernel-scaled", plain, 0), ("pre-scaled", scaled, 1)):
+        q, k, v = views(buf)
+        o = torch.empty(b, s, hq, d, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(b, hq, s, dtype=torch.float32, device=dev)
+        grads = torch.zeros_like(buf)
+        dq, dk, dv = views(grads)
+        delta = torch.empty(2, b, hq, s, dtype=torch.float32, device=dev)
+        bp = _cabi.AttnBwdParams()
+        fp = bp.fwd
+        fp.q, fp.k, fp.v, fp.o, fp.lse, fp.key_valid, fp.q_start = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), None, None
+        fp.batch, fp.seq_q, fp.heads_q, fp.head_dim, fp.seq_k, fp.heads_kv = b, s, hq, d, s, hkv
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+            setattr(fp, f"{name}_stride_b", t.stride(0))
+            setattr(fp, f"{name}_stride_s", t.stride(1))
+            setattr(fp, f"{name}_stride_h", t.stride(2))
+        fp.scale, fp.causal, fp.dtype, fp.dropout_p, fp.dropout_seed, fp.q_prescaled = scale, 1, _cabi.TAMD_BF16, 0.0, 0, flag
+        bp.dout, bp.dq, bp.dk, bp.dv, bp.delta = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
+        bp.rope_cos, bp.rope_sin, bp.rope_cos_batch = None, None, 1
+        lib.check(lib.tamd_attn_fwd(ctypes.byref(fp), stream), "fwd")
+        lib.check(lib.tamd_attn_bwd(ctypes.byref(bp), stream), "bwd")
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        errs[tag] = (rel_err(o, ref), rel_err(dq, qr.grad), rel_err(dk, kr.grad), rel_err(dv, vr.grad))
+        assert errs[tag][0] < 0.0052 and max(errs[tag][1:]) < 0.0065, (tag, errs[tag])   # (gradients are w.r.t. the UNSCALED q)
+    # measured on the CPU model: O 0.00316 -> 0.00288, dq 0.00403 -> 0.00385, dk 0.00423 -> 0.00387, dv 0.00373 -> 0.00320
+    assert all(a <= b_ for a, b_ in zip(errs["pre-scaled"], errs["kernel-scaled"])), errs
+    assert errs["pre-scaled"][0] < 0.96 * errs["kernel-scaled"][0], errs  # one rounding of q less
+
+
 ATTN_CASES_SMALL = [
     # b, sq, sk, hq, hkv, d, causal, mask
     (1, 128, 128, 2, 1, 128, True, False),

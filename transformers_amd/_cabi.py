@@ -14,7 +14,7 @@ TAMD_BF16, TAMD_F16, TAMD_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 GEMM_A_KM, GEMM_B_KN = 1, 2
 EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_BIAS_ACT, EPI_ACCUM = 0, 1, 2, 3, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 P = c_void_p
 I64 = c_int64
@@ -29,7 +29,7 @@ class AttnParams(Structure):
         ("v_stride_b", I64), ("v_stride_s", I64), ("v_stride_h", I64),
         ("o_stride_b", I64), ("o_stride_s", I64), ("o_stride_h", I64),
         ("scale", c_float), ("causal", c_int), ("dtype", c_int),
-        ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint64), ("q_start", P),
+        ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint64), ("q_start", P), ("q_prescaled", ctypes.c_int32),
     ]
 
 
@@ -50,7 +50,7 @@ SIGNATURES = {
     "tamd_layernorm_dropout_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_float, ctypes.c_uint64, c_int, P]),
     "tamd_layernorm_dropout_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_float, ctypes.c_uint64,
                                            c_int, P]),
-    "tamd_rope_inplace": (c_int, [P, P, P, I64, I64, I64, I64, I64, I64, c_int, c_int, P]),
+    "tamd_rope_inplace": (c_int, [P, P, P, I64, I64, I64, I64, I64, I64, c_int, I64, c_float, c_int, P]),
     "tamd_embedding_fwd": (c_int, [P, P, P, I64, I64, I64, P, c_int, P]),
     "tamd_embedding_bwd_workspace_bytes": (c_size_t, [I64, I64]),
     "tamd_embedding_bwd": (c_int, [P, P, P, P, P, c_size_t, I64, I64, I64, I64, c_int, P]),
@@ -98,7 +98,7 @@ class TamdError(RuntimeError):
 class TamdLib:
     """A loaded C-ABI library with typed entry points (`lib.tamd_gemm(...)`)."""
 
-    def __init__(self, path, diag: bool = False):
+    def __init__(self, path, diag: bool = False, accept_abi=None):
         self.path = str(path)
         self._dll = ctypes.CDLL(self.path)
         missing = []
@@ -115,7 +115,7 @@ class TamdLib:
         if missing:
             raise TamdError(f"{self.path} does not export: {', '.join(missing)}")
         ver = self.tamd_abi_version()
-        if ver != ABI_VERSION:
+        if ver != ABI_VERSION and ver not in (accept_abi or ()):  # (tools/attn_lib_ab.py loads a build of an earlier ABI)
             raise TamdError(f"{self.path}: ABI version {ver}, expected {ABI_VERSION}")
 
     def check(self, code: int, what: str) -> None:

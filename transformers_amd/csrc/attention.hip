@@ -117,6 +117,7 @@ AttnArgs make_args(const tamd_attn_params* p) {
   a.seed_hi = (unsigned)(p->dropout_seed >> 32);
   a.nqt = (int)ceil_div(p->seq_q, kQB);
   a.xcd_map = ((p->batch * p->heads_kv) % 8 == 0) ? 1 : 0;
+  a.q_prescaled = p->q_prescaled != 0;
 #ifdef TAMD_DIAG
   a.trace = g_attn_trace;
 #else

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   }
   if (!(DBG & 1)) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[ks] = scale_frag<T, true>(kf[ks], a.scale_log2);  // S leaves the MFMAs in the exp2 domain
+    // S leaves the MFMAs in the exp2 domain: the factor rides on K here, unless the Q tiles already carry it (q_prescaled)
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = scale_frag<T, true>(kf[ks], a.scale_log2, !a.q_prescaled);
   }
   constexpr bool FOLD_DELTA = !DROP;  // dP's chain starts from -delta (dropout: (dP*keep - delta) is not linear in dP)
   bool key_ok = krow < a.seq_k;
@@ -530,7 +531,9 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   T* dK = reinterpret_cast<T*>(g.dk) + (int64_t)b * a.ksb + (int64_t)hkv * a.ksh;
   T* dV = reinterpret_cast<T*>(g.dv) + (int64_t)b * a.vsb + (int64_t)hkv * a.vsh;
   const unsigned st = (unsigned)wave * (32u * OROWB);
-  store_rows_via_lds<T, D>(dkacc, g.scale, smem, st, dK, a.kss, kw0, a.seq_k, lane, reinterpret_cast<const T*>(g.rope_cos),
+  // dK = scale * dS^T Q; with pre-scaled queries Q' = Q * scale * log2(e): dK = dS^T Q' / log2(e)
+  const float dk_mul = a.q_prescaled ? g.scale / a.scale_log2 : g.scale;
+  store_rows_via_lds<T, D>(dkacc, dk_mul, smem, st, dK, a.kss, kw0, a.seq_k, lane, reinterpret_cast<const T*>(g.rope_cos),
                            reinterpret_cast<const T*>(g.rope_sin),
                            (g.rope_cos_batch == 1 ? 0 : (int64_t)b * a.seq_k) + kw0);  // (rotary: key position = row index)
   wave_lockstep_point();

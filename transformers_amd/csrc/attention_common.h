@@ -37,6 +37,7 @@ struct AttnArgs {
   unsigned seed_lo, seed_hi;
   int nqt;           // query tiles per (b, h)
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
+  int q_prescaled;   // 1: q already carries scale*log2(e) (include/tamd.h): no operand is scaled and re-rounded here
   unsigned long long* trace;  // diagnostic build: per-phase shader-clock sums of workgroup 0 (tamd_attn_set_trace), else null
 };
 
@@ -253,13 +254,17 @@ __device__ __forceinline__ void pack_c_to_b(const float* p, u32x4* out2) {
 // The attention loops are bound by instruction issue (4-5 instructions hide beside an MFMA), so an
 // instruction less per element is time.  Cost: one more rounding of the operand to the storage dtype (relative 2^-9 in
 // bf16; the reference's own bf16 path rounds S itself to bf16).
+// `apply` (wave-uniform): false when the producer delivered the operand pre-scaled (AttnArgs::q_prescaled)
 template <typename T, bool IN_AGPR = false>  // IN_AGPR: the one-wave-per-SIMD kernels keep their resident operands in AGPRs
-__device__ __forceinline__ u32x4 scale_frag(u32x4 f, float c) {
-  float x[8];
-  unpack16<T>(f, x);
+__device__ __forceinline__ u32x4 scale_frag(u32x4 f, float c, bool apply = true) {
+  u32x4 r = f;
+  if (apply) {
+    float x[8];
+    unpack16<T>(f, x);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] *= c;
-  u32x4 r = pack16<T>(x);
+    for (int e = 0; e < 8; ++e) x[e] *= c;
+    r = pack16<T>(x);
+  }
 #if defined(__HIP_DEVICE_COMPILE__)
   // one 128-bit value from here on, born in the register file its MFMAs read it from (left as four dwords, or pinned in
   // VGPRs, the dK/dV kernel's tuples were re-assembled by 28 v_accvgpr_mov per tile in front of the MFMAs)

@@ -17,7 +17,7 @@ namespace tamd {
 template <typename T>
 __global__ void rope_kernel(T* __restrict__ x, const T* __restrict__ cosp, const T* __restrict__ sinp,
                             int64_t tokens, int64_t seq, int64_t row_stride, int nheads, int head_dim,
-                            int64_t cos_batch, int conj) {
+                            int64_t cos_batch, int conj, int q_heads, float q_scale) {
   constexpr int VE = vec16<T>::N;
   const int half = head_dim / 2;
   const int vec_per_head = half / VE;  // vectors in the first half of a head
@@ -33,6 +33,9 @@ __global__ void rope_kernel(T* __restrict__ x, const T* __restrict__ cosp, const
     T* p2 = p1 + half;
     const T* c1 = cosp + crow * head_dim + vi * VE;
     const T* s1 = sinp + crow * head_dim + vi * VE;
+    // query heads can leave multiplied by scale*log2(e), applied to the fp32 sum of the two rounded products BEFORE the one
+    // rounding to the storage dtype (include/tamd.h: the pre-scaled q of the attention kernels); 1.0 is exact
+    const float hs = (hd < q_heads) ? q_scale : 1.f;
     float a[VE], b[VE], ca[VE], cb[VE], sa[VE], sb[VE], oa[VE], ob[VE];
     unpack16<T>(ld16(p1), a);
     unpack16<T>(ld16(p2), b);
@@ -43,8 +46,8 @@ __global__ void rope_kernel(T* __restrict__ x, const T* __restrict__ cosp, const
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
       if (!conj) {
-        oa[i] = round_through<T>(a[i] * ca[i]) + round_through<T>(-b[i] * sa[i]);
-        ob[i] = round_through<T>(b[i] * cb[i]) + round_through<T>(a[i] * sb[i]);
+        oa[i] = (round_through<T>(a[i] * ca[i]) + round_through<T>(-b[i] * sa[i])) * hs;
+        ob[i] = (round_through<T>(b[i] * cb[i]) + round_through<T>(a[i] * sb[i])) * hs;
       } else {
         // y = x*cos + R(x)*sin with R(x)=[-x2, x1]  =>  dx1 = dy1*cos1 + dy2*sin2 ; dx2 = dy2*cos2 - dy1*sin1
         oa[i] = round_through<T>(a[i] * ca[i]) + round_through<T>(b[i] * sb[i]);
@@ -576,9 +579,10 @@ using namespace tamd;
 extern "C" {
 
 int tamd_rope_inplace(void* x, const void* cos, const void* sin, int64_t tokens, int64_t seq, int64_t row_stride,
-                      int64_t nheads, int64_t head_dim, int64_t cos_batch, int conj, int dtype,
-                      tamd_stream_t stream) {
+                      int64_t nheads, int64_t head_dim, int64_t cos_batch, int conj, int64_t q_heads, float q_scale,
+                      int dtype, tamd_stream_t stream) {
   if (!x || !cos || !sin) return TAMD_E_NULL;
+  if (q_heads < 0 || q_heads > nheads || (conj && q_heads > 0 && q_scale != 1.f)) return TAMD_E_ARG;
   if (tokens <= 0 || nheads <= 0) return TAMD_OK;
   if (seq <= 0 || tokens % seq != 0) return TAMD_E_SHAPE;
   if (cos_batch != 1 && cos_batch != tokens / seq) return TAMD_E_SHAPE;
@@ -589,7 +593,7 @@ int tamd_rope_inplace(void* x, const void* cos, const void* sin, int64_t tokens,
     const int64_t total = tokens * nheads * (head_dim / 2 / VE);
     hipLaunchKernelGGL((rope_kernel<T>), dim3(stream_grid(total, 256)), dim3(256), 0, TAMD_STREAM(stream), (T*)x,
                        (const T*)cos, (const T*)sin, tokens, seq, row_stride, (int)nheads, (int)head_dim, cos_batch,
-                       conj);
+                       conj, (int)q_heads, q_scale);
   });
   return launch_status();
 }

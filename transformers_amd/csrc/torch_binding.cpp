@@ -259,9 +259,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_bwd(const Tensor&
   return {dx.view(h.sizes()), dxd.view(h.sizes()), dw, db};
 }
 
-// in-place rotary on the first `nheads` heads of every row of x2d [tokens, row_stride]
+// in-place rotary on the first `nheads` heads of every row of x2d [tokens, row_stride]; the first `q_heads` of them leave
+// multiplied by `q_scale` before their one rounding (include/tamd.h: the pre-scaled queries of the attention kernels)
 void k_rope_(const Tensor& x2d, const Tensor& cos_, const Tensor& sin_, int64_t seq, int64_t nheads, int64_t head_dim,
-             bool conj) {
+             bool conj, int64_t q_heads = 0, double q_scale = 1.0) {
   Launch L({&x2d, &cos_, &sin_});
   TORCH_CHECK(x2d.dim() == 2 && x2d.stride(1) == 1, "tamd: rope_ takes a row-major [tokens, row] matrix");
   Tensor cos = contig(cos_), sin = contig(sin_);
@@ -271,7 +272,7 @@ void k_rope_(const Tensor& x2d, const Tensor& cos_, const Tensor& sin_, int64_t 
   }
   const int64_t cos_batch = cos.dim() == 3 ? cos.size(0) : 1;
   check(api().tamd_rope_inplace(mptr(x2d), ptr(cos), ptr(sin), x2d.size(0), seq, x2d.stride(0), nheads, head_dim,
-                                cos_batch, (int)conj, code_of(x2d), L.stream),
+                                cos_batch, (int)conj, q_heads, (float)q_scale, code_of(x2d), L.stream),
         "tamd_rope_inplace");
 }
 
@@ -564,7 +565,7 @@ Tensor k_gemm_rope(const Tensor& x2, const Tensor& wqkv, const Tensor& cos_, con
 // ---- attention
 void fill_attn_params(tamd_attn_params* ap, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
                       const Tensor& lse, const Tensor& key_valid, double scale, bool causal, double dropout_p, int64_t seed,
-                      const Tensor& q_start) {
+                      const Tensor& q_start, bool q_prescaled = false) {
   ap->q = ptr(q);
   ap->k = ptr(k);
   ap->v = ptr(v);
@@ -589,6 +590,7 @@ void fill_attn_params(tamd_attn_params* ap, const Tensor& q, const Tensor& k, co
   ap->dropout_p = (float)dropout_p;
   ap->dropout_seed = (uint64_t)seed;
   ap->q_start = (const int32_t*)ptr(q_start);
+  ap->q_prescaled = q_prescaled ? 1 : 0;
 }
 
 // [batch, seq_k] key-validity plane (1 = attend): the kernels index it as key_valid[b * seq_k + key]
@@ -611,14 +613,14 @@ Tensor checked_q_start(const OptTensor& q_start, const Tensor& q, bool causal) {
 // q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32 or undefined
 std::tuple<Tensor, Tensor> k_attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale, bool causal,
                                       const OptTensor& key_valid_, bool need_lse, double dropout_p, int64_t seed,
-                                      const OptTensor& q_start_) {
+                                      const OptTensor& q_start_, bool q_prescaled = false) {
   Launch L({&q, &k, &v, p(key_valid_)});
   Tensor o = at::empty({q.size(0), q.size(1), q.size(2), q.size(3)}, q.options());
   Tensor lse = need_lse ? f32_like(q, {q.size(0), q.size(2), q.size(1)}) : Tensor();
   Tensor key_valid = checked_key_valid(key_valid_, q, k);
   Tensor q_start = checked_q_start(q_start_, q, causal);
   tamd_attn_params ap;
-  fill_attn_params(&ap, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start);
+  fill_attn_params(&ap, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start, q_prescaled);
   check(api().tamd_attn_fwd(&ap, L.stream), "tamd_attn_fwd");
   return {o, lse};
 }
@@ -629,7 +631,7 @@ std::tuple<Tensor, Tensor, Tensor> k_attn_bwd(const Tensor& q, const Tensor& k, 
                                               const Tensor& lse, const Tensor& dout_, double scale, bool causal,
                                               const OptTensor& key_valid_, Tensor dq, Tensor dk, Tensor dv, double dropout_p,
                                               int64_t seed, const OptTensor& q_start_, const Tensor& rope_cos_,
-                                              const Tensor& rope_sin_) {
+                                              const Tensor& rope_sin_, bool q_prescaled = false) {
   Launch L({&q, &k, &v, &o, &lse, &dout_, p(key_valid_)});
   Tensor dout = dout_;
   if (dout.strides() != o.strides()) dout = o.is_contiguous() ? dout.contiguous() : dout.clone(at::MemoryFormat::Preserve);
@@ -642,9 +644,9 @@ std::tuple<Tensor, Tensor, Tensor> k_attn_bwd(const Tensor& q, const Tensor& k, 
   Tensor q_start = checked_q_start(q_start_, q, causal);
   auto dshape = lse.sizes().vec();
   dshape.insert(dshape.begin(), 2);
-  Tensor delta = at::empty(dshape, lse.options());  // delta | lse*log2(e)
+  Tensor delta = at::empty(dshape, lse.options());  // -delta | -lse*log2(e) (written by the dQ kernel)
   tamd_attn_bwd_params bp;
-  fill_attn_params(&bp.fwd, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start);
+  fill_attn_params(&bp.fwd, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start, q_prescaled);
   bp.dout = ptr(dout);
   bp.dq = mptr(dq);
   bp.dk = mptr(dk);
@@ -941,6 +943,10 @@ bool env_flag(const char* name, bool dflt) {
 const bool kFuseRopeFwd = env_flag("TAMD_FUSE_ROPE_FWD", false);
 const bool kFuseRopeBwd = env_flag("TAMD_FUSE_ROPE_BWD", true);
 const bool kSaveSwigluAct = env_flag("TAMD_SAVE_SWIGLU_ACT", true);
+// the rotary kernel hands the attention kernels queries that already carry scale*log2(e), applied before its one rounding
+// (include/tamd.h q_prescaled; 0: the attention kernels scale and re-round their operand themselves)
+const bool kRopePrescale = env_flag("TAMD_ROPE_PRESCALE", true);
+constexpr double kLog2e = 1.44269504088896340736;
 
 struct Qkv {
   Tensor q, k, v;
@@ -948,6 +954,12 @@ struct Qkv {
 Qkv split_qkv(const Tensor& qkv, int64_t b, int64_t s, int64_t hq, int64_t hkv, int64_t d) {
   return {qkv.narrow(1, 0, hq * d).view({b, s, hq, d}), qkv.narrow(1, hq * d, hkv * d).view({b, s, hkv, d}),
           qkv.narrow(1, (hq + hkv) * d, hkv * d).view({b, s, hkv, d})};
+}
+
+// does the layer's rotary kernel deliver pre-scaled queries?  (not when the rotary embedding rides in the q|k|v GEMM's
+// epilogue, which keeps the reference's bits)
+bool llama_q_prescaled(const Tensor& xn, const Tensor& wqkv, const Tensor& cos, int64_t d) {
+  return kRopePrescale && !(kFuseRopeFwd && gemm_rope_supported(xn, wqkv, cos, d));
 }
 
 using LlamaLayerOut = std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>;
@@ -962,14 +974,15 @@ LlamaLayerOut op_llama_layer(const Tensor& h_in, const Tensor& cos, const Tensor
   Tensor x = contig(h_in).view({t, hd});
   auto [xn, h_unused, rstd1] = k_rmsnorm_fwd(x, w_ln1, eps, {});
   Tensor qkv;
+  const bool q_prescaled = llama_q_prescaled(xn, wqkv, cos, d);  // (the backward re-derives it from the same operands)
   if (kFuseRopeFwd && gemm_rope_supported(xn, wqkv, cos, d)) {
     qkv = k_gemm_rope(xn, wqkv, cos, sin, s, hq + hkv, d);
   } else {
     qkv = gemm_plain(xn, wqkv);
-    k_rope_(qkv, cos, sin, s, hq + hkv, d, false);
+    k_rope_(qkv, cos, sin, s, hq + hkv, d, false, q_prescaled ? hq : 0, q_prescaled ? scale * kLog2e : 1.0);
   }
   Qkv p3 = split_qkv(qkv, b, s, hq, hkv, d);
-  auto [o, lse] = k_attn_fwd(p3.q, p3.k, p3.v, scale, causal, key_valid, train, 0.0, 0, q_start);
+  auto [o, lse] = k_attn_fwd(p3.q, p3.k, p3.v, scale, causal, key_valid, train, 0.0, 0, q_start, q_prescaled);
   Tensor h_mid = gemm_plain(o.view({t, hq * d}), wo, false, false, {}, x, TAMD_EPI_RESIDUAL);
   auto [xn2, h_unused2, rstd2] = k_rmsnorm_fwd(h_mid, w_ln2, eps, {});
   Tensor gu, act;
@@ -1023,7 +1036,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   Qkv f = split_qkv(qkv, b, s, hq, hkv, d), g = split_qkv(d_qkv, b, s, hq, hkv, d);
   const bool fused_rope = kFuseRopeBwd && attn_bwd_rope_supported(f.q, f.k, cos, d);  // the transposed rotary inside the kernels
   k_attn_bwd(f.q, f.k, f.v, o, lse, d_o.view({b, s, hq, d}), scale, causal, key_valid, g.q, g.k, g.v, 0.0, 0, q_start,
-             fused_rope ? cos : Tensor(), fused_rope ? sin : Tensor());
+             fused_rope ? cos : Tensor(), fused_rope ? sin : Tensor(), llama_q_prescaled(xn, wqkv, cos, d));
   d_o = Tensor();
   if (!fused_rope) k_rope_(d_qkv, cos, sin, s, hq + hkv, d, true);
   Tensor d_xn = gemm_plain(d_qkv, wqkv, false, true);
