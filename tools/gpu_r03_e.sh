@@ -3,24 +3,24 @@ exec < /dev/null
 # Round 3, GPU visit 5: validation of HEAD (after the 8-wave attention variant was removed, the varlen kwargs, the re-set
 # gates and the bench defaults): the whole parity suite, smoke, the default bench line (CPU baseline included), rocprofv3
 # kernel stats + FETCH/WRITE PMC passes of the same command, bert-base and LLaVA bench lines.
-# usage: gpurun --timeout 1500 -- bash tools/gpu_r03_e.sh [tag]
+# usage: gpurun --timeout 590 -- bash tools/gpu_r03_e.sh [tag]
 tag=${1:-r03e}
 R=$PWD
 out=$R/gpurun_out
 mkdir -p $out/$tag
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp
-timeout 700 python -m pytest tests -m gpu -q --timeout 600 > $out/${tag}_tests.log 2>&1
+timeout 330 python -m pytest tests -m gpu -q --timeout 300 > $out/${tag}_tests.log 2>&1
 echo "tests exit $?" >> $out/${tag}_tests.log
 cp $out/parity_hip.json $out/${tag}_parity.json 2>/dev/null
 tail -6 $out/${tag}_tests.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.log 2>&1
 echo "smoke exit $?" >> $out/${tag}_smoke.log; tail -4 $out/${tag}_smoke.log
-timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 240 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 echo "bench exit $?"; cut -c1-420 $out/${tag}_bench.json; tail -2 $out/${tag}_bench.err
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag/stats -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_prof_bench.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$tag/fetch -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$tag/write -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag/stats -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/${tag}_prof_bench.log 2>&1
+timeout 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/$tag/fetch -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_fetch.log 2>&1
+timeout 150 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/$tag/write -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_pmc_write.log 2>&1
 cd $R
 python tools/prof_traffic.py $out/$tag $out/${tag} r03 > $out/${tag}_traffic.log 2>&1
 cp $(find $out/$tag/stats -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_kernel_stats.csv 2>/dev/null
