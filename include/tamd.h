@@ -269,8 +269,11 @@ int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const void* cos, 
  * key_valid: optional [batch, seq_k] uint8 padding mask (1 = attend); NULL = no padding.
  * lse [batch, heads_q, seq_q] fp32 (natural-log sum-exp of the scaled scores) is written for
  * the backward; may be NULL for inference.  head_dim in {64, 128}; bf16/f16. */
-/* 32-bit mixing function of the dropout mask (exported so hosts/tests can rebuild the mask). */
+/* 32-bit mixing function of the dropout masks (exported so hosts/tests can rebuild them). */
 uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index);
+/* ABI 7: the 16-bit field that decides attention-dropout element (batch_head = b*heads_q + h, q, k): one hash decides a
+ * 2 x 2 block of the probability matrix (csrc/dropout.h) -- the element is kept iff field >= floor(dropout_p * 65536). */
+uint32_t tamd_attn_dropout_field(uint64_t seed, uint64_t batch_head, uint64_t seq_q, uint64_t seq_k, uint64_t q, uint64_t k);
 struct tamd_attn_params {
   const void* q;
   const void* k;
@@ -287,8 +290,8 @@ struct tamd_attn_params {
   int causal;
   int dtype;
   /* attention dropout (nn.functional.dropout on the probabilities, modeling_llama.py:209, modeling_bert.py:131):
-   * element (b, h, q, k) is kept iff tamd_dropout_hash(seed, ((b*heads_q+h)*seq_q+q)*seq_k+k) >= dropout_p*2^32
-   * and scaled by 1/(1-p); the same counter-based mask is regenerated in the backward.  0 disables. */
+   * element (b, h, q, k) is kept iff tamd_attn_dropout_field(seed, b*heads_q+h, seq_q, seq_k, q, k) >= floor(dropout_p*2^16)
+   * and scaled by 1/(1-p); the same counter-based mask is regenerated in the backward.  0 (or p < 2^-16) disables. */
   float dropout_p;
   uint64_t dropout_seed;
   /* packed sequences (several sequences in one batch row, position_ids restarting: masking_utils.py:728-757,

@@ -568,14 +568,25 @@ def test_attention_dropout_matches_explicit_mask(env):
 
 
 def test_dropout_hash_export_matches_host_mirror(env):
+    """The attention-dropout mask as include/tamd.h defines it (tamd_attn_dropout_field: one hash per 2 x 2 block, 16 bits
+    per element) against the vectorised host mirror, odd sizes included; the 32-bit mix does not collide on a few indices."""
     lib = ops.backend().lib
-    import numpy as np
     seed = 0xDEADBEEFCAFEF00D
+    for (b, h, sq, sk, p) in [(1, 1, 1, 3, 0.5), (2, 3, 5, 7, 0.1), (1, 2, 6, 4, 0.3)]:
+        mask = ops.dropout_keep_mask(seed, b, h, sq, sk, p)
+        thr16 = int(float(torch.tensor(p, dtype=torch.float32)) * 65536.0)
+        for bh in range(b * h):
+            for q in range(sq):
+                for k in range(sk):
+                    f = lib.tamd_attn_dropout_field(seed, bh, sq, sk, q, k)
+                    assert 0 <= f < 65536 and bool(mask.view(b * h, sq, sk)[bh, q, k]) == (f >= thr16), (bh, q, k)
+    big = ops.dropout_keep_mask(seed, 2, 4, 128, 256, 0.25)
+    assert abs(big.float().mean().item() - 0.75) < 0.01          # unbiased at rate p ...
+    for sl in (big[..., 0::2, 0::2], big[..., 1::2, 0::2], big[..., 0::2, 1::2], big[..., 1::2, 1::2]):
+        assert abs(sl.float().mean().item() - 0.75) < 0.02       # ... in each of the four fields of a block
+    a, c = big[..., 0::2, 0::2].float() - 0.75, big[..., 1::2, 1::2].float() - 0.75
+    assert abs((a * c).mean().item()) < 0.01                     # ... which do not move together
     idx = [0, 1, 2, 12345, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 17]
-    thr0 = ops.dropout_keep_mask(seed, 1, 1, 1, 3, 0.5)   # indices 0..2
-    for i in range(3):
-        h = lib.tamd_dropout_hash(seed, i)
-        assert bool(thr0.view(-1)[i]) == (h >= 2 ** 31)
     assert len({lib.tamd_dropout_hash(seed, i) for i in idx}) == len(idx)
 
 

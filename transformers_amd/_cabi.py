@@ -75,6 +75,7 @@ SIGNATURES = {
     "tamd_gemm_swiglu": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_gemm_rope": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),
+    "tamd_attn_dropout_field": (ctypes.c_uint32, [ctypes.c_uint64] * 6),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),
     "tamd_attn_bwd": (c_int, [POINTER(AttnBwdParams), P]),
 }

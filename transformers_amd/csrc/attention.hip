@@ -111,8 +111,9 @@ AttnArgs make_args(const tamd_attn_params* p) {
   a.osh = p->o_stride_h;
   a.scale_log2 = p->scale * 1.44269504088896340736f;
   const double pd = p->dropout_p;
-  a.drop_thr = (pd > 0.0) ? (unsigned)(pd >= 1.0 ? 4294967295.0 : pd * 4294967296.0) : 0u;
-  a.drop_scale = (pd > 0.0 && pd < 1.0) ? (float)(1.0 / (1.0 - pd)) : 1.f;
+  // 16-bit keep threshold (dropout.h: one hash decides a 2 x 2 block of probabilities); a p below 2^-16 is no dropout
+  a.drop_thr = (pd > 0.0) ? (unsigned)(pd >= 1.0 ? 65535.0 : pd * 65536.0) : 0u;
+  a.drop_scale = (a.drop_thr != 0u && pd < 1.0) ? (float)(1.0 / (1.0 - pd)) : 1.f;
   a.seed_lo = (unsigned)p->dropout_seed;
   a.seed_hi = (unsigned)(p->dropout_seed >> 32);
   a.nqt = (int)ceil_div(p->seq_q, kQB);
@@ -139,6 +140,10 @@ extern "C" int tamd_attn_set_trace(void* buf) {
 
 extern "C" uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index) {
   return dropout_hash((unsigned)seed, (unsigned)(seed >> 32), (unsigned)index, (unsigned)(index >> 32));
+}
+extern "C" uint32_t tamd_attn_dropout_field(uint64_t seed, uint64_t batch_head, uint64_t seq_q, uint64_t seq_k, uint64_t q,
+                                            uint64_t k) {
+  return attn_dropout_field((unsigned)seed, (unsigned)(seed >> 32), batch_head, seq_q, seq_k, q, k);
 }
 
 extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream) {

@@ -139,7 +139,12 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   bool key_ok = krow < a.seq_k;
   if (HAS_MASK && a.key_valid != nullptr)
     key_ok = key_ok && a.key_valid[(int64_t)b * a.seq_k + (krow < a.seq_k ? krow : 0)] != 0;
-  const DropCtx drop = {a.drop_thr, a.seed_lo, a.seed_hi, a.drop_scale};
+  const AttnDrop drop = {a.drop_thr, a.seed_lo, a.seed_hi, a.drop_scale, ((unsigned long long)a.seq_q + 1) >> 1,
+                         ((unsigned long long)a.seq_k + 1) >> 1};
+  // lane part of a block index: this lane's key pair + the 2 * hi query pairs its rows sit above the chunk's first one
+  // (rows / keys past the end index blocks of other rows: their probabilities are zero anyway)
+  const unsigned long long drop_lane = (unsigned long long)(krow >> 1) + (unsigned long long)(2 * hi) * drop.csk;
+  const bool drop_kodd = (krow & 1) != 0;  // this lane's key: the first or the second word of each hash
   // PACKED: last query that sees this lane's key, and (wave-uniform) the last one that sees any key of the block
   const int* k_end = PACKED ? a.q_start + (int64_t)a.batch * a.seq_q + (int64_t)b * a.seq_k : nullptr;
   const int kend = PACKED ? k_end[krow < a.seq_k ? krow : a.seq_k - 1] : 0x3fffffff;
@@ -345,6 +350,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     // key visible to local query row r of this tile iff mask_lim <= r (padding / out-of-range keys: never)
     const int mask_lim = key_ok ? (CAUSAL ? krow - (qt0 + off) : -0x40000000) : 0x40000000;
     const int mask_hi = kend - qt0;  // PACKED: last local query row of this tile that belongs to the key's sequence
+    // dropout: block index of (this tile's head, its first query pair, key pair 0) -- wave-uniform
+    const unsigned long long drop_tile = DROP ? drop.row_base((unsigned long long)b * a.heads_q + hcur, (unsigned long long)qt0) : 0ull;
     sched_fence();
 
     f32x16 s[2], dp[2];
@@ -370,6 +377,18 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       }
       float p[4], ds[4];
       const int ql = sub * 32 + 8 * qd + 4 * hi;  // 4 consecutive query rows (r&3)
+      float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+      if (DROP) {  // rows ql + 2j, ql + 2j + 1 share a hash; this lane's key picks the word, the row its half
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // block of query pair (qt0 + ql) / 2 + j: wave-uniform tile base and chunk term, the lane's part added once
+          unsigned w0, w1;
+          drop.words(drop_tile + (unsigned long long)(sub * 16 + 4 * qd + j) * drop.csk + drop_lane, w0, w1);
+          const unsigned w = drop_kodd ? w1 : w0;
+          keep4[2 * j] = drop.keep(w & 0xffffu);
+          keep4[2 * j + 1] = drop.keep(w >> 16);
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = qd * 4 + e;
@@ -381,13 +400,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         else if (!PLAIN)
           x = (mask_lim <= ql + e) ? x : -INFINITY;
         const float pe = fast_exp2(x);  // x = S*scale*log2(e) - lse*log2(e): the chain started from -lse*log2(e)
-        float keep = 1.f;
-        if (DROP) {
-          const int qg = qt0 + ql + e;  // global query row
-          const unsigned long long base =
-              (((unsigned long long)b * a.heads_q + hcur) * a.seq_q + (qg < a.seq_q ? qg : 0)) * (unsigned long long)a.seq_k;
-          keep = drop.factor(base, krow < a.seq_k ? krow : 0);
-        }
+        const float keep = keep4[e];
         p[e] = pe * keep;  // dV uses the dropped probabilities
         ds[e] = FOLD_DELTA ? pe * dp[sub][r] : pe * (dp[sub][r] * keep + u32_as_f32(d4[e]));  // (d4 = -delta)
       }

@@ -32,7 +32,7 @@ struct AttnArgs {
   int batch, heads_q, heads_kv, seq_q, seq_k;
   int64_t qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh;
   float scale_log2;  // scale * log2(e)
-  unsigned drop_thr;  // keep iff hash >= drop_thr (0 = no dropout)
+  unsigned drop_thr;  // keep iff the element's 16-bit hash field >= drop_thr (0 = no dropout); dropout.h AttnDrop
   float drop_scale;   // 1 / (1 - p)
   unsigned seed_lo, seed_hi;
   int nqt;           // query tiles per (b, h)

@@ -810,8 +810,23 @@ def dropout_add_layernorm(x, residual, w, b, eps, dropout_p, seed=None):
 
 
 def hidden_dropout_keep_mask(seed: int, rows: int, cols: int, p: float) -> torch.Tensor:
-    """The keep mask [rows, cols] of `dropout_add_layernorm`, rebuilt on the host (tests / debugging)."""
-    return dropout_keep_mask(seed, 1, 1, rows, cols, p)[0, 0]
+    """The keep mask [rows, cols] (bool) of the hidden-state dropout inside the add + LayerNorm kernels, rebuilt on the host:
+    element (row, col) is kept iff tamd_dropout_hash(seed, row * cols + col) >= p * 2^32 (csrc/dropout.h DropCtx)."""
+    import numpy as np
+
+    idx = np.arange(rows * cols, dtype=np.uint64)
+    lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+    slo, shi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = (lo ^ slo) * np.uint32(0x9E3779B1)
+        x ^= x >> np.uint32(15)
+        x += (hi * np.uint32(0x85EBCA77)) ^ shi
+        x *= np.uint32(0xC2B2AE3D)
+        x ^= x >> np.uint32(13)
+        x *= np.uint32(0x27D4EB2F)
+        x ^= x >> np.uint32(16)
+    thr = np.uint32(min(4294967295.0, float(np.float32(p)) * 4294967296.0))
+    return torch.from_numpy((x >= thr).reshape(rows, cols))
 
 
 def linear(x, w, bias=None, residual=None, act=ACT_NONE):
@@ -845,10 +860,16 @@ def dropout_seed() -> int:
 
 
 def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int, p: float) -> torch.Tensor:
-    """The kernels' keep mask [B,H,Sq,Sk] (bool), rebuilt on the host with the exported hash -- for tests/debugging."""
+    """The attention kernels' keep mask [B,H,Sq,Sk] (bool), rebuilt on the host (csrc/dropout.h: one hash decides a 2 x 2
+    block -- query pair x key pair -- of the probability matrix, 16 bits per element; include/tamd.h
+    tamd_attn_dropout_field is the same function element by element) -- for tests/debugging."""
     import numpy as np
 
-    idx = np.arange(batch * heads * seq_q * seq_k, dtype=np.uint64)
+    csq, csk = (seq_q + 1) // 2, (seq_k + 1) // 2
+    bh = np.arange(batch * heads, dtype=np.uint64)[:, None, None]
+    qb = (np.arange(seq_q, dtype=np.uint64) >> np.uint64(1))[None, :, None]
+    kb = (np.arange(seq_k, dtype=np.uint64) >> np.uint64(1))[None, None, :]
+    idx = (bh * np.uint64(csq) + qb) * np.uint64(csk) + kb
     lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
     slo, shi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
@@ -859,8 +880,16 @@ def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int,
         x ^= x >> np.uint32(13)
         x *= np.uint32(0x27D4EB2F)
         x ^= x >> np.uint32(16)
-    thr = np.uint32(min(4294967295.0, float(np.float32(p)) * 4294967296.0))
-    return torch.from_numpy((x >= thr).reshape(batch, heads, seq_q, seq_k))
+        y = (x ^ np.uint32(0x85EBCA77)) * np.uint32(0x9E3779B1)  # the second word (odd keys)
+        y ^= y >> np.uint32(15)
+        y *= np.uint32(0xC2B2AE3D)
+        y ^= y >> np.uint32(16)
+    k_odd = (np.arange(seq_k) & 1).astype(bool)[None, None, :]
+    q_odd = (np.arange(seq_q) & 1).astype(bool)[None, :, None]
+    w = np.where(k_odd, y, x)
+    field = np.where(q_odd, w >> np.uint32(16), w & np.uint32(0xFFFF))
+    thr16 = np.uint32(min(65535.0, float(np.float32(p)) * 65536.0))
+    return torch.from_numpy((field >= thr16).reshape(batch, heads, seq_q, seq_k))
 
 
 def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None, q_start=None):
