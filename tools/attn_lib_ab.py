@@ -18,8 +18,20 @@ sys.path.insert(0, str(ROOT))
 from transformers_amd._cabi import AttnBwdParams, AttnParams, TamdLib, TAMD_BF16  # noqa: E402
 
 
-def params(q, k, v, o, lse, scale, causal):
-    p = AttnParams()
+# parameter blocks as an ABI-6 build lays them out (tamd_attn_params grew by q_prescaled in ABI 7, which moves every field
+# of tamd_attn_bwd_params behind the embedded block)
+class AttnParamsV6(ctypes.Structure):
+    _fields_ = [f for f in AttnParams._fields_ if f[0] != "q_prescaled"]
+
+
+class AttnBwdParamsV6(ctypes.Structure):
+    _fields_ = [("fwd", AttnParamsV6)] + [f for f in AttnBwdParams._fields_ if f[0] != "fwd"]
+
+
+DROPOUT = float(os.environ.get("AB_DROPOUT", "0"))  # attention dropout probability (timing only: the builds' masks differ)
+
+
+def params(q, k, v, o, lse, scale, causal, p):
     p.q, p.k, p.v, p.o, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
     p.key_valid = None
     p.batch, p.seq_q, p.heads_q, p.head_dim = q.shape
@@ -28,7 +40,7 @@ def params(q, k, v, o, lse, scale, causal):
         setattr(p, f"{name}_stride_b", t.stride(0))
         setattr(p, f"{name}_stride_s", t.stride(1))
         setattr(p, f"{name}_stride_h", t.stride(2))
-    p.scale, p.causal, p.dtype, p.dropout_p, p.dropout_seed, p.q_start = scale, int(causal), TAMD_BF16, 0.0, 0, None
+    p.scale, p.causal, p.dtype, p.dropout_p, p.dropout_seed, p.q_start = scale, int(causal), TAMD_BF16, DROPOUT, 1234567, None
     return p
 
 
@@ -88,17 +100,19 @@ def main():
         do = torch.randn(b, s, hq, d, device=dev).bfloat16()
         scale = 1 / math.sqrt(d)
         fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
-        ref = reference(q, k, v, do, scale, causal) if s <= 4096 else None
-        row = {"shape": name}
+        ref = reference(q, k, v, do, scale, causal) if s <= 4096 and DROPOUT == 0 else None
+        row = {"shape": name, "dropout_p": DROPOUT}
         runs = {}
         for tag, lib in libs.items():
             o = torch.empty_like(q)
             lse = torch.empty(b, hq, s, device=dev, dtype=torch.float32)
             dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
             delta = torch.empty(2, b, hq, s, device=dev, dtype=torch.float32)
-            fp = params(q, k, v, o, lse, scale, causal)
-            bp = AttnBwdParams()
-            bp.fwd = fp
+            v6 = lib.tamd_abi_version() < 7
+            bp = AttnBwdParamsV6() if v6 else AttnBwdParams()
+            fp = params(q, k, v, o, lse, scale, causal, bp.fwd)
+            for fn, st in ((lib.tamd_attn_fwd, type(fp)), (lib.tamd_attn_bwd, type(bp))):
+                fn.argtypes = [ctypes.POINTER(st), ctypes.c_void_p]
             bp.dout, bp.dq, bp.dk, bp.dv, bp.delta = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), delta.data_ptr()
             bp.rope_cos, bp.rope_sin, bp.rope_cos_batch = None, None, 1
             fwd = lambda lib=lib, fp=fp: lib.check(lib.tamd_attn_fwd(ctypes.byref(fp), stream), "fwd")  # noqa: E731

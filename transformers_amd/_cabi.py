@@ -113,7 +113,7 @@ class TamdLib:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
-        if missing:
+        if missing and not accept_abi:  # (a build of an earlier ABI lacks the newer entry points)
             raise TamdError(f"{self.path} does not export: {', '.join(missing)}")
         ver = self.tamd_abi_version()
         if ver != ABI_VERSION and ver not in (accept_abi or ()):  # (tools/attn_lib_ab.py loads a build of an earlier ABI)
