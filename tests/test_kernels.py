@@ -406,7 +406,8 @@ def ref_attention(q, k, v, scale, causal, key_valid, keep=None, drop_p=0.0):
     return (pr @ vf).permute(0, 2, 1, 3)
 
 
-def test_attention_takes_prescaled_queries_from_the_rotary_kernel(env):
+@pytest.mark.parametrize("d", [128, 64])
+def test_attention_takes_prescaled_queries_from_the_rotary_kernel(env, d):
     """ABI 7 (include/tamd.h): tamd_rope_inplace multiplies the query heads by scale*log2(e) BEFORE its one rounding, and
     the attention kernels, told so (q_prescaled), skip their own scale-and-re-round of the resident operand.  Checked
     through the C ABI: the scaled rotary kernel's bits; forward and backward of both forms against the fp32 model (rotary
@@ -416,7 +417,7 @@ def test_attention_takes_prescaled_queries_from_the_rotary_kernel(env):
     be = ops.backend()
     lib, dev = be.lib, env.device
     torch.manual_seed(61)
-    b, s, hq, hkv, d = (2, 1024, 8, 2, 128) if env.big else (1, 200, 4, 2, 128)
+    b, s, hq, hkv = (2, 1024, 8, 2) if env.big else (1, 200, 4, 2)
     row = (hq + 2 * hkv) * d
     qkv = torch.randn(b, s, row).bfloat16().to(dev)
     inv = 1.0 / (500000.0 ** (torch.arange(0, d, 2).float() / d))
@@ -480,8 +481,10 @@ def test_attention_takes_prescaled_queries_from_the_rotary_kernel(env):
         errs[tag] = (rel_err(o, ref), rel_err(dq, qr.grad), rel_err(dk, kr.grad), rel_err(dv, vr.grad))
         assert errs[tag][0] < 0.0052 and max(errs[tag][1:]) < 0.0065, (tag, errs[tag])   # (gradients are w.r.t. the UNSCALED q)
     # measured on the CPU model: O 0.00316 -> 0.00288, dq 0.00403 -> 0.00385, dk 0.00423 -> 0.00387, dv 0.00373 -> 0.00320
-    assert all(a <= b_ for a, b_ in zip(errs["pre-scaled"], errs["kernel-scaled"])), errs
-    assert errs["pre-scaled"][0] < 0.99 * errs["kernel-scaled"][0], errs  # one rounding of q less (MI355X, big shape: 0.00324 vs 0.00349)
+    print("prescaled-q errors (O, dq, dk, dv):", d, errs)
+    slack = 1.0 if d == 128 else 1.03  # (head_dim 64 was measured on the CPU model only)
+    assert all(a <= slack * b_ for a, b_ in zip(errs["pre-scaled"], errs["kernel-scaled"])), errs
+    assert errs["pre-scaled"][0] < 0.99 * slack * errs["kernel-scaled"][0], errs  # one rounding of q less (MI355X, 128: 0.00324 vs 0.00349)
 
 
 ATTN_CASES_SMALL = [
@@ -528,9 +531,10 @@ def test_attention_fwd_bwd(env):
             assert rel_err(a, r) < 0.0057, (case, name)
 
 
-DROPOUT_CASES_SMALL = [(1, 130, 130, 2, 1, 64, True, False, 0.1), (2, 96, 160, 2, 2, 128, False, True, 0.5)]
+DROPOUT_CASES_SMALL = [(1, 130, 130, 2, 1, 64, True, False, 0.1), (2, 96, 160, 2, 2, 128, False, True, 0.5),
+                       (1, 67, 131, 3, 1, 64, True, False, 0.2)]  # odd lengths: the 2 x 2 hash blocks end ragged
 DROPOUT_CASES_BIG = [(2, 1024, 1024, 8, 2, 128, True, False, 0.1), (4, 512, 512, 12, 12, 64, False, True, 0.1),
-                     (1, 300, 777, 4, 4, 64, True, True, 0.3)]
+                     (1, 300, 777, 4, 4, 64, True, True, 0.3), (1, 333, 333, 2, 1, 128, False, False, 0.25)]
 
 
 def test_attention_dropout_matches_explicit_mask(env):
