@@ -517,7 +517,10 @@ bool gemm_swiglu_supported(const Tensor& x2, const Tensor& wgu) {
   return half_type(x2) && wgu.scalar_type() == x2.scalar_type() && k % 64 == 0 && two_i % 16 == 0 && x2.stride(1) == 1 &&
          wgu.stride(1) == 1 && x2.stride(0) % 8 == 0 && wgu.stride(0) % 8 == 0 &&
          two_i * wgu.stride(0) * 2 < ((int64_t)1 << 31) &&
-         api().tamd_gemm_workspace_bytes(x2.size(0), two_i, k, 0, TAMD_EPI_NONE) == 0;  // (small grids: split-K + swiglu kernel)
+         // small grids: the plain GEMM (128 x 128 tile or split-K by the library's policy) + the swiglu kernel.  "Small" as
+         // for a k-major product (flags 3): the forward-layout exception of the policy -- short K goes to the 128 x 128
+         // tile instead of split-K -- is about WHICH plain kernel runs, not about whether the grid fills the GPU
+         api().tamd_gemm_workspace_bytes(x2.size(0), two_i, k, 3, TAMD_EPI_NONE) == 0;
 }
 
 // x2 [T, K], wgu [2I, K] = [gate_proj.weight ; up_proj.weight]  ->  (gu [T, 2I] or undefined, act [T, I])
@@ -541,7 +544,7 @@ bool gemm_rope_supported(const Tensor& x2, const Tensor& wqkv, const Tensor& cos
   return head_dim == 128 && ((cos.dim() == 3 && cos.size(0) > 1) || cos.size(-2) >= 128) && half_type(x2) &&
          wqkv.scalar_type() == x2.scalar_type() && k % 64 == 0 && n % 128 == 0 && x2.stride(1) == 1 && wqkv.stride(1) == 1 &&
          x2.stride(0) % 8 == 0 && wqkv.stride(0) % 8 == 0 && cos.size(-1) == 128 &&
-         api().tamd_gemm_workspace_bytes(x2.size(0), n, k, 0, TAMD_EPI_NONE) == 0;
+         api().tamd_gemm_workspace_bytes(x2.size(0), n, k, 3, TAMD_EPI_NONE) == 0;  // (small grids: as gemm_swiglu_supported)
 }
 
 Tensor k_gemm_rope(const Tensor& x2, const Tensor& wqkv, const Tensor& cos_, const Tensor& sin_, int64_t seq,

@@ -266,7 +266,7 @@ def gemm_rope_supported(x2, wqkv, cos, head_dim) -> bool:
             and n % 128 == 0 and x2.stride(1) == 1 and wqkv.stride(1) == 1 and x2.stride(0) % 8 == 0
             and wqkv.stride(0) % 8 == 0 and cos.shape[-1] == 128
             # a tile grid that cannot fill the GPU (a short prompt) is better off with split-K and the rotary kernel
-            and gemm_workspace_bytes(x2.shape[0], n, k, EPI_NONE) == 0)
+            and gemm_workspace_bytes(x2.shape[0], n, k, EPI_NONE, 3) == 0)  # ("small" as for a k-major product: torch_binding.cpp)
 
 
 def raw_gemm_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim):
@@ -281,7 +281,7 @@ def gemm_swiglu_supported(x2, wgu) -> bool:
     return (x2.dtype in (torch.bfloat16, torch.float16) and wgu.dtype == x2.dtype and k % 64 == 0 and two_i % 16 == 0
             and x2.stride(1) == 1 and wgu.stride(1) == 1 and x2.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0
             and two_i * wgu.stride(0) * 2 < 2 ** 31
-            and gemm_workspace_bytes(x2.shape[0], two_i, k, EPI_NONE) == 0)  # (small grids: split-K + swiglu kernel)
+            and gemm_workspace_bytes(x2.shape[0], two_i, k, EPI_NONE, 3) == 0)  # (small grids: plain GEMM + swiglu kernel)
 
 
 def raw_gemm_swiglu(x2, wgu, need_gu=True):
