@@ -5,6 +5,7 @@
 #      (tools/ab/libtamd_base.so: per-element hash, no srcC chains) -- the 2 x 2-block dropout's per-kernel gain;
 #   2. the same without dropout (the srcC chains alone) for the split;
 #   3. bert-base bench line + rocprofv3 kernel stats of it (attention rows: 116 / 131 / 154 us per layer before).
+# (tools/ab/libtamd_base.so is git-ignored: tools/build_base_lib.sh rebuilds it from commit 23d1524 if it is gone)
 # usage: gpurun --timeout 300 -- bash tools/gpu_r04_open.sh
 mkdir -p gpurun_out
 export TMPDIR=/tmp
