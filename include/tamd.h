@@ -1,10 +1,12 @@
 /* tamd.h -- C ABI of libtamd.so: the MI355X (gfx950) transformer-block kernels.
  *
  * This is the drop-in boundary ("B3"): plain pointers,
- * sizes, strides, scalars and a hipStream_t -- no torch types.  The Python
- * host side (transformers_amd/ops.py) binds these with ctypes and registers
- * them as torch.ops.tamd.*; any other host (C++, a `kernels`-style Hub
- * package) can bind the same symbols.
+ * sizes, strides, scalars and a hipStream_t -- no torch types.  The product's
+ * host side is compiled: transformers_amd/csrc/torch_binding.cpp
+ * (libtamd_torch.so) resolves these symbols with dlopen/dlsym at run time and
+ * exposes them as torch.ops.tamd.* (TORCH_LIBRARY); ctypes (transformers_amd/
+ * _cabi.py) is only how the tests and tools call an entry point directly.  Any
+ * other host (C++, a `kernels`-style Hub package) can bind the same symbols.
  *
  * Contract for every entry point:
  *   - returns 0 on success; <0 = TAMD_E_* argument error (nothing launched);

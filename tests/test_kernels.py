@@ -482,6 +482,9 @@ def test_attention_takes_prescaled_queries_from_the_rotary_kernel(env, d):
         assert errs[tag][0] < 0.0052 and max(errs[tag][1:]) < 0.0065, (tag, errs[tag])   # (gradients are w.r.t. the UNSCALED q)
     # measured on the CPU model: O 0.00316 -> 0.00288, dq 0.00403 -> 0.00385, dk 0.00423 -> 0.00387, dv 0.00373 -> 0.00320
     print("prescaled-q errors (O, dq, dk, dv):", d, errs)
+    for tag, e4 in errs.items():  # into the parity report (gpurun_out/parity_hip.json on MI355X)
+        for nm, e in zip(("O", "dq", "dk", "dv"), e4):
+            record("attn_prescaled_q", f"d{d}:{tag}:{nm}", e)
     slack = 1.0 if d == 128 else 1.03  # (head_dim 64 was measured on the CPU model only)
     assert all(a <= slack * b_ for a, b_ in zip(errs["pre-scaled"], errs["kernel-scaled"])), errs
     assert errs["pre-scaled"][0] < 0.99 * slack * errs["kernel-scaled"][0], errs  # one rounding of q less (MI355X, 128: 0.00324 vs 0.00349)

@@ -23,15 +23,18 @@ def load():
     global _dll
     if _dll is not None:
         return _dll
-    if not LIB_PATH.exists():
-        # first import of a fresh checkout: the binding is 15 s of host C++ (no GPU, no hipcc needed); the kernel library
-        # itself is built by `python -m transformers_amd.build` / __graft_entry__.build()
-        try:
-            from . import build
+    from . import build
 
+    # a fresh checkout (no library), or a library built from another source / against another torch (an ABI bump, a torch
+    # upgrade: the stamp next to it says so): (re)build -- 15 s of host C++, no GPU and no hipcc needed; atomic and
+    # serialised across ranks (build.build_torch_binding).  A library without a stamp cannot be checked and is loaded as is.
+    current = build.torch_binding_is_current() if LIB_PATH.exists() else False
+    if current is False:
+        try:
             build.build_torch_binding()
         except Exception as e:
-            raise TamdError(f"{LIB_PATH} not found and building it failed ({e}); run `python -m transformers_amd.build` "
+            what = "not found" if not LIB_PATH.exists() else "is stale (built from another source or torch version)"
+            raise TamdError(f"{LIB_PATH} {what} and building it failed ({e}); run `python -m transformers_amd.build` "
                             "(the compiled torch.ops.tamd.* binding; the MI355X path has no Python/eager fallback)") from e
     torch.ops.load_library(str(LIB_PATH))
     dll = ctypes.CDLL(str(LIB_PATH))

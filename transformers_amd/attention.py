@@ -11,6 +11,7 @@ models/clip/modeling_clip.py:321-330):
 """
 from __future__ import annotations
 
+import threading
 from typing import Optional
 
 import torch
@@ -140,20 +141,39 @@ def split_mask(attention_mask, batch: int, kv_len: int):
     return _key_valid_from_mask(attention_mask, batch, kv_len), None
 
 
+_varlen_cache = threading.local()  # the last (cu_seq_lens_q, cu_seq_lens_k, total) -> q_start of this thread
+
+
+def _same_tensor(a, b) -> bool:
+    """Same bytes by construction: the same object, or two views of one storage at the same version (the caller holds a
+    reference to `a`, so its storage cannot have been recycled for `b`)."""
+    return a is b or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape
+                      and a.dtype == b.dtype and a._version == b._version)
+
+
 def varlen_q_start(q_start, kwargs, batch: int, sq: int, sk: int, causal: bool):
     """The reference's varlen kwargs (`cu_seq_lens_q / cu_seq_lens_k / max_length_q / max_length_k`,
     modeling_flash_attention_utils.py:575-590, consumed by its flash path :768-790) for a flattened batch: the same
     block-diagonal causal attention the mask factory derives from restarting `position_ids` -- used when the mask did not
-    already carry it.  Different query / key boundaries (a KV cache under packing) are refused, not ignored."""
+    already carry it.  Different query / key boundaries (a KV cache under packing) are refused, not ignored.
+    Every layer of a forward receives the same two tensors: the boundaries are validated (one comparison on the device,
+    the only host synchronisation of this path) and turned into `q_start` ONCE per forward, the other layers reuse it."""
     cu_q = kwargs.get("cu_seq_lens_q")
     if q_start is not None or cu_q is None:
         return q_start
     cu_k = kwargs.get("cu_seq_lens_k")
-    if batch != 1 or sq != sk or not causal or (cu_k is not None and cu_k is not cu_q and (
-            cu_k.shape != cu_q.shape or not torch.equal(cu_k, cu_q))):
+    if batch != 1 or sq != sk or not causal:
         raise TamdError("attn_implementation='tamd' takes cu_seq_lens_q/k for one flattened, causal row without a KV cache "
                         "(equal query and key boundaries)")
-    return ops.q_start_from_cu_seqlens(cu_q, sq)
+    hit = getattr(_varlen_cache, "entry", None)
+    if hit is not None and hit[2] == sq and _same_tensor(hit[0], cu_q) and (cu_k is None or _same_tensor(hit[1], cu_k)):
+        return hit[3]
+    if cu_k is not None and cu_k is not cu_q and (cu_k.shape != cu_q.shape or not torch.equal(cu_k, cu_q)):
+        raise TamdError("attn_implementation='tamd' takes cu_seq_lens_q/k for one flattened, causal row without a KV cache "
+                        "(equal query and key boundaries)")
+    qs = ops.q_start_from_cu_seqlens(cu_q, sq)
+    _varlen_cache.entry = (cu_q, cu_k if cu_k is not None else cu_q, sq, qs)
+    return qs
 
 
 def _key_valid_from_mask(attention_mask, batch: int, kv_len: int) -> Optional[torch.Tensor]:

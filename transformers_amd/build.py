@@ -87,9 +87,30 @@ def _build(lib: Path, sources, obj_dir: Path, defines, force: bool, verbose: boo
 TORCH_LIB = HERE / "libtamd_torch.so"  # torch.ops.tamd.*: csrc/torch_binding.cpp (host C++ only, no device code)
 
 
+def torch_binding_source_digest() -> str:
+    """What a built libtamd_torch.so must match to be loaded: its source, the C ABI header and the torch it was compiled
+    against (cheap: no compiler probing -- `_native.load()` checks it at import)."""
+    import torch
+
+    return _digest([CSRC / "torch_binding.cpp", INCLUDE / "tamd.h"]) + " torch " + torch.__version__
+
+
+def torch_binding_is_current() -> bool | None:
+    """True / False: the library on disk was built from the current source and torch; None: no stamp to tell by."""
+    stamp = OBJ_DIR / "torch_binding.stamp"
+    if not TORCH_LIB.exists() or not stamp.exists():
+        return None
+    lines = stamp.read_text().split("\n")
+    return len(lines) >= 1 and lines[0] == torch_binding_source_digest()
+
+
 def build_torch_binding(force: bool = False, verbose: bool = False) -> Path:
     """Compile csrc/torch_binding.cpp against the installed torch (TORCH_LIBRARY(tamd, ...): the compiled dispatcher ops
-    that call the C ABI of include/tamd.h through a table bound at run time)."""
+    that call the C ABI of include/tamd.h through a table bound at run time).  Safe under concurrent callers (several
+    ranks importing a fresh checkout): one builds under a file lock, into a temporary file that replaces the library
+    atomically -- nobody can `load_library` a half-written .so."""
+    import fcntl
+
     import torch
     from torch.utils import cpp_extension as ce
 
@@ -103,20 +124,26 @@ def build_torch_binding(force: bool = False, verbose: bool = False) -> Path:
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-unused-result"]
     for inc in ce.include_paths():
         cmd += ["-isystem", inc]
-    cmd += ["-isystem", str(rocm / "include"), str(src), "-o", str(TORCH_LIB), f"-L{torch_lib}", "-ltorch", "-ltorch_cpu",
-            "-lc10", "-lc10_hip", "-ltorch_hip", f"-L{rocm / 'lib'}", "-lamdhip64", "-ldl", f"-Wl,-rpath,{torch_lib}",
-            f"-Wl,-rpath,{rocm / 'lib'}"]
+    cmd += ["-isystem", str(rocm / "include"), str(src)]
+    tail = [f"-L{torch_lib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", f"-L{rocm / 'lib'}",
+            "-lamdhip64", "-ldl", f"-Wl,-rpath,{torch_lib}", f"-Wl,-rpath,{rocm / 'lib'}"]
     stamp = OBJ_DIR / "torch_binding.stamp"
-    digest = _digest([src, INCLUDE / "tamd.h"]) + torch.__version__ + " ".join(cmd)
-    if not force and TORCH_LIB.exists() and stamp.exists() and stamp.read_text() == digest:
-        return TORCH_LIB
+    digest = torch_binding_source_digest() + "\n" + " ".join(cmd + tail)
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"building {TORCH_LIB.name} failed:\n{r.stdout}\n{r.stderr[-6000:]}")
-    stamp.write_text(digest)
+    with open(OBJ_DIR / "torch_binding.lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)  # (released when the file is closed)
+        if not force and TORCH_LIB.exists() and stamp.exists() and stamp.read_text() == digest:
+            return TORCH_LIB  # up to date -- possibly built by the rank that held the lock before us
+        tmp = TORCH_LIB.with_name(f".{TORCH_LIB.name}.{os.getpid()}.tmp")
+        full = cmd + ["-o", str(tmp)] + tail
+        if verbose:
+            print(" ".join(full), flush=True)
+        r = subprocess.run(full, capture_output=True, text=True)
+        if r.returncode != 0:
+            tmp.unlink(missing_ok=True)
+            raise RuntimeError(f"building {TORCH_LIB.name} failed:\n{r.stdout}\n{r.stderr[-6000:]}")
+        os.replace(tmp, TORCH_LIB)
+        stamp.write_text(digest)
     return TORCH_LIB
 
 

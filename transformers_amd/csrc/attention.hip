@@ -113,7 +113,9 @@ AttnArgs make_args(const tamd_attn_params* p) {
   const double pd = p->dropout_p;
   // 16-bit keep threshold (dropout.h: one hash decides a 2 x 2 block of probabilities); a p below 2^-16 is no dropout
   a.drop_thr = (pd > 0.0) ? (unsigned)(pd >= 1.0 ? 65535.0 : pd * 65536.0) : 0u;
-  a.drop_scale = (a.drop_thr != 0u && pd < 1.0) ? (float)(1.0 / (1.0 - pd)) : 1.f;
+  // the keep-scale is the inverse of the EFFECTIVE keep probability (65536 - thr) / 65536 of the quantised threshold, so that
+  // E[keep * scale] == 1 exactly (1 / (1 - p) differs from it by <= 2^-16 relative: p = 0.1 -> thr 6553, p_eff 0.09999)
+  a.drop_scale = (a.drop_thr != 0u && pd < 1.0) ? (float)(65536.0 / (65536.0 - (double)a.drop_thr)) : 1.f;
   a.seed_lo = (unsigned)p->dropout_seed;
   a.seed_hi = (unsigned)(p->dropout_seed >> 32);
   a.nqt = (int)ceil_div(p->seq_q, kQB);

@@ -33,7 +33,7 @@ struct AttnArgs {
   int64_t qsb, qss, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, oss, osh;
   float scale_log2;  // scale * log2(e)
   unsigned drop_thr;  // keep iff the element's 16-bit hash field >= drop_thr (0 = no dropout); dropout.h AttnDrop
-  float drop_scale;   // 1 / (1 - p)
+  float drop_scale;   // 65536 / (65536 - drop_thr): 1 / (1 - p) of the quantised p (attention.hip make_args)
   unsigned seed_lo, seed_hi;
   int nqt;           // query tiles per (b, h)
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs

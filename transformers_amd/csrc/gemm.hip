@@ -1,6 +1,7 @@
 // gemm.hip -- bf16/f16 MFMA GEMM for gfx950 with fused epilogues.
 //
-//   C[M,N] = epilogue( A[M,K] . B[N,K]^T )        fp32 accumulation on v_mfma_f32_32x32x16_{bf16,f16}
+//   C[M,N] = epilogue( A[M,K] . B[N,K]^T )        fp32 accumulation on v_mfma_f32_16x16x32_{bf16,f16} (gemm_fl_kernel) or
+//                                                 v_mfma_f32_32x32x16_{bf16,f16} (gemm_pp_kernel, gemm_sm_kernel)
 //
 // replaces every nn.Linear on the hot path (reference call sites, src/transformers/):
 //   models/llama/modeling_llama.py:254-256 (q/k/v), :280 (o_proj), :174-176 (gate/up/down),
@@ -11,28 +12,29 @@
 //   dW[N',K'] = dY[M,N']^T . X[M,K']    -> TAMD_GEMM_A_KM | TAMD_GEMM_B_KN (both stored k-major)
 // so no operand is ever transposed through HBM.
 //
-// Common structure of both kernels below:
-//   * 256x256 output tile per workgroup, K advances in sub-tiles of BK=32 through a 4-stage LDS ring
-//     (stage = A[256][32] 16 KiB + B[256][32] 16 KiB); operands stream L2 -> LDS with
-//     global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip), three sub-tiles ahead of the math, retired by
-//     COUNTED s_waitcnt vmcnt(N) and raw s_barrier (never __syncthreads(), which would drain vmcnt);
-//   * LDS images are lane-linear (an LDS-DMA requirement), so the bank-conflict swizzle is applied to the
-//     per-lane SOURCE address and undone on the fragment read (cdna guide rule 21):
-//       row-major operand stage [256 rows][32 k] (64-byte rows): slot' = slot ^ ((row>>2)&3)  ds_read_b128
-//       k-major operand stage   [32 k][256 cols]               : slot' = slot ^ ((k&3)<<2)    ds_read_b64_tr_b16
+// Common to the kernels below (each kernel's own comment has its tile, ring and schedule):
+//   * operands stream L2 -> LDS with LDS-DMA (global_load_lds_dwordx4 / buffer_load ... lds: no VGPR round trip) into a ring
+//     of stages, ahead of the math, retired by COUNTED s_waitcnt vmcnt(N) and raw s_barrier (never __syncthreads(), which
+//     would drain vmcnt);
+//   * LDS images are lane-linear (an LDS-DMA requirement), so the bank-conflict swizzle is applied to the per-lane SOURCE
+//     address and undone on the fragment read (cdna guide rule 21):
+//       row-major operand stage, 64-deep  [rows][64 k] (128-byte rows) : chunk' = chunk ^ ((row>>1)&7)    ds_read_b128
+//       row-major operand stage, 32-deep  [rows][32 k] (64-byte rows)  : slot'  = slot ^ ((row>>2)&3)     ds_read_b128
+//       k-major operand stage             [k][256 cols]               : slot'  = slot ^ f(k)             ds_read_b64_tr_b16
 //     (conflict-free in the LDS bank model of tests/hipemu and by SQ_LDS_BANK_CONFLICT on MI355X);
 //   * the MFMA is issued "swapped" (A-operand = B/W fragment, B-operand = A/X fragment) so each lane ends up
 //     with 4 consecutive output columns of one output row; the epilogue rounds to the storage dtype, stages the
 //     wave's tile in LDS and writes full row segments (bias / activation / residual / accumulate fused there);
 //   * workgroup ids are remapped XCD-aware (8 XCDs, private L2s): each XCD owns a contiguous chunk of a grouped
-//     (8 M-tiles wide) tile order, so concurrently resident tiles share A/B panels in L2 (84.6 % hits measured).
-// Three kernels (profiles/r01_gemm_variants.md has the measurements that led to the first two):
-//   gemm_fl_kernel  4 waves x (128 x 128), one wave per SIMD, 512 registers, 64-deep "full-line" stages: every
-//                   layout when K % 64 == 0 (all Llama / BERT / CLIP / GPT-2 products, forward and backward)
-//   gemm_pp_kernel  8 waves, 2 groups one phase apart (ping-pong), 32-deep stages: any K (ragged token counts in
-//                   dW, odd hidden sizes)
-//   gemm_sm_kernel  128 x 128 tile, 4 waves x (64 x 64), two workgroups per CU: forward products whose 256 x 256 grid
-//                   cannot spread over the GPU (a CLIP tower's 577 tokens)
+//     (8 M-tiles wide) tile order, so concurrently resident tiles share A/B panels in L2.
+// Three kernels (profiles/r01_gemm_variants.md, r02_gemm_variants.md have the measurements that led to them):
+//   gemm_fl_kernel  256 x 256 tile, 4 waves x (128 x 128) on v_mfma_f32_16x16x32, one wave per SIMD, 512 registers, 64-deep
+//                   "full-line" stages in 5 half-slots of 32 KiB (all 160 KiB of LDS): every layout when K % 64 == 0 (all
+//                   Llama / BERT / CLIP / GPT-2 products, forward and backward)
+//   gemm_pp_kernel  256 x 256 tile, 8 waves in 2 groups one phase apart (ping-pong) on v_mfma_f32_32x32x16, 32-deep stages
+//                   in a 4-stage ring: any K (ragged token counts in dW, odd hidden sizes)
+//   gemm_sm_kernel  128 x 128 tile, 4 waves x (64 x 64) on v_mfma_f32_32x32x16, two workgroups per CU: forward products whose
+//                   256 x 256 grid cannot spread over the GPU (a CLIP tower's 577 tokens)
 #include <stdlib.h>
 
 #include "common.h"

@@ -9,8 +9,14 @@ this package owns the code: the decoder layers.  `LlamaModel.forward` (models/ll
 in a plain loop, `hidden_states = decoder_layer(hidden_states, ...)`; layer 0 runs the whole stack as a graph and hands
 back the final hidden state, the other layers recognise that tensor (by identity) and pass it through.
 
-Used when nothing is being differentiated, no KV cache is in play and no hook wants per-layer outputs; a shape is captured
-the second time it is seen (a one-off forward stays eager).  `TAMD_HIP_GRAPH=0` switches it off.
+Used when nothing is being differentiated, no KV cache is in play, no hook wants per-layer outputs and every layer's
+weights live on the device of the hidden state (no `device_map` spread, no accelerate offload hooks); a shape is captured
+the second time it is seen (a one-off forward stays eager); a signature whose capture failed is never tried again.
+`TAMD_HIP_GRAPH=0` switches it off.
+
+Aliasing contract: the tensor `run()` returns is the graph's static output buffer -- the NEXT replay of the same signature
+overwrites it in place.  `LlamaModel.forward` feeds it straight into its final norm (a fresh tensor), which is the only
+consumer this module serves; a caller that keeps the returned hidden state across two forwards must clone it.
 """
 from __future__ import annotations
 
@@ -24,6 +30,7 @@ from . import ops
 
 _ENABLED = os.environ.get("TAMD_HIP_GRAPH", "1") != "0"
 _MAX_GRAPHS = 4  # captured shapes kept per stack (each holds its own activation pool)
+_MAX_SEEN = 64   # signatures remembered before capture (sightings / failures); beyond that the stack stays eager
 
 
 def enabled() -> bool:
@@ -43,9 +50,12 @@ class LlamaStackGraph:
     def __init__(self, layers):
         self.layers = list(layers)
         self._graphs = {}   # key -> (graph, static inputs, static output)
-        self._seen = {}     # key -> times seen before capture
+        self._seen = {}     # key -> sightings before capture
+        self._failed = set()  # keys whose capture raised: eager from then on
+        self._lock = threading.Lock()  # capture / replay write the shared static buffers: one thread at a time
         self._pass = threading.local()  # the output handed out by layer 0, for the other layers to recognise
         self.replays = 0
+        self.capture_failures = 0
 
     # ---- per-call protocol (called from TamdLlamaDecoderLayer.forward)
     def passthrough(self, hidden_states) -> bool:
@@ -63,30 +73,53 @@ class LlamaStackGraph:
         # output recorders hook the decoder layers for `output_hidden_states`, utils/output_capturing.py)
         if not all(layer._fused_ok(hidden_states, None) and not _has_hooks(layer) for layer in self.layers):
             return None
-        key = self._key(hidden_states, cos, sin, key_valid, q_start)
-        entry = self._graphs.get(key)
-        if entry is None:
-            n = self._seen.get(key, 0)
-            self._seen[key] = n + 1
-            if n == 0 or len(self._graphs) >= _MAX_GRAPHS:
-                return None  # first sighting of this signature (or the cache is full): eager
-            entry = self._capture(key, hidden_states, cos, sin, key_valid, q_start)
+        sig = self._weights_signature()
+        if not self._placement_ok(hidden_states.device, sig):
+            return None
+        key = self._key(hidden_states, cos, sin, key_valid, q_start, sig)
+        with self._lock:
+            entry = self._graphs.get(key)
             if entry is None:
-                return None
-        graph, static, out = entry
-        static["h"].copy_(hidden_states)
-        static["cos"].copy_(cos)
-        static["sin"].copy_(sin)
-        if key_valid is not None:
-            static["key_valid"].copy_(key_valid)
-        if q_start is not None:
-            static["q_start"].copy_(q_start)
-        graph.replay()
-        self.replays += 1
+                if key in self._failed:
+                    return None
+                n = self._seen.get(key, 0)
+                if n == 0 and len(self._seen) >= _MAX_SEEN:
+                    return None  # (a stream of ever-new shapes: do not remember them all)
+                self._seen[key] = n + 1
+                if n == 0 or len(self._graphs) >= _MAX_GRAPHS:
+                    return None  # first sighting of this signature (or the cache is full): eager
+                entry = self._capture(key, hidden_states, cos, sin, key_valid, q_start)
+                if entry is None:
+                    return None
+            graph, static, out = entry
+            static["h"].copy_(hidden_states)
+            static["cos"].copy_(cos)
+            static["sin"].copy_(sin)
+            if key_valid is not None:
+                static["key_valid"].copy_(key_valid)
+            if q_start is not None:
+                static["q_start"].copy_(q_start)
+            graph.replay()
+            self.replays += 1
         self._pass.out = out
         return out
 
     # ---- internals
+    def _placement_ok(self, device, sig) -> bool:
+        """Every parameter of every layer on `device` and materialised, no accelerate hook on a layer: `_forward_all` calls
+        the layer op directly, i.e. it bypasses the forward wrappers accelerate installs for `device_map` / offloading.
+        (Cached on the weights' signature: their storage does not move without it changing.)"""
+        cached = self.__dict__.get("_placement")
+        if cached is not None and cached[0] == (sig, device):
+            return cached[1]
+        ok = True
+        for layer in self.layers:
+            if hasattr(layer, "_hf_hook") or any(p.device != device for p in layer.parameters()):
+                ok = False  # (an offloaded / meta / other-GPU weight, or a wrapper that moves weights per call)
+                break
+        self.__dict__["_placement"] = ((sig, device), ok)
+        return ok
+
     def _weights_signature(self):
         sig = []
         for layer in self.layers:
@@ -96,10 +129,10 @@ class LlamaStackGraph:
                         layer.input_layernorm.weight.data_ptr(), layer.post_attention_layernorm.weight.data_ptr()))
         return hash(tuple(sig))
 
-    def _key(self, h, cos, sin, key_valid, q_start):
+    def _key(self, h, cos, sin, key_valid, q_start, sig):
         return (tuple(h.shape), h.dtype, h.device.index, tuple(cos.shape), cos.dtype,
                 None if key_valid is None else (tuple(key_valid.shape), key_valid.dtype),
-                None if q_start is None else tuple(q_start.shape), self._weights_signature())
+                None if q_start is None else tuple(q_start.shape), sig)
 
     def _forward_all(self, h, cos, sin, key_valid, q_start):
         from . import layer_ops
@@ -132,7 +165,8 @@ class LlamaStackGraph:
             with torch.cuda.graph(graph), torch.no_grad():
                 out = self._forward_all(*args)
         except Exception:  # a capture that fails must leave the eager path intact: never try this signature again
-            self._seen[key] = -(1 << 30)
+            self._failed.add(key)
+            self.capture_failures += 1
             torch.cuda.synchronize()
             return None
         entry = (graph, static, out)
