@@ -463,11 +463,15 @@ def main():
         # add host time to the timed region -- so the `roofline` object of these configurations comes from two extra
         # UNTIMED steps with the log on, run after the timed region (same kernels, same shapes)
         roofline_steps = 2
+        from transformers_amd import graph_stack
+
+        was = graph_stack.set_enabled(False)  # (launches replayed from a captured decoder stack cannot be timed one by one)
         timer.enabled = True
         for _ in range(roofline_steps):
             run()
         torch.cuda.synchronize()
         timer.enabled = False
+        graph_stack.set_enabled(was)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 7
+#define TAMD_ABI_VERSION 8
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -90,24 +90,28 @@ int tamd_layernorm_fwd(const void* x, const void* residual, const void* w, const
                        float* mean, float* rstd, int64_t rows, int64_t cols, float eps, int dtype,
                        tamd_stream_t stream);
 
-/* dx = (dres?dres:0) + rstd*(g - mean(g) - xhat*mean(g*xhat)); dw = sum dy*xhat; db = sum dy (db may be NULL). */
+/* dx = (dres?dres:0) + rstd*(g - mean(g) - xhat*mean(g*xhat)); dw = sum dy*xhat; db = sum dy (db may be NULL).
+ * ABI 8: dcolsum (nullable, [cols], needs dres == NULL) additionally receives the column sums of dx as stored -- in a post-LN
+ * block, LayerNorm(dense(x) + residual) (modeling_bert.py:289-293, :347-351), that is the bias gradient of `dense`, which
+ * otherwise costs a tamd_colsum pass over dx. */
 int tamd_layernorm_bwd(const void* dy, const void* h, const void* w, const float* mean, const float* rstd,
-                       const void* dres, void* dx, void* dw, void* db, void* workspace, size_t workspace_bytes,
-                       int64_t rows, int64_t cols, int dtype, tamd_stream_t stream);
+                       const void* dres, void* dx, void* dw, void* db, void* dcolsum, void* workspace,
+                       size_t workspace_bytes, int64_t rows, int64_t cols, int dtype, tamd_stream_t stream);
 
 /* Post-LN block of BERT in train mode (models/bert/modeling_bert.py:289-293, :347-351):
  *   h = dropout(x, p) + residual;  y = LayerNorm(h)
  * The keep mask is the counter-based hash of (seed, row * cols + col) (tamd_dropout_hash), so the backward regenerates
  * it; kept elements are scaled by 1/(1-p) and rounded to the storage type before the residual is added, as the
  * reference's bf16 ops do.  Backward: dx = d loss / d h (the gradient of the residual input), dx_drop = the gradient of
- * x (dx masked and scaled); dres as in tamd_layernorm_bwd. */
+ * x (dx masked and scaled); dres as in tamd_layernorm_bwd; dcolsum (ABI 8, nullable, needs dres == NULL): the column
+ * sums of dx_drop = the bias gradient of the dense layer that produced x. */
 int tamd_layernorm_dropout_fwd(const void* x, const void* residual, const void* w, const void* b, void* y, void* h_out,
                                float* mean, float* rstd, int64_t rows, int64_t cols, float eps, float dropout_p,
                                uint64_t seed, int dtype, tamd_stream_t stream);
 int tamd_layernorm_dropout_bwd(const void* dy, const void* h, const void* w, const float* mean, const float* rstd,
-                               const void* dres, void* dx, void* dx_drop, void* dw, void* db, void* workspace,
-                               size_t workspace_bytes, int64_t rows, int64_t cols, float dropout_p, uint64_t seed,
-                               int dtype, tamd_stream_t stream);
+                               const void* dres, void* dx, void* dx_drop, void* dw, void* db, void* dcolsum,
+                               void* workspace, size_t workspace_bytes, int64_t rows, int64_t cols, float dropout_p,
+                               uint64_t seed, int dtype, tamd_stream_t stream);
 
 /* ------------------------------------------------------------------ rotary */
 
@@ -168,9 +172,11 @@ int tamd_swiglu_bwd(const void* gate, const void* up, const void* dact, void* dg
  * (models/gpt2/modeling_gpt2.py:238-243), CLIPMLP (models/clip/modeling_clip.py:346-350). bias may be NULL. */
 int tamd_bias_act_fwd(const void* x, const void* bias, void* y, int64_t rows, int64_t cols, int act, int dtype,
                       tamd_stream_t stream);
-/* dx = dy * act'(x [+ bias]) */
-int tamd_bias_act_bwd(const void* x, const void* bias, const void* dy, void* dx, int64_t rows, int64_t cols,
-                      int act, int dtype, tamd_stream_t stream);
+/* dx = dy * act'(x [+ bias]).  ABI 8: dbias (nullable, [cols]) additionally receives the column sums of dx as stored -- the
+ * bias gradient of the dense layer whose output x is -- in the same pass; it needs a workspace of
+ * tamd_colsum_workspace_bytes(rows, cols) bytes (workspace / workspace_bytes are ignored when dbias == NULL). */
+int tamd_bias_act_bwd(const void* x, const void* bias, const void* dy, void* dx, void* dbias, void* workspace,
+                      size_t workspace_bytes, int64_t rows, int64_t cols, int act, int dtype, tamd_stream_t stream);
 
 /* out = round(a + b) elementwise (residual adds, modeling_llama.py:317,323), n elements. */
 int tamd_add(const void* a, const void* b, void* out, int64_t n, int dtype, tamd_stream_t stream);
@@ -240,6 +246,23 @@ size_t tamd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags, int
 int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N, int64_t K,
                  int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act, int dtype,
                  void* workspace, size_t workspace_bytes, tamd_stream_t stream);
+
+/* ABI 8.  BertIntermediate / CLIPMLP.fc1 in train mode (models/bert/modeling_bert.py:334-337, models/clip/modeling_clip.py:
+ * 346-350): the activation AND the rounded pre-activation its backward needs, from ONE GEMM:
+ *   PRE[M,N] = round(A . B^T + bias)      Y[M,N] = round(act(PRE))
+ * -- the bits of tamd_gemm(TAMD_EPI_BIAS) followed by tamd_bias_act_fwd.  Operands and flags as tamd_gemm. */
+int tamd_gemm_bias_act_pre(const void* A, const void* B, void* Y, void* PRE, const void* bias, int64_t M, int64_t N,
+                           int64_t K, int64_t lda, int64_t ldb, int64_t ldy, int64_t ldpre, int flags, int act, int dtype,
+                           tamd_stream_t stream);
+
+/* ABI 8.  A projection whose leading columns leave scaled: the query columns of a fused q|k|v projection
+ * (models/bert/modeling_bert.py:175-177, models/clip/modeling_clip.py:304-318) carrying the attention kernels'
+ * scale*log2(e) BEFORE their one rounding (tamd_attn_params.q_prescaled; the counterpart of tamd_rope_inplace's q_scale
+ * for models without a rotary kernel):
+ *   C[m, n] = round((A . B^T [+ bias])[m, n] * (n < scale_cols ? col_scale : 1))        bias nullable; scale_cols % 4 == 0 */
+int tamd_gemm_colscale(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc, int flags, int64_t scale_cols, float col_scale, int dtype,
+                       tamd_stream_t stream);
 
 /* The gate|up projection of LlamaMLP with the SiLU*up product in the GEMM epilogue
  * (models/llama/modeling_llama.py:174-176: down_proj(act_fn(gate_proj(x)) * up_proj(x))):

@@ -866,3 +866,133 @@ def test_gemm_piece_placements_are_bit_identical(env):
                 lib.tamd_gemm_set_dbg(0)
     finally:
         lib.tamd_gemm_set_dbg(0)
+
+
+# ---- round 4: the bert-base fusions (one GEMM for activation + pre-activation, pre-scaled query columns, bias gradients
+# ---- accumulated by the kernels that produce the tensors they sum)
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm"])
+def test_gemm_bias_act_pre_is_bit_identical_to_gemm_plus_activation_kernel(env, sched):
+    """BertIntermediate in train mode (modeling_bert.py:334-337): tamd_gemm_bias_act_pre writes act(round(xW^T + b)) AND the
+    rounded pre-activation from one GEMM -- the bits of tamd_gemm(TAMD_EPI_BIAS) followed by tamd_bias_act_fwd, on every
+    kernel, ragged M / N included."""
+    import ctypes
+
+    from transformers_amd import _cabi
+
+    torch.manual_seed(71)
+    dev = env.device
+    be = ops.backend()
+    lib = be.lib
+    hint = {"pp": 1, "sm": 2, "fl": 3}[sched] << 8
+    for (m, n, k) in ([(4096, 3072, 768), (1000, 1032, 320), (577, 4096, 1024)] if env.big else
+                      [(264, 248, 128), (130, 520, 192), (72, 264, 64)]):
+        x = torch.randn(m, k).bfloat16().to(dev)
+        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+        b = torch.randn(n).bfloat16().to(dev)
+        for act in (ops.ACT_GELU_ERF, ops.ACT_QUICK_GELU):
+            y = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            pre = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            st = be.stream(x)
+            lib.check(lib.tamd_gemm_bias_act_pre(x.data_ptr(), w.data_ptr(), y.data_ptr(), pre.data_ptr(), b.data_ptr(), m, n, k,
+                                                 k, k, n, n, hint, act, _cabi.TAMD_BF16, ctypes.c_void_p(st) if st else None),
+                      "gemm_bias_act_pre")
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            pre_ref = ops.raw_gemm(x, w, bias=b, epilogue=ops.EPI_BIAS, sched=sched)
+            assert torch.equal(pre, pre_ref), (sched, m, n, k, act)
+            assert torch.equal(y, ops.raw_bias_act_fwd(pre_ref, None, act)), (sched, m, n, k, act)
+            assert torch.equal(y, ops.raw_gemm(x, w, bias=b, epilogue=ops.EPI_BIAS_ACT, act=act, sched=sched))
+    # the dispatcher op (default schedule)
+    y2, pre2 = torch.ops.tamd.gemm_bias_act_pre(x, w, b, ops.ACT_GELU_ERF)
+    assert torch.equal(pre2, ops.raw_gemm(x, w, bias=b, epilogue=ops.EPI_BIAS))
+    assert torch.equal(y2, ops.raw_bias_act_fwd(pre2, None, ops.ACT_GELU_ERF))
+
+
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm"])
+def test_gemm_colscale_scales_the_query_columns_before_their_one_rounding(env, sched):
+    """tamd_gemm_colscale (the q|k|v projection of BertSelfAttention, modeling_bert.py:175-177, delivering pre-scaled queries):
+    columns >= scale_cols carry the bits of the plain GEMM; the scaled columns are round((acc + bias) * s) -- closer to the
+    fp32 product than rounding first and scaling after, and exactly the plain result for s = 1 / a power of two."""
+    import ctypes
+
+    from transformers_amd import _cabi
+
+    torch.manual_seed(72)
+    dev = env.device
+    be = ops.backend()
+    lib = be.lib
+    hint = {"pp": 1, "sm": 2, "fl": 3}[sched] << 8
+    for (m, n, k, sc) in ([(4096, 2304, 768, 768), (1000, 1032, 320, 344)] if env.big else [(264, 248, 128, 80), (72, 264, 64, 264)]):
+        x = torch.randn(m, k).bfloat16().to(dev)
+        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
+        b = torch.randn(n).bfloat16().to(dev)
+        plain = ops.raw_gemm(x, w, bias=b, epilogue=ops.EPI_BIAS, sched=sched)
+        ref = x.float() @ w.float().t() + b.float()
+
+        def run(s, bias=b):
+            c = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
+            st = be.stream(x)
+            lib.check(lib.tamd_gemm_colscale(x.data_ptr(), w.data_ptr(), c.data_ptr(), None if bias is None else bias.data_ptr(),
+                                             m, n, k, k, k, n, hint, sc, s, _cabi.TAMD_BF16, ctypes.c_void_p(st) if st else None),
+                      "gemm_colscale")
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            return c
+
+        s = 0.125 * 1.4426950408889634
+        c = run(s)
+        assert torch.equal(c[:, sc:], plain[:, sc:])
+        e_pre = rel_err(c[:, :sc], ref[:, :sc] * s)
+        e_post = rel_err((plain[:, :sc].float() * s).bfloat16(), ref[:, :sc] * s)  # scale after rounding: two roundings
+        assert e_pre < 0.0034 and e_pre <= e_post * 1.001, (e_pre, e_post)
+        assert torch.equal(run(1.0), plain) and torch.equal(run(0.25)[:, :sc].float(), plain[:, :sc].float() * 0.25)
+        assert torch.equal(run(1.0, None), ops.raw_gemm(x, w, sched=sched))  # no bias
+    c2 = torch.ops.tamd.gemm_colscale(x, w, b, sc, s)
+    assert torch.equal(c2, c)
+
+
+@pytest.mark.parametrize("cols", [768, 1024])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_layernorm_backward_accumulates_the_dense_bias_gradient(env, cols, p):
+    """ABI 8: the LayerNorm backward of a post-LN block (modeling_bert.py:289-293) also returns the column sums of the
+    gradient it writes for the dense output -- dx without hidden dropout, dx_drop with -- i.e. the dense bias gradient,
+    without changing any other output."""
+    torch.manual_seed(73)
+    rows = 4096 if env.big else 37
+    dev = env.device
+    h = torch.randn(rows, cols).bfloat16().to(dev)
+    dy = torch.randn(rows, cols).bfloat16().to(dev)
+    w = (torch.rand(cols) + 0.5).bfloat16().to(dev)
+    mean = h.float().mean(-1)
+    rstd = (h.float().var(-1, unbiased=False) + 1e-12).rsqrt()
+    T = torch.ops.tamd
+    if p == 0.0:
+        dx, dw, db, dc = T.layernorm_bwd(dy, h, w, mean, rstd, None, True, True)
+        dx0, dw0, db0, none = T.layernorm_bwd(dy, h, w, mean, rstd, None, True, False)
+        src = dx
+    else:
+        seed = 0x5EED_1234
+        dx, dxd, dw, db, dc = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, p, seed, None, True, True)
+        dx0, dxd0, dw0, db0, none = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, p, seed, None, True, False)
+        assert torch.equal(dxd, dxd0)
+        src = dxd
+    assert none.numel() == 0 and torch.equal(dx, dx0) and torch.equal(dw, dw0) and torch.equal(db, db0)
+    want = src.float().sum(0)
+    assert rel_err(dc, want) < 0.0034  # (one output rounding; fp32 sums of the stored values)
+    assert rel_err(dc, ops.raw_colsum(src)) < 0.0034
+
+
+@pytest.mark.parametrize("act", ["gelu", "quick_gelu"])
+def test_bias_act_backward_accumulates_the_bias_gradient(env, act):
+    """ABI 8: tamd_bias_act_bwd with dbias returns dx (the bits of the plain kernel) and its column sums in one pass."""
+    torch.manual_seed(74)
+    rows, cols = (4100, 3072) if env.big else (37, 136)
+    dev = env.device
+    x = torch.randn(rows, cols).bfloat16().to(dev)
+    b = torch.randn(cols).bfloat16().to(dev)
+    dy = torch.randn(rows, cols).bfloat16().to(dev)
+    code = ops.ACT_CODES[act]
+    for bias in (None, b):
+        dx, db = ops.raw_bias_act_bwd(x, bias, dy, code, need_colsum=True)
+        assert torch.equal(dx, ops.raw_bias_act_bwd(x, bias, dy, code))
+        assert rel_err(db, dx.float().sum(0)) < 0.0034

@@ -14,7 +14,7 @@ TAMD_BF16, TAMD_F16, TAMD_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 GEMM_A_KM, GEMM_B_KN = 1, 2
 EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_BIAS_ACT, EPI_ACCUM = 0, 1, 2, 3, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 P = c_void_p
 I64 = c_int64
@@ -46,10 +46,10 @@ SIGNATURES = {
     "tamd_norm_bwd_workspace_bytes": (c_size_t, [I64, I64]),
     "tamd_rmsnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_int, P]),
     "tamd_layernorm_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_int, P]),
-    "tamd_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_int, P]),
+    "tamd_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_int, P]),
     "tamd_layernorm_dropout_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_float, ctypes.c_uint64, c_int, P]),
-    "tamd_layernorm_dropout_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_float, ctypes.c_uint64,
-                                           c_int, P]),
+    "tamd_layernorm_dropout_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_float,
+                                           ctypes.c_uint64, c_int, P]),
     "tamd_rope_inplace": (c_int, [P, P, P, I64, I64, I64, I64, I64, I64, c_int, I64, c_float, c_int, P]),
     "tamd_embedding_fwd": (c_int, [P, P, P, I64, I64, I64, P, c_int, P]),
     "tamd_embedding_bwd_workspace_bytes": (c_size_t, [I64, I64]),
@@ -59,7 +59,7 @@ SIGNATURES = {
     "tamd_swiglu_fwd": (c_int, [P, P, P, I64, I64, I64, I64, c_int, P]),
     "tamd_swiglu_bwd": (c_int, [P, P, P, P, P, P, I64, I64, I64, I64, c_int, P]),
     "tamd_bias_act_fwd": (c_int, [P, P, P, I64, I64, c_int, c_int, P]),
-    "tamd_bias_act_bwd": (c_int, [P, P, P, P, I64, I64, c_int, c_int, P]),
+    "tamd_bias_act_bwd": (c_int, [P, P, P, P, P, P, c_size_t, I64, I64, c_int, c_int, P]),
     "tamd_add": (c_int, [P, P, P, I64, c_int, P]),
     "tamd_adamw_step": (c_int, [P, P, P, P, I64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                 ctypes.c_double, I64, ctypes.c_double, c_int, c_int, P]),
@@ -72,6 +72,8 @@ SIGNATURES = {
     "tamd_gemm_workspace_bytes": (c_size_t, [I64, I64, I64, c_int, c_int]),
     "tamd_gemm_ws": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P, c_size_t,
                              P]),
+    "tamd_gemm_bias_act_pre": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, P]),
+    "tamd_gemm_colscale": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, I64, c_float, c_int, P]),
     "tamd_gemm_swiglu": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_gemm_rope": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),

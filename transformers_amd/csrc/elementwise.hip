@@ -6,6 +6,7 @@
 // reference's intermediate roundings where the reference computes in the storage dtype,
 // and never synchronise or allocate.
 #include "common.h"
+#include "colsum.h"
 
 namespace tamd {
 
@@ -359,6 +360,41 @@ __global__ void bias_act_kernel(const T* __restrict__ x, const T* __restrict__ b
     }
     st16(out + idx * VE, pack16<T>(o));
   }
+}
+
+// dx = dy * act'(x [+ bias]) AND the column sums of dx as stored (the bias gradient of the dense layer whose output x is:
+// BertIntermediate's, models/bert/modeling_bert.py:334-337) in one pass: a thread owns ONE 16-byte column vector and walks
+// a slab of rows (blockIdx.y), so the sums stay in its registers; partial [gridDim.y, cols] fp32 -> colsum_f32_kernel.
+template <typename T, int ACT>
+__global__ void bias_act_bwd_colsum_kernel(const T* __restrict__ x, const T* __restrict__ bias, const T* __restrict__ dy,
+                                           T* __restrict__ out, float* __restrict__ part, int64_t rows, int cols,
+                                           int rows_per_slab) {
+  constexpr int VE = vec16<T>::N;
+  const int col = (blockIdx.x * blockDim.x + threadIdx.x) * VE;
+  if (col >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r1 = (r0 + rows_per_slab < rows) ? r0 + rows_per_slab : rows;
+  float acc[VE], b[VE];
+#pragma unroll
+  for (int i = 0; i < VE; ++i) acc[i] = 0.f, b[i] = 0.f;
+  if (bias != nullptr) unpack16<T>(ld16(bias + col), b);
+  for (int64_t r = r0; r < r1; ++r) {
+    float v[VE], d[VE], o[VE];
+    unpack16<T>(ld16(x + r * cols + col), v);
+    unpack16<T>(ld16(dy + r * cols + col), d);
+    if (bias != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VE; ++i) v[i] = round_through<T>(v[i] + b[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+      o[i] = d[i] * dact_f<ACT>(v[i]);
+      acc[i] += round_through<T>(o[i]);
+    }
+    st16(out + r * cols + col, pack16<T>(o));
+  }
+#pragma unroll
+  for (int i = 0; i < VE; ++i) part[(int64_t)blockIdx.y * cols + col + i] = acc[i];
 }
 
 template <typename T>
@@ -736,13 +772,40 @@ int tamd_bias_act_fwd(const void* x, const void* bias, void* y, int64_t rows, in
   return launch_status();
 }
 
-int tamd_bias_act_bwd(const void* x, const void* bias, const void* dy, void* dx, int64_t rows, int64_t cols,
-                      int act, int dtype, tamd_stream_t stream) {
+#define TAMD_BC(A_)                                                                                                    \
+  hipLaunchKernelGGL((bias_act_bwd_colsum_kernel<T, A_>), grid, block, 0, s, (const T*)x, (const T*)bias, (const T*)dy, \
+                     (T*)out, part, rows, (int)cols, rows_per_slab);                                                   \
+  break;
+int tamd_bias_act_bwd(const void* x, const void* bias, const void* dy, void* dx, void* dbias, void* workspace,
+                      size_t workspace_bytes, int64_t rows, int64_t cols, int act, int dtype, tamd_stream_t stream) {
   if (!x || !dy || !dx) return TAMD_E_NULL;
   if (rows <= 0 || cols <= 0) return TAMD_OK;
   if (!aligned16(x) || !aligned16(dy) || !aligned16(dx) || (bias && !aligned16(bias))) return TAMD_E_ALIGN;
   hipStream_t s = TAMD_STREAM(stream);
   void* out = dx;
+  if (dbias != nullptr) {  // + the column sums of dx (tamd_colsum's workspace and partial layout)
+    if (!workspace) return TAMD_E_NULL;
+    if (workspace_bytes < tamd_colsum_workspace_bytes(rows, cols)) return TAMD_E_WORKSPACE;
+    int rows_per_slab = (int)ceil_div(rows, kNormMaxPartials);
+    if (rows_per_slab < 16) rows_per_slab = 16;
+    const int P = (int)ceil_div(rows, rows_per_slab);
+    float* part = reinterpret_cast<float*>(workspace);
+    TAMD_DISPATCH_DTYPE(dtype, {
+      constexpr int VE = vec16<T>::N;
+      if (cols % VE != 0) return TAMD_E_SHAPE;
+      dim3 grid((unsigned)ceil_div(cols / VE, 128), (unsigned)P), block(128);
+      switch (act) {
+        case TAMD_ACT_NONE: TAMD_BC(TAMD_ACT_NONE)
+        case TAMD_ACT_GELU_ERF: TAMD_BC(TAMD_ACT_GELU_ERF)
+        case TAMD_ACT_GELU_TANH: TAMD_BC(TAMD_ACT_GELU_TANH)
+        case TAMD_ACT_QUICK_GELU: TAMD_BC(TAMD_ACT_QUICK_GELU)
+        case TAMD_ACT_SILU: TAMD_BC(TAMD_ACT_SILU)
+        default: return TAMD_E_ARG;
+      }
+      colsum_partials_reduce<T>(part, dbias, P, (int)cols, s);
+    });
+    return launch_status();
+  }
   TAMD_DISPATCH_DTYPE(dtype, {
     constexpr int VE = vec16<T>::N;
     if (cols % VE != 0) return TAMD_E_SHAPE;

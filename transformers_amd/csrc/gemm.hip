@@ -37,6 +37,8 @@
 //                   256 x 256 grid cannot spread over the GPU (a CLIP tower's 577 tokens)
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace tamd {
@@ -90,10 +92,15 @@ struct GemmArgs {
   // rotary epilogue (kEpiRope): R = cos, C2 = sin ([cos_batch, seq, 128] in the storage dtype), n_half = the leading
   // columns to rotate (query + key heads, a multiple of 128), seq / cos_batch below
   int64_t seq, cos_batch;
+  // column-scale epilogue (kEpiColScale): C[m, n] = round((acc + bias[n]) * (n < scale_cols ? col_scale : 1)) -- the query
+  // columns of a q|k|v projection leave carrying the attention kernels' scale*log2(e) (tamd_attn_params.q_prescaled)
+  int64_t scale_cols;
+  float col_scale;
 };
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
 constexpr int kEpiRope = 103;
+constexpr int kEpiColScale = 104;
 
 // the LlamaMLP inner product (models/llama/modeling_llama.py:174-176; same expression as swiglu_fwd_kernel in
 // elementwise.hip, so the fused epilogue and the stand-alone kernel agree bit for bit)
@@ -285,7 +292,7 @@ template <typename T, int EPI>
 __device__ __forceinline__ void gemm_bias4(const GemmArgs& g, int64_t gn, float* bv) {
   bv[0] = bv[1] = bv[2] = bv[3] = 0.f;
   const T* bias = reinterpret_cast<const T*>(g.bias);
-  if (EPI == TAMD_EPI_BIAS || EPI == TAMD_EPI_BIAS_ACT || (EPI == TAMD_EPI_RESIDUAL && bias != nullptr)) {
+  if (EPI == TAMD_EPI_BIAS || EPI == TAMD_EPI_BIAS_ACT || ((EPI == TAMD_EPI_RESIDUAL || EPI == kEpiColScale) && bias != nullptr)) {
     if (gn < g.N) {  // N % 8 == 0 and gn % 4 == 0: the 4 columns are valid together
       const u32x2 bq = ld8(bias + gn);
       bv[0] = elem<T>::to_f32((typename elem<T>::raw)(bq[0] & 0xffffu));
@@ -296,14 +303,33 @@ __device__ __forceinline__ void gemm_bias4(const GemmArgs& g, int64_t gn, float*
   }
 }
 // 4 accumulator values of one output row -> rounded (+bias, +activation) -> 8 staged bytes
+// (sc: the column-scale epilogue's factor of these 4 columns, applied BEFORE the one rounding)
 template <typename T, int EPI, int ACT>
-__device__ __forceinline__ u32x2 gemm_round4(float a0, float a1, float a2, float a3, const float* bv) {
+__device__ __forceinline__ u32x2 gemm_round4(float a0, float a1, float a2, float a3, const float* bv, float sc = 1.f) {
   float v[4] = {a0 + bv[0], a1 + bv[1], a2 + bv[2], a3 + bv[3]};
   if (EPI == TAMD_EPI_BIAS_ACT) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = gemm_act<ACT>(round_through<T>(v[e]));
   }
+  if (EPI == kEpiColScale) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= sc;
+  }
   return u32x2{pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3])};
+}
+// factor of the 4 consecutive columns starting at gn (scale_cols % 4 == 0: they are scaled together)
+template <int EPI>
+__device__ __forceinline__ float gemm_colscale4(const GemmArgs& g, int64_t gn) {
+  return (EPI == kEpiColScale && gn < g.scale_cols) ? g.col_scale : 1.f;
+}
+// TAMD_EPI_BIAS_ACT with a second output (GemmArgs.C2 / ldc2): the rounded pre-activation round(acc + bias) -- what the
+// activation's backward needs -- leaves through the same way out first (BertIntermediate in train mode: one GEMM instead
+// of GEMM + activation kernel, models/bert/modeling_bert.py:334-337)
+__device__ __forceinline__ GemmArgs gemm_pre_args(const GemmArgs& g) {
+  GemmArgs p = g;
+  p.C = g.C2;
+  p.ldc = g.ldc2;
+  return p;
 }
 
 // 32x32x16 accumulators (gemm_pp_kernel): acc[ni][mi][r] = D[n = ni*32 + (r&3) + 8*(r>>2) + 4*hi][m = mi*32 + l31]
@@ -312,24 +338,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
                                               int64_t row0, int64_t col0, int lane) {
   constexpr int ROWB = NI * 32 * 2 + 16;
   const int hi = lane >> 5, l31 = lane & 31;
-  gemm_epilogue_rows<T, EPI, ACT, NI * 32, MI / 2>(g, smem, st_off, row0, col0, lane, [&](int half) {
+  auto stage_as = [&](auto epi_tag, int half) {
+    constexpr int E = decltype(epi_tag)::value;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int nl = ni * 32 + 8 * qd + 4 * hi;  // first of 4 consecutive local columns
         float bv[4];
-        gemm_bias4<T, EPI>(g, col0 + nl, bv);
+        gemm_bias4<T, E>(g, col0 + nl, bv);
+        const float sc = gemm_colscale4<E>(g, col0 + nl);
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) {
           const int mi = half * 2 + m2;
           lds_write8(smem, st_off + (unsigned)(m2 * 32 + l31) * ROWB + (unsigned)nl * 2u,
-                     gemm_round4<T, EPI, ACT>(acc[ni][mi][qd * 4 + 0], acc[ni][mi][qd * 4 + 1], acc[ni][mi][qd * 4 + 2],
-                                              acc[ni][mi][qd * 4 + 3], bv));
+                     gemm_round4<T, E, ACT>(acc[ni][mi][qd * 4 + 0], acc[ni][mi][qd * 4 + 1], acc[ni][mi][qd * 4 + 2],
+                                            acc[ni][mi][qd * 4 + 3], bv, sc));
         }
       }
     }
-  });
+  };
+  if (EPI == TAMD_EPI_BIAS_ACT && g.C2 != nullptr) {
+    const GemmArgs gp = gemm_pre_args(g);
+    gemm_epilogue_rows<T, TAMD_EPI_BIAS, ACT, NI * 32, MI / 2>(gp, smem, st_off, row0, col0, lane, [&](int half) {
+      stage_as(std::integral_constant<int, TAMD_EPI_BIAS>{}, half);
+    });
+  }
+  gemm_epilogue_rows<T, EPI, ACT, NI * 32, MI / 2>(g, smem, st_off, row0, col0, lane,
+                                                   [&](int half) { stage_as(std::integral_constant<int, EPI>{}, half); });
 }
 
 // 16x16x32 accumulators (gemm_fl_kernel): acc[nb][mb][r] = D[n = nb*16 + 4*(lane>>4) + r][m = mb*16 + (lane&15)],
@@ -339,20 +375,30 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, f32x4 (&acc)[
                                                 int64_t row0, int64_t col0, int lane) {
   constexpr int ROWB = 128 * 2 + 16;
   const int g4 = lane >> 4, l15 = lane & 15;
-  gemm_epilogue_rows<T, EPI, ACT, 128, 2>(g, smem, st_off, row0, col0, lane, [&](int half) {
+  auto stage_as = [&](auto epi_tag, int half) {
+    constexpr int E = decltype(epi_tag)::value;
 #pragma unroll
     for (int nb = 0; nb < 8; ++nb) {
       const int nl = nb * 16 + 4 * g4;  // first of 4 consecutive local columns
       float bv[4];
-      gemm_bias4<T, EPI>(g, col0 + nl, bv);
+      gemm_bias4<T, E>(g, col0 + nl, bv);
+      const float sc = gemm_colscale4<E>(g, col0 + nl);
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4) {
         const f32x4 a = acc[nb][half * 4 + m4];
         lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
-                   gemm_round4<T, EPI, ACT>(a[0], a[1], a[2], a[3], bv));
+                   gemm_round4<T, E, ACT>(a[0], a[1], a[2], a[3], bv, sc));
       }
     }
-  });
+  };
+  if (EPI == TAMD_EPI_BIAS_ACT && g.C2 != nullptr) {
+    const GemmArgs gp = gemm_pre_args(g);
+    gemm_epilogue_rows<T, TAMD_EPI_BIAS, ACT, 128, 2>(gp, smem, st_off, row0, col0, lane, [&](int half) {
+      stage_as(std::integral_constant<int, TAMD_EPI_BIAS>{}, half);
+    });
+  }
+  gemm_epilogue_rows<T, EPI, ACT, 128, 2>(g, smem, st_off, row0, col0, lane,
+                                          [&](int half) { stage_as(std::integral_constant<int, EPI>{}, half); });
 }
 
 // SwiGLU epilogue of one wave of gemm_fl_kernel<..., kEpiSwiGLU>.  The tile's 256 B-rows are 8 blocks of 32 weight rows,
@@ -938,6 +984,7 @@ static int gemm_diag_dbg() {
     case TAMD_EPI_BIAS: LAUNCH(TAMD_EPI_BIAS, TAMD_ACT_NONE)              \
     case TAMD_EPI_RESIDUAL: LAUNCH(TAMD_EPI_RESIDUAL, TAMD_ACT_NONE)      \
     case TAMD_EPI_ACCUM: LAUNCH(TAMD_EPI_ACCUM, TAMD_ACT_NONE)            \
+    case kEpiColScale: LAUNCH(kEpiColScale, TAMD_ACT_NONE)                \
     case TAMD_EPI_BIAS_ACT:                                               \
       switch (act) {                                                      \
         case TAMD_ACT_GELU_ERF: LAUNCH(TAMD_EPI_BIAS_ACT, TAMD_ACT_GELU_ERF)     \
@@ -1097,6 +1144,8 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->n_half = 0;
   g->seq = 1;
   g->cos_batch = 1;
+  g->scale_cols = 0;
+  g->col_scale = 1.f;
   return TAMD_OK;
 }
 
@@ -1162,10 +1211,9 @@ extern "C" int tamd_gemm(const void* A, const void* B, void* C, const void* bias
   return tamd_gemm_ws(A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr, flags, epilogue, act, dtype, nullptr, 0, stream);
 }
 
-extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M,
-                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags,
-                            int epilogue, int act, int dtype, void* workspace, size_t workspace_bytes,
-                            tamd_stream_t stream) {
+// argument checks shared by the plain-GEMM entry points
+static int gemm_check(const void* A, const void* B, const void* C, const void* bias, const void* R, int64_t M, int64_t N,
+                      int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue) {
   if (!A || !B || !C) return TAMD_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0) return TAMD_E_SHAPE;
   // 16-byte accesses run along the contiguous dimension of each operand: K for a row-major operand, M (A) / N (B)
@@ -1178,10 +1226,15 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
   if ((epilogue == TAMD_EPI_BIAS || epilogue == TAMD_EPI_BIAS_ACT) && !bias) return TAMD_E_NULL;
   if (bias && (reinterpret_cast<uintptr_t>(bias) & 7u)) return TAMD_E_ALIGN;
   if (epilogue == TAMD_EPI_RESIDUAL && (!R || (ldr % 8) || !aligned16(R))) return R ? TAMD_E_ALIGN : TAMD_E_NULL;
-  GemmArgs g;
-  gemm_fill_args(&g, A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr);
-  // schedule: the full-line kernel whenever K % 64 == 0, else the ping-pong kernel.  TAMD_GEMM=pp in the
-  // environment or a TAMD_GEMM_SCHED_* hint in `flags` forces one (A/B measurements, tests).
+  return TAMD_OK;
+}
+
+// kernel selection for a filled GemmArgs: split-K (when a workspace allows it), the 128 x 128 tile for small row-major
+// grids, the full-line kernel whenever K % 64 == 0, else the ping-pong kernel.  TAMD_GEMM=pp in the environment or a
+// TAMD_GEMM_SCHED_* hint in `flags` forces one (A/B measurements, tests).
+static int gemm_run(GemmArgs& g, int flags, int epilogue, int act, int dtype, void* workspace, size_t workspace_bytes,
+                    tamd_stream_t stream) {
+  const int64_t M = g.M, N = g.N, K = g.K;
   static const int forced = [] {
     const char* e = getenv("TAMD_GEMM");
     return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 's' ? 2 : 0)));
@@ -1210,6 +1263,52 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
     TAMD_DISPATCH_HALF(dtype, return (gemm_pp_launch<T>(g, flags, epilogue, act, TAMD_STREAM(stream))));
   }
   return TAMD_E_DTYPE;
+}
+
+extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M,
+                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags,
+                            int epilogue, int act, int dtype, void* workspace, size_t workspace_bytes,
+                            tamd_stream_t stream) {
+  const int st = gemm_check(A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr, flags, epilogue);
+  if (st != TAMD_OK) return st;
+  if (epilogue < TAMD_EPI_NONE || epilogue > TAMD_EPI_ACCUM) return TAMD_E_ARG;
+  GemmArgs g;
+  gemm_fill_args(&g, A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr);
+  return gemm_run(g, flags, epilogue, act, dtype, workspace, workspace_bytes, stream);
+}
+
+// BertIntermediate / CLIPMLP.fc1 / GPT2MLP.c_fc in train mode (models/bert/modeling_bert.py:334-337): the activation AND the
+// rounded pre-activation its backward needs, from one GEMM:
+//   PRE[M,N] = round(A . B^T + bias)      Y[M,N] = round(act(PRE))        -- the bits of tamd_gemm(TAMD_EPI_BIAS) followed by
+// tamd_bias_act_fwd (= of tamd_gemm(TAMD_EPI_BIAS_ACT) for Y)
+extern "C" int tamd_gemm_bias_act_pre(const void* A, const void* B, void* Y, void* PRE, const void* bias, int64_t M,
+                                      int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldy, int64_t ldpre, int flags,
+                                      int act, int dtype, tamd_stream_t stream) {
+  const int st = gemm_check(A, B, Y, bias, nullptr, M, N, K, lda, ldb, ldy, 0, flags, TAMD_EPI_BIAS_ACT);
+  if (st != TAMD_OK) return st;
+  if (!PRE) return TAMD_E_NULL;
+  if ((ldpre % 8) || !aligned16(PRE)) return (ldpre % 8) ? TAMD_E_SHAPE : TAMD_E_ALIGN;
+  GemmArgs g;
+  gemm_fill_args(&g, A, B, Y, bias, nullptr, M, N, K, lda, ldb, ldy, 0);
+  g.C2 = PRE;
+  g.ldc2 = ldpre;
+  return gemm_run(g, flags, TAMD_EPI_BIAS_ACT, act, dtype, nullptr, 0, stream);
+}
+
+// A projection whose leading columns leave scaled (the query columns of a fused q|k|v projection, models/bert/
+// modeling_bert.py:175-177, carrying the attention kernels' scale*log2(e): tamd_attn_params.q_prescaled):
+//   C[m, n] = round((A . B^T [+ bias])[m, n] * (n < scale_cols ? col_scale : 1))      -- ONE rounding, like the reference's q
+extern "C" int tamd_gemm_colscale(const void* A, const void* B, void* C, const void* bias, int64_t M, int64_t N, int64_t K,
+                                  int64_t lda, int64_t ldb, int64_t ldc, int flags, int64_t scale_cols, float col_scale,
+                                  int dtype, tamd_stream_t stream) {
+  const int st = gemm_check(A, B, C, bias, nullptr, M, N, K, lda, ldb, ldc, 0, flags, TAMD_EPI_NONE);
+  if (st != TAMD_OK) return st;
+  if (scale_cols < 0 || scale_cols > N || (scale_cols % 4)) return TAMD_E_SHAPE;
+  GemmArgs g;
+  gemm_fill_args(&g, A, B, C, bias, nullptr, M, N, K, lda, ldb, ldc, 0);
+  g.scale_cols = scale_cols;
+  g.col_scale = col_scale;
+  return gemm_run(g, flags, kEpiColScale, TAMD_ACT_NONE, dtype, nullptr, 0, stream);
 }
 
 // gate|up projection of LlamaMLP with the SiLU*up product in the GEMM epilogue (models/llama/modeling_llama.py:174-176):

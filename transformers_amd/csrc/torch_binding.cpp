@@ -43,7 +43,7 @@ using OptTensor = std::optional<at::Tensor>;
   X(tamd_bert_embeddings_fwd) X(tamd_swiglu_fwd) X(tamd_swiglu_bwd) X(tamd_bias_act_fwd) X(tamd_bias_act_bwd)         \
   X(tamd_add) X(tamd_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
   X(tamd_cross_entropy_fwd) X(tamd_cross_entropy_bwd) X(tamd_gemm) X(tamd_gemm_workspace_bytes) X(tamd_gemm_ws)       \
-  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_attn_fwd) X(tamd_attn_bwd)
+  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_attn_fwd) X(tamd_attn_bwd)
 
 struct Api {
   void* handle = nullptr;
@@ -130,6 +130,13 @@ struct GemmTimerScope {
   GemmTimerScope(double flops, double bytes, tamd_stream_t stream)
       : on(g_gemm_log.load(std::memory_order_relaxed) && !api().emulated), s((hipStream_t)stream) {
     if (!on) return;
+    // a launch being captured into a HIP graph (graph_stack.py, a user's torch.cuda.graph) has no duration of its own:
+    // an event recorded there becomes a graph node and hipEventElapsedTime on it fails
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+      on = false;
+      return;
+    }
     rec.flops = flops;
     rec.bytes = bytes;
     if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) {
@@ -201,9 +208,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_fwd(const Tensor& x, cons
   return {y.view(x.sizes()), h.view(x.sizes()), mean, rstd};
 }
 
-// -> (dx, dw, db or undefined)
-std::tuple<Tensor, Tensor, Tensor> k_layernorm_bwd(const Tensor& dy, const Tensor& h, const Tensor& w_, const Tensor& mean,
-                                                   const Tensor& rstd, const OptTensor& dres, bool need_db) {
+// -> (dx, dw, db or undefined, column sums of dx or undefined)
+std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_bwd(const Tensor& dy, const Tensor& h, const Tensor& w_,
+                                                           const Tensor& mean, const Tensor& rstd, const OptTensor& dres,
+                                                           bool need_db, bool need_colsum = false) {
   const int64_t cols = h.size(-1);
   Tensor dy2 = contig(dy).view({-1, cols}), h2 = contig(h).view({-1, cols});
   Tensor dr2 = dres ? contig(*dres).view({-1, cols}) : Tensor();
@@ -212,12 +220,14 @@ std::tuple<Tensor, Tensor, Tensor> k_layernorm_bwd(const Tensor& dy, const Tenso
   const int64_t rows = h2.size(0);
   Tensor dx = at::empty_like(h2), dw = at::empty_like(w);
   Tensor db = need_db ? at::empty_like(w) : Tensor();
+  Tensor dc = need_colsum ? at::empty_like(w) : Tensor();
   const size_t nbytes = api().tamd_norm_bwd_workspace_bytes(rows, cols);
   Tensor ws = at::empty({(int64_t)nbytes}, h.options().dtype(at::kByte));
   check(api().tamd_layernorm_bwd(ptr(dy2), ptr(h2), ptr(w), (const float*)ptr(mean), (const float*)ptr(rstd), ptr(dr2),
-                                 mptr(dx), mptr(dw), mptr(db), mptr(ws), nbytes, rows, cols, code_of(h2), L.stream),
+                                 mptr(dx), mptr(dw), mptr(db), mptr(dc), mptr(ws), nbytes, rows, cols, code_of(h2),
+                                 L.stream),
         "tamd_layernorm_bwd");
-  return {dx.view(h.sizes()), dw, db};
+  return {dx.view(h.sizes()), dw, db, dc};
 }
 
 // h = dropout(x, p) + residual; y = LayerNorm(h)  ->  (y, h, mean, rstd)
@@ -238,10 +248,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_fwd(const Tensor&
   return {y.view(x.sizes()), h.view(x.sizes()), mean, rstd};
 }
 
-// -> (dx = gradient of the residual input, dxd = gradient of the dropped-out input, dw, db or undefined)
-std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_bwd(const Tensor& dy, const Tensor& h, const Tensor& w_,
-                                                                   const Tensor& mean, const Tensor& rstd, double dropout_p,
-                                                                   int64_t seed, const OptTensor& dres, bool need_db) {
+// -> (dx = gradient of the residual input, dxd = gradient of the dropped-out input, dw, db or undefined, column sums of dxd
+//     or undefined)
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_bwd(const Tensor& dy, const Tensor& h, const Tensor& w_,
+                                                                           const Tensor& mean, const Tensor& rstd,
+                                                                           double dropout_p, int64_t seed,
+                                                                           const OptTensor& dres, bool need_db,
+                                                                           bool need_colsum = false) {
   const int64_t cols = h.size(-1);
   Tensor dy2 = contig(dy).view({-1, cols}), h2 = contig(h).view({-1, cols});
   Tensor dr2 = dres ? contig(*dres).view({-1, cols}) : Tensor();
@@ -250,13 +263,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_bwd(const Tensor&
   const int64_t rows = h2.size(0);
   Tensor dx = at::empty_like(h2), dxd = at::empty_like(h2), dw = at::empty_like(w);
   Tensor db = need_db ? at::empty_like(w) : Tensor();
+  Tensor dc = need_colsum ? at::empty_like(w) : Tensor();
   const size_t nbytes = api().tamd_norm_bwd_workspace_bytes(rows, cols);
   Tensor ws = at::empty({(int64_t)nbytes}, h.options().dtype(at::kByte));
   check(api().tamd_layernorm_dropout_bwd(ptr(dy2), ptr(h2), ptr(w), (const float*)ptr(mean), (const float*)ptr(rstd),
-                                         ptr(dr2), mptr(dx), mptr(dxd), mptr(dw), mptr(db), mptr(ws), nbytes, rows, cols,
-                                         (float)dropout_p, (uint64_t)seed, code_of(h2), L.stream),
+                                         ptr(dr2), mptr(dx), mptr(dxd), mptr(dw), mptr(db), mptr(dc), mptr(ws), nbytes, rows,
+                                         cols, (float)dropout_p, (uint64_t)seed, code_of(h2), L.stream),
         "tamd_layernorm_dropout_bwd");
-  return {dx.view(h.sizes()), dxd.view(h.sizes()), dw, db};
+  return {dx.view(h.sizes()), dxd.view(h.sizes()), dw, db, dc};
 }
 
 // in-place rotary on the first `nheads` heads of every row of x2d [tokens, row_stride]; the first `q_heads` of them leave
@@ -370,14 +384,23 @@ Tensor k_bias_act_fwd(const Tensor& x, const OptTensor& bias, int64_t act) {
   return y.view(x.sizes());
 }
 
-Tensor k_bias_act_bwd(const Tensor& x, const OptTensor& bias, const Tensor& dy, int64_t act) {
+// -> (dx, column sums of dx [cols] or undefined)
+std::tuple<Tensor, Tensor> k_bias_act_bwd(const Tensor& x, const OptTensor& bias, const Tensor& dy, int64_t act,
+                                          bool need_colsum = false) {
   Tensor x2 = contig(x).view({-1, x.size(-1)}), dy2 = contig(dy).view({-1, x.size(-1)});
   Launch L({&x2, p(bias), &dy2});
   Tensor dx = at::empty_like(x2);
-  check(api().tamd_bias_act_bwd(ptr(x2), ptr(bias), ptr(dy2), mptr(dx), x2.size(0), x2.size(1), (int)act, code_of(x2),
-                                L.stream),
+  Tensor dc, ws;
+  size_t nbytes = 0;
+  if (need_colsum) {
+    dc = at::empty({x2.size(1)}, x2.options());
+    nbytes = api().tamd_colsum_workspace_bytes(x2.size(0), x2.size(1));
+    ws = at::empty({(int64_t)nbytes}, x2.options().dtype(at::kByte));
+  }
+  check(api().tamd_bias_act_bwd(ptr(x2), ptr(bias), ptr(dy2), mptr(dx), mptr(dc), mptr(ws), nbytes, x2.size(0), x2.size(1),
+                                (int)act, code_of(x2), L.stream),
         "tamd_bias_act_bwd");
-  return dx.view(x.sizes());
+  return {dx.view(x.sizes()), dc};
 }
 
 Tensor k_add(const Tensor& a_, const Tensor& b_) {
@@ -507,6 +530,35 @@ Tensor gemm_plain(const Tensor& a, const Tensor& b, bool a_km = false, bool b_kn
                   const OptTensor& residual = {}, int64_t epilogue = TAMD_EPI_NONE, int64_t act = TAMD_ACT_NONE,
                   const OptTensor& out = {}) {
   return k_gemm(a, b, a_km, b_kn, bias, residual, epilogue, act, out, 0);
+}
+
+// (y, pre) = (act(round(x2 . w^T + bias)), round(x2 . w^T + bias)) from one GEMM (tamd_gemm_bias_act_pre)
+std::tuple<Tensor, Tensor> k_gemm_bias_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
+  Launch L({&x2, &w, &bias});
+  TORCH_CHECK(x2.dim() == 2 && w.dim() == 2 && x2.stride(1) == 1 && w.stride(1) == 1 && x2.size(1) == w.size(1),
+              "tamd: gemm_bias_act_pre takes row-major x [M, K] and w [N, K]");
+  const int64_t m = x2.size(0), n = w.size(0), k = x2.size(1);
+  Tensor y = at::empty({m, n}, x2.options()), pre = at::empty({m, n}, x2.options());
+  GemmTimerScope timer(2.0 * (double)m * (double)n * (double)k, 2.0 * ((double)m * k + (double)n * k + 2.0 * (double)m * n),
+                       L.stream);
+  check(api().tamd_gemm_bias_act_pre(ptr(x2), ptr(w), mptr(y), mptr(pre), ptr(bias), m, n, k, x2.stride(0), w.stride(0), n, n,
+                                     0, (int)act, code_of(x2), L.stream),
+        "tamd_gemm_bias_act_pre");
+  return {y, pre};
+}
+
+// x2 . w^T (+ bias) with the first scale_cols columns multiplied by col_scale before the one rounding (tamd_gemm_colscale)
+Tensor k_gemm_colscale(const Tensor& x2, const Tensor& w, const OptTensor& bias, int64_t scale_cols, double col_scale) {
+  Launch L({&x2, &w, p(bias)});
+  TORCH_CHECK(x2.dim() == 2 && w.dim() == 2 && x2.stride(1) == 1 && w.stride(1) == 1 && x2.size(1) == w.size(1),
+              "tamd: gemm_colscale takes row-major x [M, K] and w [N, K]");
+  const int64_t m = x2.size(0), n = w.size(0), k = x2.size(1);
+  Tensor y = at::empty({m, n}, x2.options());
+  GemmTimerScope timer(2.0 * (double)m * (double)n * (double)k, 2.0 * ((double)m * k + (double)n * k + (double)m * n), L.stream);
+  check(api().tamd_gemm_colscale(ptr(x2), ptr(w), mptr(y), ptr(bias), m, n, k, x2.stride(0), w.stride(0), n, 0, scale_cols,
+                                 (float)col_scale, code_of(x2), L.stream),
+        "tamd_gemm_colscale");
+  return y;
 }
 
 bool half_type(const Tensor& t) { return t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf; }
@@ -685,16 +737,30 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> op_layernorm_fwd(const Tensor& x, con
   auto [y, h, mean, rstd] = k_layernorm_fwd(x, w, b, eps, residual);
   return {y, residual ? h : nothing(x), mean, rstd};
 }
-std::tuple<Tensor, Tensor, Tensor> op_layernorm_bwd(const Tensor& dy, const Tensor& h, const Tensor& w, const Tensor& mean,
-                                                    const Tensor& rstd, const OptTensor& dres, bool need_db) {
-  auto [dx, dw, db] = k_layernorm_bwd(dy, h, w, mean, rstd, dres, need_db);
-  return {dx, dw, db.defined() ? db : nothing(w)};
+std::tuple<Tensor, Tensor, Tensor, Tensor> op_layernorm_bwd(const Tensor& dy, const Tensor& h, const Tensor& w,
+                                                            const Tensor& mean, const Tensor& rstd, const OptTensor& dres,
+                                                            bool need_db, bool need_colsum) {
+  auto [dx, dw, db, dc] = k_layernorm_bwd(dy, h, w, mean, rstd, dres, need_db, need_colsum);
+  return {dx, dw, db.defined() ? db : nothing(w), dc.defined() ? dc : nothing(w)};
 }
-std::tuple<Tensor, Tensor, Tensor, Tensor> op_layernorm_dropout_bwd(const Tensor& dy, const Tensor& h, const Tensor& w,
-                                                                    const Tensor& mean, const Tensor& rstd, double dropout_p,
-                                                                    int64_t seed, const OptTensor& dres, bool need_db) {
-  auto [dx, dxd, dw, db] = k_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres, need_db);
-  return {dx, dxd, dw, db.defined() ? db : nothing(w)};
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> op_layernorm_dropout_bwd(const Tensor& dy, const Tensor& h, const Tensor& w,
+                                                                            const Tensor& mean, const Tensor& rstd,
+                                                                            double dropout_p, int64_t seed,
+                                                                            const OptTensor& dres, bool need_db,
+                                                                            bool need_colsum) {
+  auto [dx, dxd, dw, db, dc] = k_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres, need_db, need_colsum);
+  return {dx, dxd, dw, db.defined() ? db : nothing(w), dc.defined() ? dc : nothing(w)};
+}
+std::tuple<Tensor, Tensor> op_bias_act_bwd(const Tensor& x, const OptTensor& bias, const Tensor& dy, int64_t act,
+                                           bool need_colsum) {
+  auto [dx, dc] = k_bias_act_bwd(x, bias, dy, act, need_colsum);
+  return {dx, dc.defined() ? dc : nothing(x)};
+}
+std::tuple<Tensor, Tensor> op_gemm_bias_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
+  return k_gemm_bias_act_pre(x2, w, bias, act);
+}
+Tensor op_gemm_colscale(const Tensor& x2, const Tensor& w, const OptTensor& bias, int64_t scale_cols, double col_scale) {
+  return k_gemm_colscale(x2, w, bias, scale_cols, col_scale);
 }
 void op_rope_(Tensor& x2d, const Tensor& cos, const Tensor& sin, int64_t seq, int64_t nheads, int64_t head_dim, bool conj) {
   k_rope_(x2d, cos, sin, seq, nheads, head_dim, conj);
@@ -799,9 +865,8 @@ std::tuple<Tensor, Tensor> op_linear(const Tensor& x, const Tensor& w, const Opt
     epi = TAMD_EPI_BIAS;
   }
   Tensor pre, y;
-  if (epi == TAMD_EPI_BIAS_ACT && train) {  // keep the pre-activation for the backward: GEMM+bias, then the activation kernel
-    pre = gemm_plain(x2, w, false, false, bias, {}, TAMD_EPI_BIAS);
-    y = k_bias_act_fwd(pre, {}, act);
+  if (epi == TAMD_EPI_BIAS_ACT && train) {  // the pre-activation is kept for the backward: both leave the one GEMM
+    std::tie(y, pre) = k_gemm_bias_act_pre(x2, w, *bias, act);
   } else {
     pre = nothing(x);
     y = gemm_plain(x2, w, false, false, bias, r2, epi, act);
@@ -950,6 +1015,8 @@ const bool kSaveSwigluAct = env_flag("TAMD_SAVE_SWIGLU_ACT", true);
 // (include/tamd.h q_prescaled; 0: the attention kernels scale and re-round their operand themselves)
 const bool kRopePrescale = env_flag("TAMD_ROPE_PRESCALE", true);
 constexpr double kLog2e = 1.44269504088896340736;
+// BertLayer: the q|k|v GEMM's epilogue delivers the pre-scaled queries (TAMD_BERT_PRESCALE=0: the kernels scale and re-round)
+const bool kBertPrescale = env_flag("TAMD_BERT_PRESCALE", true);
 
 struct Qkv {
   Tensor q, k, v;
@@ -1068,9 +1135,12 @@ BertLayerOut op_bert_layer(const Tensor& h_in, const OptTensor& key_valid, const
                            bool train) {
   const int64_t b = h_in.size(0), s = h_in.size(1), hd = h_in.size(2), t = b * s;
   Tensor x = contig(h_in).view({t, hd});
-  Tensor qkv = gemm_plain(x, wqkv, false, false, bqkv, {}, TAMD_EPI_BIAS);
+  // the query columns leave the q|k|v GEMM carrying scale*log2(e) before their one rounding (tamd_gemm_colscale): the
+  // attention kernels then scale and re-round nothing (q_prescaled) -- the reference's q has one rounding too
+  Tensor qkv = kBertPrescale ? k_gemm_colscale(x, wqkv, bqkv, heads * d, scale * kLog2e)
+                             : gemm_plain(x, wqkv, false, false, bqkv, {}, TAMD_EPI_BIAS);
   Qkv p3 = split_qkv(qkv, b, s, heads, heads, d);
-  auto [o, lse] = k_attn_fwd(p3.q, p3.k, p3.v, scale, false, key_valid, train, p_attn, seed_attn, {});
+  auto [o, lse] = k_attn_fwd(p3.q, p3.k, p3.v, scale, false, key_valid, train, p_attn, seed_attn, {}, kBertPrescale);
   auto dense_add_ln = [&](const Tensor& inp, const Tensor& w, const Tensor& bias, const Tensor& res, const Tensor& ln_w,
                           const Tensor& ln_b, int64_t seed) -> std::tuple<Tensor, Tensor, Tensor, Tensor> {
     if (p_hidden > 0.0) {
@@ -1083,9 +1153,8 @@ BertLayerOut op_bert_layer(const Tensor& h_in, const OptTensor& key_valid, const
   };
   auto [h1, y1, mean1, rstd1] = dense_add_ln(o.view({t, hd}), wo, bo, x, ln1_w, ln1_b, seed1);
   Tensor pre, inter;
-  if (train) {  // the pre-activation is what the activation's backward needs
-    pre = gemm_plain(h1, wi, false, false, bi, {}, TAMD_EPI_BIAS);
-    inter = k_bias_act_fwd(pre, {}, act);
+  if (train) {  // the pre-activation is what the activation's backward needs: it leaves the same GEMM
+    std::tie(inter, pre) = k_gemm_bias_act_pre(h1, wi, bi, act);
   } else {
     pre = nothing(h_in);
     inter = gemm_plain(h1, wi, false, false, bi, {}, TAMD_EPI_BIAS_ACT, act);
@@ -1108,33 +1177,31 @@ BertLayerOut op_bert_layer_bwd(const Tensor& d_out, const Tensor& h_in, const Op
   const int64_t b = h_in.size(0), s = h_in.size(1), hd = h_in.size(2), t = b * s;
   Tensor x = contig(h_in).view({t, hd});
   Tensor dy = contig(d_out).view({t, hd});
-  // -> (gradient of the residual input, of the dense output, dw, db)
+  // -> (gradient of the residual input, of the dense output, dw, db, column sums of the dense output's gradient = the
+  //     dense layer's bias gradient, accumulated by the same kernel)
   auto ln_bwd = [&](const Tensor& g, const Tensor& y, const Tensor& ln_w, const Tensor& mean, const Tensor& rstd,
-                    int64_t seed) -> std::tuple<Tensor, Tensor, Tensor, Tensor> {
-    if (p_hidden > 0.0) return k_layernorm_dropout_bwd(g, y, ln_w, mean, rstd, p_hidden, seed, {}, true);
-    auto [dx, dw, db] = k_layernorm_bwd(g, y, ln_w, mean, rstd, {}, true);
-    return {dx, dx, dw, db};
+                    int64_t seed) -> std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> {
+    if (p_hidden > 0.0) return k_layernorm_dropout_bwd(g, y, ln_w, mean, rstd, p_hidden, seed, {}, true, true);
+    auto [dx, dw, db, dc] = k_layernorm_bwd(g, y, ln_w, mean, rstd, {}, true, true);
+    return {dx, dx, dw, db, dc};
   };
   // ---- BertOutput / BertIntermediate
-  auto [d_h1_res, d_b, dw_ln2, db_ln2] = ln_bwd(dy, y2, ln2_w, mean2, rstd2, seed2);
-  Tensor dbo2 = k_colsum(d_b);
+  auto [d_h1_res, d_b, dw_ln2, db_ln2, dbo2] = ln_bwd(dy, y2, ln2_w, mean2, rstd2, seed2);
   Tensor dwo2 = gemm_plain(d_b, inter, true, true);  // [hd, I]
   Tensor d_inter = gemm_plain(d_b, wo2, false, true);  // [T, I]
-  Tensor d_pre = k_bias_act_bwd(pre, {}, d_inter, act);
+  auto [d_pre, dbi] = k_bias_act_bwd(pre, {}, d_inter, act, true);  // (+ its column sums: the intermediate bias gradient)
   d_inter = Tensor();
-  Tensor dbi = k_colsum(d_pre);
   Tensor dwi = gemm_plain(d_pre, h1, true, true);  // [I, hd]
   Tensor d_h1 = gemm_plain(d_pre, wi, false, true, {}, d_h1_res, TAMD_EPI_RESIDUAL);  // + the residual path's gradient
   d_pre = Tensor();
   // ---- BertSelfOutput / BertSelfAttention
-  auto [d_x_res, d_a, dw_ln1, db_ln1] = ln_bwd(d_h1, y1, ln1_w, mean1, rstd1, seed1);
-  Tensor dbo = k_colsum(d_a);
+  auto [d_x_res, d_a, dw_ln1, db_ln1, dbo] = ln_bwd(d_h1, y1, ln1_w, mean1, rstd1, seed1);
   Tensor dwo = gemm_plain(d_a, o.view({t, hd}), true, true);
   Tensor d_o = gemm_plain(d_a, wo, false, true);
   Tensor d_qkv = at::empty_like(qkv);
   Qkv f = split_qkv(qkv, b, s, heads, heads, d), g = split_qkv(d_qkv, b, s, heads, heads, d);
   k_attn_bwd(f.q, f.k, f.v, o, lse, d_o.view({b, s, heads, d}), scale, false, key_valid, g.q, g.k, g.v, p_attn, seed_attn, {},
-             Tensor(), Tensor());
+             Tensor(), Tensor(), kBertPrescale);
   d_o = Tensor();
   Tensor dbqkv = k_colsum(d_qkv);
   Tensor dwqkv = gemm_plain(d_qkv, x, true, true);  // [3 hd, hd]
@@ -1150,12 +1217,12 @@ TORCH_LIBRARY(tamd, m) {
   m.def("rmsnorm_fwd(Tensor x, Tensor w, float eps, Tensor? residual=None) -> (Tensor, Tensor, Tensor)");
   m.def("rmsnorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor rstd, Tensor? dres=None) -> (Tensor, Tensor)");
   m.def("layernorm_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor? residual=None) -> (Tensor, Tensor, Tensor, Tensor)");
-  m.def("layernorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd, Tensor? dres=None, bool need_db=True) -> "
-        "(Tensor, Tensor, Tensor)");
+  m.def("layernorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd, Tensor? dres=None, bool need_db=True, "
+        "bool need_colsum=False) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_dropout_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor residual, float dropout_p, int seed) -> "
         "(Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_dropout_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd, float dropout_p, int seed, "
-        "Tensor? dres=None, bool need_db=True) -> (Tensor, Tensor, Tensor, Tensor)");
+        "Tensor? dres=None, bool need_db=True, bool need_colsum=False) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("rope_(Tensor(a!) x2d, Tensor cos, Tensor sin, int seq, int nheads, int head_dim, bool conj=False) -> ()");
   m.def("embedding_fwd(Tensor ids, Tensor table) -> Tensor");
   m.def("embedding_bwd(Tensor ids, Tensor dout, int vocab, int padding_idx=-1) -> Tensor");
@@ -1164,7 +1231,7 @@ TORCH_LIBRARY(tamd, m) {
   m.def("swiglu_fwd(Tensor gu) -> Tensor");
   m.def("swiglu_bwd(Tensor gu, Tensor dact, bool want_act=False) -> (Tensor, Tensor)");
   m.def("bias_act_fwd(Tensor x, Tensor? bias, int act) -> Tensor");
-  m.def("bias_act_bwd(Tensor x, Tensor? bias, Tensor dy, int act) -> Tensor");
+  m.def("bias_act_bwd(Tensor x, Tensor? bias, Tensor dy, int act, bool need_colsum=False) -> (Tensor, Tensor)");
   m.def("add(Tensor a, Tensor b) -> Tensor");
   m.def("colsum(Tensor x2d) -> Tensor");
   m.def("transpose(Tensor x2d) -> Tensor");
@@ -1177,6 +1244,8 @@ TORCH_LIBRARY(tamd, m) {
   m.def("gemm_out(Tensor(a!) out, Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, "
         "Tensor? residual=None, int epilogue=0, int act=0, int sched=0) -> ()");
   m.def("gemm_swiglu(Tensor x2, Tensor wgu, bool need_gu=True) -> (Tensor, Tensor)");
+  m.def("gemm_bias_act_pre(Tensor x2, Tensor w, Tensor bias, int act) -> (Tensor, Tensor)");
+  m.def("gemm_colscale(Tensor x2, Tensor w, Tensor? bias, int scale_cols, float col_scale) -> Tensor");
   m.def("gemm_rope(Tensor x2, Tensor wqkv, Tensor cos, Tensor sin, int seq, int rope_heads, int head_dim) -> Tensor");
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None, bool need_lse=True, "
         "float dropout_p=0.0, int seed=0, Tensor? q_start=None) -> (Tensor, Tensor)");
@@ -1247,7 +1316,9 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("swiglu_fwd", &k_swiglu_fwd);                               \
   m.impl("swiglu_bwd", &op_swiglu_bwd);                              \
   m.impl("bias_act_fwd", &k_bias_act_fwd);                           \
-  m.impl("bias_act_bwd", &k_bias_act_bwd);                           \
+  m.impl("bias_act_bwd", &op_bias_act_bwd);                          \
+  m.impl("gemm_bias_act_pre", &op_gemm_bias_act_pre);                \
+  m.impl("gemm_colscale", &op_gemm_colscale);                        \
   m.impl("add", &k_add);                                             \
   m.impl("colsum", &k_colsum);                                       \
   m.impl("transpose", &k_transpose);                                 \

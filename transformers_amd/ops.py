@@ -132,7 +132,7 @@ def raw_layernorm_fwd(x, w, b, eps, residual=None):
 
 
 def raw_layernorm_bwd(dy, h, w, mean, rstd, dres=None, need_db=True):
-    dx, dw, db = T.layernorm_bwd(dy, h, w, mean, rstd, dres, need_db)
+    dx, dw, db, _ = T.layernorm_bwd(dy, h, w, mean, rstd, dres, need_db, False)
     return dx, dw, (db if need_db else None)
 
 
@@ -144,7 +144,7 @@ def raw_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed):
 
 def raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True):
     """-> (dx = gradient of the residual input, dx_drop = gradient of the dropped-out input, dw, db)."""
-    dx, dxd, dw, db = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, float(dropout_p), int(seed) & 0x7FFFFFFFFFFFFFFF, dres,
+    dx, dxd, dw, db, _ = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, float(dropout_p), int(seed) & 0x7FFFFFFFFFFFFFFF, dres,
                                               need_db)
     return dx, dxd, dw, (db if need_db else None)
 
@@ -177,8 +177,10 @@ def raw_bias_act_fwd(x, bias, act):
     return T.bias_act_fwd(x, bias, int(act))
 
 
-def raw_bias_act_bwd(x, bias, dy, act):
-    return T.bias_act_bwd(x, bias, dy, int(act))
+def raw_bias_act_bwd(x, bias, dy, act, need_colsum=False):
+    """-> dx, or (dx, column sums of dx = the bias gradient) with need_colsum."""
+    dx, dc = T.bias_act_bwd(x, bias, dy, int(act), bool(need_colsum))
+    return (dx, dc) if need_colsum else dx
 
 
 def raw_add(a, b):
@@ -348,12 +350,14 @@ register("rmsnorm_bwd", lambda dy, h, w, rstd, dres=None: (torch.empty_like(h), 
 register("layernorm_fwd", lambda x, w, b, eps, residual=None: (torch.empty_like(x),
                                                                torch.empty_like(x) if residual is not None else _nothing(x),
                                                                _f32(x, _rows(x)), _f32(x, _rows(x))))
-register("layernorm_bwd", lambda dy, h, w, mean, rstd, dres=None, need_db=True: (
-    torch.empty_like(h), torch.empty_like(w), torch.empty_like(w) if need_db else _nothing(w)))
+register("layernorm_bwd", lambda dy, h, w, mean, rstd, dres=None, need_db=True, need_colsum=False: (
+    torch.empty_like(h), torch.empty_like(w), torch.empty_like(w) if need_db else _nothing(w),
+    torch.empty_like(w) if need_colsum else _nothing(w)))
 register("layernorm_dropout_fwd", lambda x, w, b, eps, residual, dropout_p, seed: (
     torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x)), _f32(x, _rows(x))))
-register("layernorm_dropout_bwd", lambda dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True: (
-    torch.empty_like(h), torch.empty_like(h), torch.empty_like(w), torch.empty_like(w) if need_db else _nothing(w)))
+register("layernorm_dropout_bwd", lambda dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True, need_colsum=False: (
+    torch.empty_like(h), torch.empty_like(h), torch.empty_like(w), torch.empty_like(w) if need_db else _nothing(w),
+    torch.empty_like(w) if need_colsum else _nothing(w)))
 register("rope_", lambda x2d, cos, sin, seq, nheads, head_dim, conj=False: None)
 register("embedding_fwd", lambda ids, table: table.new_empty(*ids.shape, table.shape[1]))
 register("embedding_bwd", lambda ids, dout, vocab, padding_idx=-1: dout.new_empty(vocab, dout.shape[-1]))
@@ -366,7 +370,11 @@ register("swiglu_fwd", lambda gu: gu.new_empty(gu.shape[0], gu.shape[1] // 2))
 register("swiglu_bwd", lambda gu, dact, want_act=False: (torch.empty_like(gu),
                                                          torch.empty_like(dact) if want_act else _nothing(gu)))
 register("bias_act_fwd", lambda x, bias, act: torch.empty_like(x))
-register("bias_act_bwd", lambda x, bias, dy, act: torch.empty_like(x))
+register("bias_act_bwd", lambda x, bias, dy, act, need_colsum=False: (
+    torch.empty_like(x), x.new_empty(x.shape[-1]) if need_colsum else _nothing(x)))
+register("gemm_bias_act_pre", lambda x2, w, bias, act: (x2.new_empty(x2.shape[0], w.shape[0]),
+                                                        x2.new_empty(x2.shape[0], w.shape[0])))
+register("gemm_colscale", lambda x2, w, bias, scale_cols, col_scale: x2.new_empty(x2.shape[0], w.shape[0]))
 register("add", lambda a, b: torch.empty_like(a))
 register("colsum", lambda x2d: x2d.new_empty(x2d.shape[1]))
 register("transpose", lambda x2d: x2d.new_empty(x2d.shape[1], x2d.shape[0]))
@@ -452,7 +460,7 @@ def _layernorm_backward(ctx, dy, _dm, _dr):
     if dy is None:
         return None, None, None, None
     x, w, mean, rstd = ctx.saved_tensors
-    dx, dw, db = T.layernorm_bwd(dy, x, w, mean, rstd, None, ctx.has_b)
+    dx, dw, db, _ = T.layernorm_bwd(dy, x, w, mean, rstd, None, ctx.has_b, False)
     return dx, dw, (db if ctx.has_b else None), None
 
 
@@ -471,7 +479,7 @@ def _add_layernorm_backward(ctx, dy, dh, _dm, _dr):
     if dy is None:
         return dh, dh, None, None, None
     h, w, mean, rstd = ctx.saved_tensors
-    dx, dw, db = T.layernorm_bwd(dy, h, w, mean, rstd, dh, ctx.has_b)
+    dx, dw, db, _ = T.layernorm_bwd(dy, h, w, mean, rstd, dh, ctx.has_b, False)
     return dx, dx, dw, (db if ctx.has_b else None), None
 
 
@@ -495,7 +503,7 @@ def _dropout_add_layernorm_backward(ctx, dy, dh, _dm, _dr):
             return none
         raise TamdError("dropout_add_layernorm: only the pre-norm sum is differentiated; use ops.layernorm pieces")
     h, w, mean, rstd = ctx.saved_tensors
-    dx, dxd, dw, db = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, ctx.drop[0], ctx.drop[1], dh, ctx.has_b)
+    dx, dxd, dw, db, _ = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, ctx.drop[0], ctx.drop[1], dh, ctx.has_b, False)
     return (dxd, dx, dw, (db if ctx.has_b else None)) + none[4:]
 
 
@@ -523,14 +531,17 @@ def _linear_backward(ctx, dy, _dpre):
     if ctx.act != ACT_NONE:
         if pre.numel() == 0:
             raise TamdError("linear(act=...) was run with train=False but is being differentiated")
-        dy2 = T.bias_act_bwd(pre, None, dy2, ctx.act)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dy2, db_act = T.bias_act_bwd(pre, None, dy2, ctx.act, want_db)   # (+ its column sums: the bias gradient)
+    else:
+        db_act = None
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
         dx = T.gemm(dy2, w, False, True).view(x.shape)                      # dX = dY . W
     if ctx.needs_input_grad[1]:
         dw = T.gemm(dy2, _c(x).view(-1, k), True, True)                     # dW = dY^T . X
     if ctx.has_bias and ctx.needs_input_grad[2]:
-        db = T.colsum(dy2)
+        db = db_act if db_act is not None else T.colsum(dy2)
     return dx, dw, db, dres, None, None
 
 
@@ -642,9 +653,8 @@ def _bias_act_setup(ctx, inputs, output):
 
 def _bias_act_backward(ctx, dy):
     x, bias = ctx.saved_tensors
-    dx = T.bias_act_bwd(x, bias, dy, ctx.act)
-    db = T.colsum(dx.view(-1, dx.shape[-1])) if bias is not None else None
-    return dx, db, None
+    dx, db = T.bias_act_bwd(x, bias, dy, ctx.act, bias is not None)
+    return dx, (db if bias is not None else None), None
 
 
 register("bias_act", lambda x, bias, act: torch.empty_like(x), _bias_act_backward, _bias_act_setup)
@@ -682,7 +692,7 @@ def _bert_embeddings_backward(ctx, dy, _dpre, _dm, _dr):
     if pre.numel() == 0:
         raise TamdError("bert_embeddings was run with train=False but is being differentiated")
     vocab, tvocab, npos, padding_idx = ctx.meta
-    d_pre, dw, db = T.layernorm_bwd(dy, pre, ln_w, mean, rstd)
+    d_pre, dw, db, _ = T.layernorm_bwd(dy, pre, ln_w, mean, rstd)
     d_word = T.embedding_bwd(input_ids, d_pre, vocab, padding_idx)
     d_typ = T.embedding_bwd(token_type_ids, d_pre, tvocab, -1)
     d_pos = T.embedding_bwd(position_ids, d_pre, npos, -1)
