@@ -158,10 +158,14 @@ def test_embedding_backward_long_runs(env):
                             torch.full((n - 129,), 2)]))                             # boundaries at 31, 64, 128, 129
     cases.append(torch.randint(0, 4, (n,)))                                          # 4 long interleaved runs (after sort)
     cases.append(torch.cat([torch.arange(40), torch.full((n - 40,), 17)]))           # short runs then a long one
+    # a run of more pieces than the join kernel has waves (16), over a row of more than one 256-column chunk, ragged
+    cases.append(torch.cat([torch.full((5,), 1), torch.full((1200 if not env.big else 40000,), 6), torch.full((3,), 8)]))
     for ci, ids in enumerate(cases):
         torch.manual_seed(40 + ci)
         vocab = 64
         ids = ids.to(dev)
+        if ci == len(cases) - 1:
+            dim = 1096 if env.big else 328
         dout = torch.randn(ids.numel(), dim).bfloat16().to(dev)
         ref = torch.zeros(vocab, dim, dtype=torch.float32, device=dev).index_add_(0, ids, dout.float())
         for pad in (None, int(ids[-1])):

@@ -132,15 +132,22 @@ __global__ void embedding_bwd_seg_kernel(const int64_t* __restrict__ sorted_ids,
   }
 }
 
+// Pass 2: one WORKGROUP (16 waves) per run that crosses a segment boundary, found at the segment where the run starts.  The
+// run's end comes from a binary search in the sorted ids; its pieces -- tail of the first segment, tails of the fully covered
+// ones, head of the last -- are split over the waves (wave w takes pieces w, w + 16, ...: independent loads, 8 in flight)
+// and combined through LDS in wave order: deterministic.  (The first version gave the whole run to ONE wave, piece after
+// piece: BERT's token_type_ids are all 0 -- one run of 16384 tokens, 512 dependent round trips, 669 us of a 25 ms
+// bert-base step, profiles/r04a_bert_kernel_stats.csv.)
+constexpr int kEmbJoinWaves = 16;
 template <typename T>
-__global__ void embedding_bwd_join_kernel(const int64_t* __restrict__ sorted_ids, T* __restrict__ dtable,
-                                          const float* __restrict__ ws, int64_t ntokens, int64_t vocab, int dim,
-                                          int64_t padding_idx) {
-  constexpr int VE = vec16<T>::N;
+__global__ __launch_bounds__(kEmbJoinWaves * 64) void embedding_bwd_join_kernel(const int64_t* __restrict__ sorted_ids,
+                                                                                 T* __restrict__ dtable,
+                                                                                 const float* __restrict__ ws, int64_t ntokens,
+                                                                                 int64_t vocab, int dim, int64_t padding_idx) {
+  __shared__ __attribute__((aligned(16))) float part[kEmbJoinWaves][64][4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
   const int64_t nseg = (ntokens + kEmbSeg - 1) / kEmbSeg;
-  for (int64_t sg = (int64_t)blockIdx.x * wpb + wave; sg + 1 < nseg; sg += (int64_t)gridDim.x * wpb) {
+  for (int64_t sg = blockIdx.x; sg + 1 < nseg; sg += gridDim.x) {  // (block-uniform control flow throughout)
     const int64_t t1 = (sg + 1) * kEmbSeg;  // first token of the next segment (exists: sg + 1 < nseg)
     const int64_t id = sorted_ids[t1 - 1];
     if (sorted_ids[t1] != id) continue;  // no run leaves this segment to the right
@@ -148,28 +155,53 @@ __global__ void embedding_bwd_join_kernel(const int64_t* __restrict__ sorted_ids
     const int64_t t0 = sg * kEmbSeg;
     if (sorted_ids[t0] == id && t0 > 0 && sorted_ids[t0 - 1] == id) continue;
     if (id < 0 || id >= vocab || id == padding_idx) continue;
-    for (int c = lane * VE; c < dim; c += 64 * VE) {
-      float acc[VE];
-#pragma unroll
-      for (int i = 0; i < VE; ++i) acc[i] = 0.f;
-      auto add = [&](const float* slot) {
-#pragma unroll
-        for (int i = 0; i < VE; i += 4) {
-          const u32x4 v = ld16(slot + i);
-          acc[i] += u32_as_f32(v[0]);
-          acc[i + 1] += u32_as_f32(v[1]);
-          acc[i + 2] += u32_as_f32(v[2]);
-          acc[i + 3] += u32_as_f32(v[3]);
+    int64_t lo = t1, hi = ntokens;  // first token after the run: the first index in [t1, ntokens] whose id differs
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (sorted_ids[mid] == id)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    const int64_t kl = (lo - 1) / kEmbSeg;  // the segment the run ends in (> sg)
+    const int64_t npieces = kl - sg + 1;
+    // piece i: i = 0 the tail of segment sg, 0 < i < npieces - 1 the tail of segment sg + i (fully covered: pass 1 filed
+    // the whole segment as tail), i = npieces - 1 the head of segment kl
+    auto piece = [&](int64_t i) -> const float* {
+      return ws + ((sg + i) * 2 + (i == npieces - 1 ? 0 : 1)) * (int64_t)dim;
+    };
+    for (int c = lane * 4; c < ((dim + 255) / 256) * 256; c += 256) {  // (every wave walks every chunk: the barriers are uniform)
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      if (c < dim) {
+#pragma unroll 8
+        for (int64_t i = wave; i < npieces; i += kEmbJoinWaves) {
+          const u32x4 v = ld16(piece(i) + c);
+          a0 += u32_as_f32(v[0]);
+          a1 += u32_as_f32(v[1]);
+          a2 += u32_as_f32(v[2]);
+          a3 += u32_as_f32(v[3]);
         }
-      };
-      add(ws + ((sg * 2 + 1) * (int64_t)dim + c));  // tail of the segment the run starts in
-      for (int64_t k = sg + 1; k < nseg; ++k) {
-        const int64_t e1 = ((k + 1) * kEmbSeg < ntokens) ? (k + 1) * kEmbSeg : ntokens;
-        const bool covers = sorted_ids[e1 - 1] == id && e1 < ntokens && sorted_ids[e1] == id;
-        add(ws + ((k * 2 + (covers ? 1 : 0)) * (int64_t)dim + c));  // whole segment and on: its tail; else: its head
-        if (!covers) break;
       }
-      st16(dtable + id * dim + c, pack16<T>(acc));
+      part[wave][lane][0] = a0;
+      part[wave][lane][1] = a1;
+      part[wave][lane][2] = a2;
+      part[wave][lane][3] = a3;
+      block_sync();
+      if (wave == 0 && c < dim) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int w = 0; w < kEmbJoinWaves; ++w) {
+          s0 += part[w][lane][0];
+          s1 += part[w][lane][1];
+          s2 += part[w][lane][2];
+          s3 += part[w][lane][3];
+        }
+        if constexpr (sizeof(T) == 4)
+          st16(dtable + id * dim + c, u32x4{f32_as_u32(s0), f32_as_u32(s1), f32_as_u32(s2), f32_as_u32(s3)});
+        else
+          st8(dtable + id * dim + c, u32x2{pack2<T>(s0, s1), pack2<T>(s2, s3)});
+      }
+      block_sync();
     }
   }
 }
@@ -378,20 +410,35 @@ __global__ void bias_act_bwd_colsum_kernel(const T* __restrict__ x, const T* __r
 #pragma unroll
   for (int i = 0; i < VE; ++i) acc[i] = 0.f, b[i] = 0.f;
   if (bias != nullptr) unpack16<T>(ld16(bias + col), b);
-  for (int64_t r = r0; r < r1; ++r) {
-    float v[VE], d[VE], o[VE];
-    unpack16<T>(ld16(x + r * cols + col), v);
-    unpack16<T>(ld16(dy + r * cols + col), d);
-    if (bias != nullptr) {
+  // 4 rows per trip: their 8 loads go out together (one row at a time the slab walk is a chain of dependent round trips:
+  // 3.9 TB/s at bert-base's 16384 x 3072 on MI355X against 5.8 for the grid-stride kernel, profiles/r04a)
+  constexpr int U = 4;
+  for (int64_t r = r0; r < r1; r += U) {
+    u32x4 xv[U], dv[U];
 #pragma unroll
-      for (int i = 0; i < VE; ++i) v[i] = round_through<T>(v[i] + b[i]);
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = (r + u < r1) ? r + u : r1 - 1;  // (a tail row is re-read, its result dropped below)
+      xv[u] = ld16(x + rr * cols + col);
+      dv[u] = ld16(dy + rr * cols + col);
     }
 #pragma unroll
-    for (int i = 0; i < VE; ++i) {
-      o[i] = d[i] * dact_f<ACT>(v[i]);
-      acc[i] += round_through<T>(o[i]);
+    for (int u = 0; u < U; ++u) {
+      if (r + u < r1) {
+        float v[VE], d[VE], o[VE];
+        unpack16<T>(xv[u], v);
+        unpack16<T>(dv[u], d);
+        if (bias != nullptr) {
+#pragma unroll
+          for (int i = 0; i < VE; ++i) v[i] = round_through<T>(v[i] + b[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < VE; ++i) {
+          o[i] = d[i] * dact_f<ACT>(v[i]);
+          acc[i] += round_through<T>(o[i]);
+        }
+        st16(out + (r + u) * cols + col, pack16<T>(o));
+      }
     }
-    st16(out + r * cols + col, pack16<T>(o));
   }
 #pragma unroll
   for (int i = 0; i < VE; ++i) part[(int64_t)blockIdx.y * cols + col + i] = acc[i];
@@ -666,9 +713,9 @@ int tamd_embedding_bwd(const int64_t* sorted_ids, const int64_t* perm, const voi
                        TAMD_STREAM(stream), sorted_ids, perm, (const T*)dout, (T*)dtable, (float*)workspace, ntokens,
                        vocab, (int)dim, padding_idx);
     if (nseg > 1)
-      hipLaunchKernelGGL((embedding_bwd_join_kernel<T>), dim3(stream_grid(nseg * 64, 256)), dim3(256), 0,
-                         TAMD_STREAM(stream), sorted_ids, (T*)dtable, (const float*)workspace, ntokens, vocab,
-                         (int)dim, padding_idx);
+      hipLaunchKernelGGL((embedding_bwd_join_kernel<T>), dim3((unsigned)(nseg - 1 < 4096 ? nseg - 1 : 4096)),
+                         dim3(kEmbJoinWaves * 64), 0, TAMD_STREAM(stream), sorted_ids, (T*)dtable, (const float*)workspace,
+                         ntokens, vocab, (int)dim, padding_idx);
   });
   return launch_status();
 }

@@ -561,6 +561,18 @@ Tensor k_gemm_colscale(const Tensor& x2, const Tensor& w, const OptTensor& bias,
   return y;
 }
 
+// (act(pre), pre = round(x2 . w^T + bias)) for a layer whose backward needs the pre-activation.  One GEMM with both outputs
+// (tamd_gemm_bias_act_pre) or GEMM + activation kernel: on MI355X the fused way out lost badly for erf-GELU at bert-base --
+// 495 us against 84 + 38 (profiles/r04a_bert_kernel_stats.csv): the epilogue of the 256 x 256 kernel runs one wave per SIMD
+// with nothing to overlap, and ocml's erff is ~100 dependent, divergent instructions per element there (85 cycles per
+// element in the bandwidth-bound kernel, ~900 in the epilogue).  TAMD_FUSE_ACT_PRE=1 selects the one-GEMM form (bit-identical).
+const bool kFuseActPre = [] { const char* e = getenv("TAMD_FUSE_ACT_PRE"); return e != nullptr && std::string(e) != "0"; }();
+std::tuple<Tensor, Tensor> linear_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
+  if (kFuseActPre) return k_gemm_bias_act_pre(x2, w, bias, act);
+  Tensor pre = gemm_plain(x2, w, false, false, bias, {}, TAMD_EPI_BIAS);
+  return {k_bias_act_fwd(pre, {}, act), pre};
+}
+
 bool half_type(const Tensor& t) { return t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf; }
 
 // shapes the fused gate|up GEMM + SiLU*up epilogue takes (csrc/gemm.hip tamd_gemm_swiglu)
@@ -865,8 +877,8 @@ std::tuple<Tensor, Tensor> op_linear(const Tensor& x, const Tensor& w, const Opt
     epi = TAMD_EPI_BIAS;
   }
   Tensor pre, y;
-  if (epi == TAMD_EPI_BIAS_ACT && train) {  // the pre-activation is kept for the backward: both leave the one GEMM
-    std::tie(y, pre) = k_gemm_bias_act_pre(x2, w, *bias, act);
+  if (epi == TAMD_EPI_BIAS_ACT && train) {  // the pre-activation is kept for the backward
+    std::tie(y, pre) = linear_act_pre(x2, w, *bias, act);
   } else {
     pre = nothing(x);
     y = gemm_plain(x2, w, false, false, bias, r2, epi, act);
@@ -1153,8 +1165,8 @@ BertLayerOut op_bert_layer(const Tensor& h_in, const OptTensor& key_valid, const
   };
   auto [h1, y1, mean1, rstd1] = dense_add_ln(o.view({t, hd}), wo, bo, x, ln1_w, ln1_b, seed1);
   Tensor pre, inter;
-  if (train) {  // the pre-activation is what the activation's backward needs: it leaves the same GEMM
-    std::tie(inter, pre) = k_gemm_bias_act_pre(h1, wi, bi, act);
+  if (train) {  // the pre-activation is what the activation's backward needs
+    std::tie(inter, pre) = linear_act_pre(h1, wi, bi, act);
   } else {
     pre = nothing(h_in);
     inter = gemm_plain(h1, wi, false, false, bi, {}, TAMD_EPI_BIAS_ACT, act);
