@@ -218,7 +218,8 @@ enum tamd_gemm_flags {
   TAMD_GEMM_SCHED_PP = 1 << 8, /* 8-wave ping-pong kernel, 32-deep stages (every layout, any K)                */
   TAMD_GEMM_SCHED_SM = 2 << 8, /* 128 x 128 tile, two workgroups per CU (row-major operands, K % 64 == 0): the  */
                                /* default for grids of few 256 x 256 tiles that split-K does not take           */
-  TAMD_GEMM_SCHED_FL = 3 << 8  /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
+  TAMD_GEMM_SCHED_FL = 3 << 8, /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
+  TAMD_GEMM_SCHED_TW = 4 << 8  /* 256 x 128 tile, two workgroups per CU, 32-deep units (row-major operands, K % 32 == 0) */
 };
 enum tamd_gemm_epilogue {
   TAMD_EPI_NONE = 0,

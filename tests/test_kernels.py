@@ -267,7 +267,7 @@ def test_gemm_layouts(env, layout):
         assert rel_err(c, ref) < 0.0034, (layout, m, n, k)  # bf16 output rounding only (fp32 accumulation)
 
 
-@pytest.mark.parametrize("sched", ["pp", "fl", "sm", None])
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm", "tw", None])
 def test_gemm_schedules_agree(env, sched):
     """The three GEMM kernels (ping-pong with 32-deep stages; one-wave-per-SIMD with 64-deep full-line stages; the 128 x 128
     tile for small forward grids) and the default dispatch agree bit for bit on ragged M/N, stage counts around the ring
@@ -285,7 +285,7 @@ def test_gemm_schedules_agree(env, sched):
         if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
             continue  # the default dispatch splits K for this grid: fp32 summation order differs (test_gemm_split_k)
         assert torch.equal(c, ops.raw_gemm(x, w, sched="pp")), (sched, m, n, k)  # same fp32 k-order per output
-    if sched not in ("pp", "sm"):  # k-major operands (the backward products)
+    if sched not in ("pp", "sm", "tw"):  # k-major operands (the backward products)
         for (m, n, k) in ([(4096, 1024, 4096), (1000, 1032, 320), (264, 4104, 832)] if env.big else
                           [(256, 256, 64), (264, 248, 128), (136, 520, 192), (72, 264, 320), (304, 136, 384)]):
             if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
@@ -489,9 +489,13 @@ def test_attention_takes_prescaled_queries_from_the_rotary_kernel(env, d):
     for tag, e4 in errs.items():  # into the parity report (gpurun_out/parity_hip.json on MI355X)
         for nm, e in zip(("O", "dq", "dk", "dv"), e4):
             record("attn_prescaled_q", f"d{d}:{tag}:{nm}", e)
-    slack = 1.0 if d == 128 else 1.03  # (head_dim 64 was measured on the CPU model only)
+    # MI355X (profiles/r04a_parity.json), pre-scaled vs kernel-scaled (O, dq, dk, dv): head_dim 128 0.00324 / 0.00415 / 0.00418 /
+    # 0.00342 vs 0.00349 / 0.00433 / 0.00448 / 0.00382; head_dim 64 0.00322 / 0.00422 / 0.00428 / 0.00343 vs 0.00349 / 0.00446 /
+    # 0.00461 / 0.00393 -- ahead in every output at both head dims.  The CPU model's small head_dim-64 case (200 keys) puts dq
+    # 1-3 % the other way round, hence its slack.
+    slack = 1.0 if (d == 128 or env.big) else 1.03
     assert all(a <= slack * b_ for a, b_ in zip(errs["pre-scaled"], errs["kernel-scaled"])), errs
-    assert errs["pre-scaled"][0] < 0.99 * slack * errs["kernel-scaled"][0], errs  # one rounding of q less (MI355X, 128: 0.00324 vs 0.00349)
+    assert errs["pre-scaled"][0] < 0.99 * slack * errs["kernel-scaled"][0], errs  # one rounding of q less
 
 
 ATTN_CASES_SMALL = [
@@ -874,7 +878,7 @@ def test_gemm_piece_placements_are_bit_identical(env):
 
 # ---- round 4: the bert-base fusions (one GEMM for activation + pre-activation, pre-scaled query columns, bias gradients
 # ---- accumulated by the kernels that produce the tensors they sum)
-@pytest.mark.parametrize("sched", ["pp", "fl", "sm"])
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm", "tw"])
 def test_gemm_bias_act_pre_is_bit_identical_to_gemm_plus_activation_kernel(env, sched):
     """BertIntermediate in train mode (modeling_bert.py:334-337): tamd_gemm_bias_act_pre writes act(round(xW^T + b)) AND the
     rounded pre-activation from one GEMM -- the bits of tamd_gemm(TAMD_EPI_BIAS) followed by tamd_bias_act_fwd, on every
@@ -887,7 +891,7 @@ def test_gemm_bias_act_pre_is_bit_identical_to_gemm_plus_activation_kernel(env, 
     dev = env.device
     be = ops.backend()
     lib = be.lib
-    hint = {"pp": 1, "sm": 2, "fl": 3}[sched] << 8
+    hint = {"pp": 1, "sm": 2, "fl": 3, "tw": 4}[sched] << 8
     for (m, n, k) in ([(4096, 3072, 768), (1000, 1032, 320), (577, 4096, 1024)] if env.big else
                       [(264, 248, 128), (130, 520, 192), (72, 264, 64)]):
         x = torch.randn(m, k).bfloat16().to(dev)
@@ -912,7 +916,7 @@ def test_gemm_bias_act_pre_is_bit_identical_to_gemm_plus_activation_kernel(env, 
     assert torch.equal(y2, ops.raw_bias_act_fwd(pre2, None, ops.ACT_GELU_ERF))
 
 
-@pytest.mark.parametrize("sched", ["pp", "fl", "sm"])
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm", "tw"])
 def test_gemm_colscale_scales_the_query_columns_before_their_one_rounding(env, sched):
     """tamd_gemm_colscale (the q|k|v projection of BertSelfAttention, modeling_bert.py:175-177, delivering pre-scaled queries):
     columns >= scale_cols carry the bits of the plain GEMM; the scaled columns are round((acc + bias) * s) -- closer to the
@@ -925,7 +929,7 @@ def test_gemm_colscale_scales_the_query_columns_before_their_one_rounding(env, s
     dev = env.device
     be = ops.backend()
     lib = be.lib
-    hint = {"pp": 1, "sm": 2, "fl": 3}[sched] << 8
+    hint = {"pp": 1, "sm": 2, "fl": 3, "tw": 4}[sched] << 8
     for (m, n, k, sc) in ([(4096, 2304, 768, 768), (1000, 1032, 320, 344)] if env.big else [(264, 248, 128, 80), (72, 264, 64, 264)]):
         x = torch.randn(m, k).bfloat16().to(dev)
         w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)

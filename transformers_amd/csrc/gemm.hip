@@ -936,6 +936,189 @@ __global__ __launch_bounds__(kSmThreads, 2) void gemm_sm_kernel(GemmArgs g) {
   gemm_epilogue<T, EPI, ACT, 2, 2>(g, acc, smem, (unsigned)wave * kSmStageWave, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
+// ============================================================================================ two workgroups per CU
+// 256 x 128 tile, 4 waves x (128 x 64) on v_mfma_f32_16x16x32, 32-deep units of A[256][32] (16 KiB) + B[128][32] (8 KiB) in a
+// ring of three (72 KiB), at most 256 registers per lane: TWO workgroups share a CU, so one's hand-offs, operand latency and
+// -- above all -- its way out (one wave per SIMD in gemm_fl_kernel: the matrix pipe idles while a tile leaves) sit under the
+// other's MFMAs.  Meant for the products gemm_fl_kernel serves badly: short K loops (bert-base: 12 stages of 64, where
+// prologue + epilogue are a third of a tile's time), grids of 1.2 - 2.5 dispatch rounds (a 128-wide tile halves the
+// quantum), expensive epilogues.  VERDICT r3 item 2 / 5; measurements: profiles/r04*_gemm_tw_ab.jsonl.
+// Forward layout (A [M,K], B [N,K] row-major), K % 32 == 0.
+//   LDS image of a unit: row r at r * 64 B, logical 16-byte chunk c at slot c ^ ((-(r >> 2)) & 3) -- applied on the LDS-DMA
+//   source address, undone on the fragment read; a 16x16x32 fragment read (16 rows x 4 chunks per ds_read_b128 lane group)
+//   is conflict-free with it (the ping-pong kernel's slot ^ ((r >> 2) & 3) is not: rows 0-3 and 4-7 would collide).
+//   Schedule of k-step j (unit j % 3): vmcnt(6) [own pieces of unit j landed; the 6 of unit j + 1 stay in flight] ->
+//   barrier -> 12 fragment reads (4 B, 8 A), 32 MFMAs as 8 groups that start as their A fragment arrives (counted lgkmcnt),
+//   and, one behind each of the groups 1 .. 6, this wave's 6 LDS-DMA pieces of unit j + 2 (the unit k-step j - 1 vacated:
+//   every wave passed this k-step's barrier after reading it).  Fragments are NOT read a k-step ahead: with two workgroups
+//   per CU the partner's MFMAs cover the read latency, and the registers stay under 256.
+constexpr int kTwThreads = 256;
+constexpr int kTwBM = 256, kTwBN = 128, kTwK = 32;
+constexpr unsigned kTwA = (unsigned)kTwBM * kTwK * 2u;  // 16 KiB
+constexpr unsigned kTwB = (unsigned)kTwBN * kTwK * 2u;  // 8 KiB
+constexpr unsigned kTwUnit = kTwA + kTwB;
+constexpr int kTwRing = 3;
+constexpr int kTwSmem = kTwRing * (int)kTwUnit;  // 73728 (the way out stages 4 x 64 rows x 144 B = 36 KiB in it)
+
+// s_waitcnt lgkmcnt(N) that fragment `f` depends on (untracked LDS reads complete in issue order: N = reads issued after it)
+template <int N>
+__device__ __forceinline__ void gemm_wait_frag(u32x4& f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+#else
+  (void)f;
+#endif
+}
+
+// way out of a wave of gemm_tw_kernel: acc[nb][mb][r] = D[n = nb*16 + 4*(lane>>4) + r][m = mb*16 + (lane&15)], 4 x 8 blocks = a
+// 128 x 64 piece of C
+template <typename T, int EPI, int ACT>
+__device__ __forceinline__ void gemm_epilogue16n(const GemmArgs& g, f32x4 (&acc)[4][8], char* smem, unsigned st_off,
+                                                 int64_t row0, int64_t col0, int lane) {
+  constexpr int ROWB = 64 * 2 + 16;
+  const int g4 = lane >> 4, l15 = lane & 15;
+  auto stage_as = [&](auto epi_tag, int half) {
+    constexpr int E = decltype(epi_tag)::value;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int nl = nb * 16 + 4 * g4;  // first of 4 consecutive local columns
+      float bv[4];
+      gemm_bias4<T, E>(g, col0 + nl, bv);
+      const float sc = gemm_colscale4<E>(g, col0 + nl);
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        const f32x4 a = acc[nb][half * 4 + m4];
+        lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
+                   gemm_round4<T, E, ACT>(a[0], a[1], a[2], a[3], bv, sc));
+      }
+    }
+  };
+  if (EPI == TAMD_EPI_BIAS_ACT && g.C2 != nullptr) {
+    const GemmArgs gp = gemm_pre_args(g);
+    gemm_epilogue_rows<T, TAMD_EPI_BIAS, ACT, 64, 2>(gp, smem, st_off, row0, col0, lane, [&](int half) {
+      stage_as(std::integral_constant<int, TAMD_EPI_BIAS>{}, half);
+    });
+  }
+  gemm_epilogue_rows<T, EPI, ACT, 64, 2>(g, smem, st_off, row0, col0, lane,
+                                         [&](int half) { stage_as(std::integral_constant<int, EPI>{}, half); });
+}
+
+template <typename T, int EPI, int ACT>
+__global__ __launch_bounds__(kTwThreads, 2) void gemm_tw_kernel(GemmArgs g) {
+  TAMD_DYN_SMEM(smem);
+  const int lane = threadIdx.x & 63;
+  const int wave = wave_id_uniform();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g4 = lane >> 4, l15 = lane & 15;
+  int tile_m, tile_n;
+  gemm_tile_of_block(g, (int)blockIdx.x, &tile_m, &tile_n);
+  const int64_t m0 = (int64_t)tile_m * kTwBM, n0 = (int64_t)tile_n * kTwBN;
+  const T* A = reinterpret_cast<const T*>(g.A);
+  const T* B = reinterpret_cast<const T*>(g.B);
+
+  f32x4 acc[4][8];  // [nb][mb]
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane source offsets of this wave's 4 A pieces and 2 B pieces of a unit (piece = 16 rows x 64 B; lane -> row lane>>2,
+  // LDS slot lane&3 holding logical chunk slot ^ f(row)); rows past M / N are clamped to the last valid one (their products
+  // land in rows / columns the way out never stores).  Buffer-addressed LDS-DMA: wave-uniform operand base stepped 64 B per
+  // k-step, loop-invariant 32-bit lane offsets, one M0 per operand through the shared immediate (gemm_fl_kernel's scheme).
+  unsigned voff[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const bool isa = i < 4;
+    const int row = (isa ? (wave * 4 + i) : (wave * 2 + (i - 4))) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
+    const int64_t gr = isa ? ((m0 + row < g.M) ? m0 + row : g.M - 1) - m0 : ((n0 + row < g.N) ? n0 + row : g.N - 1) - n0;
+    const int64_t o = gr * (isa ? g.lda : g.ldb) + c * 8;
+    voff[i] = (unsigned)(o * 2 + 4096 - (isa ? i : i - 4) * 1024);
+  }
+  const char* base_a = (const char*)(A + m0 * g.lda) - 4096;
+  const char* base_b = (const char*)(B + n0 * g.ldb) - 4096;
+  int64_t kinc = kTwK * 2;  // bytes per k-step; 0 once parked
+  const int nk = (int)(g.K / kTwK);
+  auto issue = [&](int p, int unit) {  // piece p (0..3 A, 4..5 B) of this wave into ring unit `unit`
+    const unsigned ub = (unsigned)unit * kTwUnit;
+    switch (p) {
+      case 0: glds16_buf<0>(base_a, voff[0], smem, ub + (unsigned)wave * 4096u); break;
+      case 1: glds16_buf<1024>(base_a, voff[1], smem, ub + (unsigned)wave * 4096u); break;
+      case 2: glds16_buf<2048>(base_a, voff[2], smem, ub + (unsigned)wave * 4096u); break;
+      case 3: glds16_buf<3072>(base_a, voff[3], smem, ub + (unsigned)wave * 4096u); break;
+      case 4: glds16_buf<0>(base_b, voff[4], smem, ub + kTwA + (unsigned)wave * 2048u); break;
+      default: glds16_buf<1024>(base_b, voff[5], smem, ub + kTwA + (unsigned)wave * 2048u); break;
+    }
+    if (p == 5) {  // every piece of the unit is out: step both operands to the next k-step
+      base_a += kinc;
+      base_b += kinc;
+    }
+  };
+  auto park = [&]() {  // past the last k-step: keep the load counts uniform and re-read the last valid unit (idempotent)
+    base_a -= kinc;
+    base_b -= kinc;
+    kinc = 0;
+  };
+  // fragment addresses (absolute LDS byte addresses; the unit and the block go into the immediates)
+  const unsigned fsw = (unsigned)((-(l15 >> 2)) & 3);
+  const unsigned lds0 = lds_base_u32(smem);
+  const unsigned addr_x = lds0 + (unsigned)(wm * 128 + l15) * 64u + (((unsigned)g4 ^ fsw) * 16u);
+  const unsigned addr_w = lds0 + kTwA + (unsigned)(wn * 64 + l15) * 64u + (((unsigned)g4 ^ fsw) * 16u);
+
+  // prologue: units 0 and 1
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j == nk) park();
+#pragma unroll
+    for (int p = 0; p < 6; ++p) issue(p, j);
+  }
+  for (int j0 = 0; j0 < nk; j0 += kTwRing) {
+#pragma unroll
+    for (int u = 0; u < kTwRing; ++u) {
+      const int j = j0 + u;
+      if (j < nk) {
+        sched_fence();
+        if (j + 2 == nk) park();
+        wait_vmcnt<6>();  // own pieces of unit u (older than the 6 newest = unit u + 1's)
+        raw_barrier();    // everybody's; and everybody is done reading unit (u + 2) % 3 (k-step j - 1)
+        sched_fence();
+        u32x4 fw[4], fx[8];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) fw[nb] = lds_read16_abs(addr_w, u * (int)kTwUnit + nb * 1024);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) fx[mb] = lds_read16_abs(addr_x, u * (int)kTwUnit + mb * 1024);
+        gemm_wait_frag<8>(fw[0]);  // the four B fragments (8 reads were issued after the last of them)
+        gemm_wait_frag<8>(fw[1]);
+        gemm_wait_frag<8>(fw[2]);
+        gemm_wait_frag<8>(fw[3]);
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) {
+          switch (mb) {  // 7 - mb reads were issued after fx[mb]
+            case 0: gemm_wait_frag<7>(fx[0]); break;
+            case 1: gemm_wait_frag<6>(fx[1]); break;
+            case 2: gemm_wait_frag<5>(fx[2]); break;
+            case 3: gemm_wait_frag<4>(fx[3]); break;
+            case 4: gemm_wait_frag<3>(fx[4]); break;
+            case 5: gemm_wait_frag<2>(fx[5]); break;
+            case 6: gemm_wait_frag<1>(fx[6]); break;
+            default: gemm_wait_frag<0>(fx[7]); break;
+          }
+          sched_fence();
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[nb][mb] = mfma16<T>(fw[nb], fx[mb], acc[nb][mb]);
+          sched_fence();
+          if (mb >= 1 && mb <= 6) issue(mb - 1, (u + 2) % kTwRing);
+          sched_fence();
+        }
+      }
+    }
+  }
+  wait_vmcnt<0>();
+  raw_barrier();
+  gemm_epilogue16n<T, EPI, ACT>(g, acc, smem, (unsigned)wave * (64u * (64 * 2 + 16)), m0 + wm * 128, n0 + wn * 64, lane);
+}
+
 // out[m][n] = round(sum_s ws[s][m][n] (+ out[m][n] if ACCUM)): 4 columns per thread (16-byte reads, 8-byte stores)
 template <typename T, bool ACCUM>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
@@ -1099,6 +1282,19 @@ static int gemm_sm_launch(GemmArgs g, int epilogue, int act, hipStream_t s) {
 #undef TAMD_G
 }
 
+// the 256 x 128 kernel, two workgroups per CU (row-major operands, K % 32 == 0): tiles_n re-counted for its tile
+template <typename T>
+static int gemm_tw_launch(GemmArgs g, int epilogue, int act, hipStream_t s) {
+  g.tiles_m = (int)ceil_div(g.M, kTwBM);
+  g.tiles_n = (int)ceil_div(g.N, kTwBN);
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kTwThreads);
+#define TAMD_G(E_, A_)                                                                    \
+  hipLaunchKernelGGL((gemm_tw_kernel<T, E_, A_>), grid, block, (size_t)kTwSmem, s, g); \
+  return launch_status();
+  TAMD_EPI_SWITCH(TAMD_G)
+#undef TAMD_G
+}
+
 }  // namespace tamd
 
 using namespace tamd;
@@ -1237,7 +1433,7 @@ static int gemm_run(GemmArgs& g, int flags, int epilogue, int act, int dtype, vo
   const int64_t M = g.M, N = g.N, K = g.K;
   static const int forced = [] {
     const char* e = getenv("TAMD_GEMM");
-    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 's' ? 2 : 0)));
+    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 's' ? 2 : (e[0] == 't' ? 4 : 0))));
   }();
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
@@ -1254,6 +1450,9 @@ static int gemm_run(GemmArgs& g, int flags, int epilogue, int act, int dtype, vo
   // 128 x 128 tiles when the 256 x 256 grid would leave most of the GPU idle (and split-K, above, did not take the
   // problem: bias / activation / residual epilogues, short K): row-major operands only.  Threshold from the A/B of the two
   // kernels over tile counts, profiles/r03q_gemm_sm_ab.jsonl
+  if (sched == 4 && K % kTwK == 0 && flags == 0) {  // (hint only: the default dispatch does not select it yet)
+    TAMD_DISPATCH_HALF(dtype, return (gemm_tw_launch<T>(g, epilogue, act, TAMD_STREAM(stream))));
+  }
   if (K % kXK == 0 && flags == 0 && (sched == 2 || (sched == 0 && (int64_t)g.tiles_m * g.tiles_n <= kSmMaxBigTiles))) {
     TAMD_DISPATCH_HALF(dtype, return (gemm_sm_launch<T>(g, epilogue, act, TAMD_STREAM(stream))));
   }

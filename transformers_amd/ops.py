@@ -241,7 +241,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int, flags: int = 0) 
     return -(-nst // sps) * m * n * 4
 
 
-GEMM_SCHED = {None: 0, "pp": 1, "sm": 2, "fl": 3}  # TAMD_GEMM_SCHED_* >> 8 (include/tamd.h)
+GEMM_SCHED = {None: 0, "pp": 1, "sm": 2, "fl": 3, "tw": 4}  # TAMD_GEMM_SCHED_* >> 8 (include/tamd.h)
 
 
 def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None,
