@@ -126,6 +126,10 @@ inline unsigned long long ballot64(bool pred) {
   memcpy(&m, hipemu::cur_wave().out[lane], 8);
   return m;
 }
+inline float lane_select(unsigned long long mask, float if_set, float if_clear) {
+  return ((mask >> hipemu::cur_lane()) & 1ull) ? if_set : if_clear;
+}
+inline unsigned long long uniform_u64(const unsigned long long* table, long long idx) { return table[idx]; }
 
 // ---------------------------------------------------------------- MFMA
 template <typename T>

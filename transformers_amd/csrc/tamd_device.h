@@ -71,6 +71,18 @@ __device__ __forceinline__ int lane_id_mbcnt() {
 // 64-bit mask of the lanes whose predicate is true
 __device__ __forceinline__ unsigned long long ballot64(bool pred) { return __ballot(pred); }
 
+// The inverse: a WAVE-UNIFORM 64-bit mask (bit l = lane l) as a per-lane choice -- one v_cndmask_b32 with the mask in an SGPR
+// pair, no per-lane bit arithmetic.
+__device__ __forceinline__ float lane_select(unsigned long long mask, float if_set, float if_clear) {
+  return __builtin_amdgcn_inverse_ballot_w64(mask) ? if_set : if_clear;
+}
+// 64-bit word `idx` of a read-only table at a WAVE-UNIFORM address: a scalar load (s_load_dwordx2 .. x16 when neighbouring
+// words are read together) through the constant address space -- the value arrives in SGPRs, ready for lane_select
+__device__ __forceinline__ unsigned long long uniform_u64(const unsigned long long* table, long long idx) {
+  typedef const __attribute__((address_space(4))) unsigned long long* cptr64;
+  return ((cptr64)(table))[idx];
+}
+
 // ---------------------------------------------------------------- MFMA
 template <typename T>
 __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c);
