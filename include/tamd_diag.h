@@ -19,6 +19,9 @@ int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M, int64_t N,
  * of a tamd_gemm launch stores {shader-clock ticks, 100 MHz real-time ticks} of its K loop at buf[2 * workgroup].
  * NULL switches it off.  tools/gemm_clock.py */
 int tamd_gemm_set_clock_buffer(void* buf);
+/* 3 x uint64 per workgroup of the next gemm_fl_kernel launches: {s_memrealtime (100 MHz) at kernel entry, at exit, XCC id} --
+ * the grid's timeline: ramp, tail, whether the XCDs finish together (tools/gemm_timeline.py); NULL switches it off */
+int tamd_gemm_set_timeline_buffer(void* buf);
 
 /* Ablation / A-B selector for the full-line GEMM kernel (plain epilogue).  Row-major operands, WRONG RESULTS by design:
  * bit mask 1 no LDS-DMA after the prologue, 2 no LDS fragment reads, 4 no vmcnt wait at the hand-off, 8 no barrier

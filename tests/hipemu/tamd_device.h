@@ -409,6 +409,7 @@ inline void setprio_hi() {}
 inline void setprio_lo() {}
 inline unsigned long long device_clock() { return 0ull; }
 inline unsigned long long device_realtime() { return 0ull; }
+inline unsigned device_xcc_id() { return 0u; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
 inline float fast_log2(float x) { return log2f(x); }

@@ -86,6 +86,7 @@ SIGNATURES = {
 DIAG_SIGNATURES = {
     "tamd_gemm_trace": (c_int, [P, P, P, I64, I64, I64, P, P]),
     "tamd_gemm_set_clock_buffer": (c_int, [P]),
+    "tamd_gemm_set_timeline_buffer": (c_int, [P]),
     "tamd_gemm_set_dbg": (c_int, [c_int]),
     "tamd_attn_set_trace": (c_int, [P]),
     "tamd_mfma_power": (c_int, [P, c_int, c_int, c_int, P, P, P]),

@@ -116,8 +116,9 @@ AttnArgs make_args(const tamd_attn_params* p) {
   // the keep-scale is the inverse of the EFFECTIVE keep probability (65536 - thr) / 65536 of the quantised threshold, so that
   // E[keep * scale] == 1 exactly (1 / (1 - p) differs from it by <= 2^-16 relative: p = 0.1 -> thr 6553, p_eff 0.09999)
   a.drop_scale = (a.drop_thr != 0u && pd < 1.0) ? (float)(65536.0 / (65536.0 - (double)a.drop_thr)) : 1.f;
-  a.seed_lo = (unsigned)p->dropout_seed;
-  a.seed_hi = (unsigned)(p->dropout_seed >> 32);
+  const unsigned long long mixed = attn_seed_mix(p->dropout_seed);  // (dropout.h: the kernels' block mix takes a mixed seed)
+  a.seed_lo = (unsigned)mixed;
+  a.seed_hi = (unsigned)(mixed >> 32);
   a.nqt = (int)ceil_div(p->seq_q, kQB);
   a.xcd_map = ((p->batch * p->heads_kv) % 8 == 0) ? 1 : 0;
   a.q_prescaled = p->q_prescaled != 0;
@@ -145,7 +146,8 @@ extern "C" uint32_t tamd_dropout_hash(uint64_t seed, uint64_t index) {
 }
 extern "C" uint32_t tamd_attn_dropout_field(uint64_t seed, uint64_t batch_head, uint64_t seq_q, uint64_t seq_k, uint64_t q,
                                             uint64_t k) {
-  return attn_dropout_field((unsigned)seed, (unsigned)(seed >> 32), batch_head, seq_q, seq_k, q, k);
+  const unsigned long long mixed = attn_seed_mix(seed);
+  return attn_dropout_field((unsigned)mixed, (unsigned)(mixed >> 32), batch_head, seq_q, seq_k, q, k);
 }
 
 extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream) {

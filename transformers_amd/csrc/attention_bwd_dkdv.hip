@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   bool key_ok = krow < a.seq_k;
   if (HAS_MASK && a.key_valid != nullptr)
     key_ok = key_ok && a.key_valid[(int64_t)b * a.seq_k + (krow < a.seq_k ? krow : 0)] != 0;
-  const AttnDrop drop = {a.drop_thr, a.seed_lo, a.seed_hi, a.drop_scale, ((unsigned long long)a.seq_q + 1) >> 1,
+  const AttnDrop drop = {a.drop_thr << 16, a.seed_lo, a.seed_hi, a.drop_scale, ((unsigned long long)a.seq_q + 1) >> 1,
                          ((unsigned long long)a.seq_k + 1) >> 1};
   // lane part of a block index: this lane's key pair + the 2 * hi query pairs its rows sit above the chunk's first one
   // (rows / keys past the end index blocks of other rows: their probabilities are zero anyway)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       }
       float p[4], ds[4];
       const int ql = sub * 32 + 8 * qd + 4 * hi;  // 4 consecutive query rows (r&3)
-      float keep4[4] = {1.f, 1.f, 1.f, 1.f};
+      bool keep4[4] = {true, true, true, true};
       if (DROP) {  // rows ql + 2j, ql + 2j + 1 share a hash; this lane's key picks the word, the row its half
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           unsigned w0, w1;
           drop.words(drop_tile + (unsigned long long)(sub * 16 + 4 * qd + j) * drop.csk + drop_lane, w0, w1);
           const unsigned w = drop_kodd ? w1 : w0;
-          keep4[2 * j] = drop.keep(w & 0xffffu);
-          keep4[2 * j + 1] = drop.keep(w >> 16);
+          keep4[2 * j] = drop.kept_lo(w);
+          keep4[2 * j + 1] = drop.kept_hi(w);
         }
       }
 #pragma unroll
@@ -400,9 +400,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         else if (!PLAIN)
           x = (mask_lim <= ql + e) ? x : -INFINITY;
         const float pe = fast_exp2(x);  // x = S*scale*log2(e) - lse*log2(e): the chain started from -lse*log2(e)
-        const float keep = keep4[e];
-        p[e] = pe * keep;  // dV uses the dropped probabilities
-        ds[e] = FOLD_DELTA ? pe * dp[sub][r] : pe * (dp[sub][r] * keep + u32_as_f32(d4[e]));  // (d4 = -delta)
+        // dV uses the dropped probabilities; their factor 1 / (1 - p) multiplies the finished dV rows, dP's rides in the fma
+        p[e] = (DROP && !keep4[e]) ? 0.f : pe;
+        ds[e] = FOLD_DELTA ? pe * dp[sub][r]
+                           : pe * fmaf((DROP && !keep4[e]) ? 0.f : dp[sub][r], drop.scale, u32_as_f32(d4[e]));  // (d4 = -delta)
       }
       const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
       pf[op][w] = pack2<T>(p[0], p[1]);
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
                            reinterpret_cast<const T*>(g.rope_sin),
                            (g.rope_cos_batch == 1 ? 0 : (int64_t)b * a.seq_k) + kw0);  // (rotary: key position = row index)
   wave_lockstep_point();
-  store_rows_via_lds<T, D>(dvacc, 1.f, smem, st, dV, a.vss, kw0, a.seq_k, lane);
+  store_rows_via_lds<T, D>(dvacc, DROP ? drop.scale : 1.f, smem, st, dV, a.vss, kw0, a.seq_k, lane);  // (dropout: P's 1 / (1 - p))
 }
 
 template <typename T, int D>

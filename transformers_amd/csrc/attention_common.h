@@ -34,7 +34,7 @@ struct AttnArgs {
   float scale_log2;  // scale * log2(e)
   unsigned drop_thr;  // keep iff the element's 16-bit hash field >= drop_thr (0 = no dropout); dropout.h AttnDrop
   float drop_scale;   // 65536 / (65536 - drop_thr): 1 / (1 - p) of the quantised p (attention.hip make_args)
-  unsigned seed_lo, seed_hi;
+  unsigned seed_lo, seed_hi;  // the halves of attn_seed_mix(dropout seed) (dropout.h)
   int nqt;           // query tiles per (b, h)
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
   int q_prescaled;   // 1: q already carries scale*log2(e) (include/tamd.h): no operand is scaled and re-rounded here

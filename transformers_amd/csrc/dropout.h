@@ -29,43 +29,69 @@ struct DropCtx {
   }
 };
 
-// Attention dropout: ONE hash decides a 2 x 2 block of the probability matrix (query pair x key pair), 16 bits per element
-// -- the mix above costs 13 integer instructions, and the attention loops are bound by instruction issue (at bert-base the
-// per-element hash cost more than the attention itself: 116 / 131 / 154 us per layer against 38 / 131 for forward /
-// backward without dropout, profiles/r03c_bert_kernel_stats.csv).  Element (b, h, q, k), bh = b * heads_q + h:
+// Attention dropout: ONE hash decides a 2 x 2 block of the probability matrix (query pair x key pair), 16 bits per element.
+// Element (b, h, q, k), bh = b * heads_q + h:
 //     block = (bh * ceil(Sq / 2) + (q >> 1)) * ceil(Sk / 2) + (k >> 1)
-//     w0 = dropout_hash(seed, block),  w1 = dropout_hash_second(w0);   word = (k & 1) ? w1 : w0
+//     (w0, w1) = attn_block_words(mix(seed), block);   word = (k & 1) ? w1 : w0
 //     field = (q & 1) ? word >> 16 : word & 0xffff;                     kept iff field >= thr16 = floor(p * 65536)
 // The forward and dQ kernels own one query row and consecutive key pairs per lane (both words, one half each), the dK/dV
-// kernel one key and consecutive query pairs (one word, both halves): every kernel halves its hash count.
-__host__ __device__ __forceinline__ unsigned dropout_hash_second(unsigned x) {
-  unsigned y = (x ^ 0x85EBCA77u) * 0x9E3779B1u;
-  y ^= y >> 15;
-  y *= 0xC2B2AE3Du;
-  y ^= y >> 16;
-  return y;
+// kernel one key and consecutive query pairs (one word, both halves).
+// Round 4: the attention loops are bound by instruction issue, and 32-bit integer multiplies issue at a quarter of the
+// VALU rate on gfx950 -- the round-3 mix (3 + 2 of them per block, dropout_hash + a second word) cost ~34 issue slots per
+// block; with dropout 0.1 the bert-base attention kernels ran 93 / 195 us forward / backward against 42 / 129 without
+// (profiles/r04a_attn_dropout_ab.jsonl).  attn_block_words is built from v_mul_u32_u24 / v_mad_u32_u24 (full rate: the low
+// 24 bits of a 32-bit word by a 24-bit constant; two of them, on bits 0..23 and 8..31, cover the word) and xor-shifts:
+// ~17 slots for the 64 bits.  The 63-bit seed is mixed once on the host (splitmix64: seeds that differ in one bit give
+// unrelated masks -- the block mix alone would not: its second input enters by addition).  Statistics (keep rate, row /
+// column variance, neighbour, head-to-head and seed-to-seed correlation, chi-square of the fields) were checked against the
+// round-3 mix: tools/probes/dropout_hash_stats.py.
+__host__ __device__ __forceinline__ unsigned long long attn_seed_mix(unsigned long long seed) {
+  unsigned long long z = seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
 }
-__host__ __device__ __forceinline__ unsigned attn_dropout_field(unsigned seed_lo, unsigned seed_hi, unsigned long long bh,
+__host__ __device__ __forceinline__ unsigned mul24(unsigned a, unsigned k24) { return (a & 0xFFFFFFu) * k24; }  // v_mul_u32_u24
+// s0, s1: the two halves of attn_seed_mix(seed)
+__host__ __device__ __forceinline__ void attn_block_words(unsigned s0, unsigned s1, unsigned blk_lo, unsigned blk_hi,
+                                                          unsigned& w0, unsigned& w1) {
+  unsigned x = blk_lo ^ s0;
+  x = mul24(x, 0x9E3779u) + mul24(x >> 8, 0x85EBCBu) + (s1 + mul24(blk_hi, 0x632BE5u));
+  x ^= x >> 15;
+  x = mul24(x, 0xC2B2AFu) + mul24(x >> 8, 0x27D4EBu);
+  x ^= x >> 13;
+  w0 = x;
+  const unsigned t = x ^ 0x165667B1u;
+  unsigned z = mul24(t, 0xD3A265u) + mul24(t >> 8, 0x7F4A7Du);
+  z ^= z >> 16;
+  w1 = z;
+}
+__host__ __device__ __forceinline__ unsigned attn_dropout_field(unsigned s0, unsigned s1, unsigned long long bh,
                                                                 unsigned long long seq_q, unsigned long long seq_k,
                                                                 unsigned long long q, unsigned long long k) {
   const unsigned long long blk = (bh * ((seq_q + 1) >> 1) + (q >> 1)) * ((seq_k + 1) >> 1) + (k >> 1);
-  const unsigned w0 = dropout_hash(seed_lo, seed_hi, (unsigned)blk, (unsigned)(blk >> 32));
-  const unsigned w = (k & 1) ? dropout_hash_second(w0) : w0;
+  unsigned w0, w1;
+  attn_block_words(s0, s1, (unsigned)blk, (unsigned)(blk >> 32), w0, w1);
+  const unsigned w = (k & 1) ? w1 : w0;
   return (q & 1) ? (w >> 16) : (w & 0xffffu);
 }
 struct AttnDrop {
-  unsigned thr16, seed_lo, seed_hi;
-  float scale;
+  unsigned thr_hi;  // thr16 << 16: a 16-bit field f in the high half of w is kept iff w >= thr_hi, one in the low half iff
+                    // (w << 16) >= thr_hi -- no field extraction
+  unsigned s0, s1;  // the halves of attn_seed_mix(seed)
+  float scale;      // 65536 / (65536 - thr16); the kernels apply it ONCE per output row (O, dV) or inside an fma (dS), not per element
   unsigned long long csq, csk;  // ceil(seq_q / 2), ceil(seq_k / 2)
   // block index of (bh, query q, key 0) -- add (k >> 1)
   __device__ __forceinline__ unsigned long long row_base(unsigned long long bh, unsigned long long q) const {
     return (bh * csq + (q >> 1)) * csk;
   }
   __device__ __forceinline__ void words(unsigned long long blk, unsigned& w0, unsigned& w1) const {
-    w0 = dropout_hash(seed_lo, seed_hi, (unsigned)blk, (unsigned)(blk >> 32));
-    w1 = dropout_hash_second(w0);
+    attn_block_words(s0, s1, (unsigned)blk, (unsigned)(blk >> 32), w0, w1);
   }
-  __device__ __forceinline__ float keep(unsigned field) const { return field >= thr16 ? scale : 0.f; }
+  // is the element whose field is the low / high half of w kept?  (lsh = 16 for the low half, 0 for the high half)
+  __device__ __forceinline__ bool kept(unsigned w, unsigned lsh) const { return (w << lsh) >= thr_hi; }
+  __device__ __forceinline__ bool kept_lo(unsigned w) const { return (w << 16) >= thr_hi; }
+  __device__ __forceinline__ bool kept_hi(unsigned w) const { return w >= thr_hi; }
 };
 
 // keep threshold / scale of a dropout probability (0 -> disabled)

@@ -67,9 +67,20 @@ __device__ __attribute__((aligned(16))) static const unsigned int g_zero16[4] = 
     g.trace[2 * (size_t)vbid] = device_clock() - clk_t0;  \
     g.trace[2 * (size_t)vbid + 1] = device_realtime() - clk_r0; \
   }
+// ... and a timeline (tamd_gemm_set_timeline_buffer): {real-time stamp at kernel entry, at exit (after the way out), XCC id}
+// at timeline[3 * workgroup]: how long the grid's tail is, whether the XCDs finish together.  tools/gemm_timeline.py
+#define TAMD_TIMELINE_BEGIN const unsigned long long tl_r0 = g.timeline ? device_realtime() : 0ull;
+#define TAMD_TIMELINE_END                                                                            \
+  if (g.timeline != nullptr && (threadIdx.x & 63) == 0 && wave_id_uniform() == 0) {                  \
+    g.timeline[3 * (size_t)blockIdx.x] = tl_r0;                                                      \
+    g.timeline[3 * (size_t)blockIdx.x + 1] = device_realtime();                                      \
+    g.timeline[3 * (size_t)blockIdx.x + 2] = (unsigned long long)device_xcc_id();                     \
+  }
 #else
 #define TAMD_CLOCK_BEGIN
 #define TAMD_CLOCK_END
+#define TAMD_TIMELINE_BEGIN
+#define TAMD_TIMELINE_END
 #endif
 
 struct GemmArgs {
@@ -81,6 +92,7 @@ struct GemmArgs {
   int64_t M, N, K, lda, ldb, ldc, ldr;
   int tiles_m, tiles_n;
   unsigned long long* trace;  // diagnostic: per-phase shader-clock stamps of workgroup 0 (tamd_gemm_trace)
+  unsigned long long* timeline;  // diagnostic: entry / exit real-time stamps and XCC id per workgroup (gemm_fl_kernel)
   // split-K (gemm_fl_kernel with EPI = kEpiSplitK): workgroup id = tile * splits + split; split s reduces stages
   // [s*stages_per_split, ...) and writes an fp32 partial tile to ws[s][M][N]; splitk_reduce_kernel sums and rounds
   float* ws;
@@ -622,6 +634,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int g4 = lane >> 4, l15 = lane & 15;
   const int vbid = (int)blockIdx.x;
+  TAMD_TIMELINE_BEGIN
   TAMD_CLOCK_BEGIN
   int tile_m, tile_n;
   const int split = (EPI == kEpiSplitK) ? (int)((unsigned)vbid % (unsigned)g.splits) : 0;
@@ -832,6 +845,7 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
         g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
   }
+  TAMD_TIMELINE_END
 }
 
 // ============================================================================================ small tile
@@ -1309,6 +1323,11 @@ extern "C" int tamd_gemm_set_clock_buffer(void* buf) {
   g_gemm_clock = reinterpret_cast<unsigned long long*>(buf);
   return TAMD_OK;
 }
+static unsigned long long* g_gemm_timeline = nullptr;
+extern "C" int tamd_gemm_set_timeline_buffer(void* buf) {  // 3 x uint64 per workgroup of the next gemm_fl_kernel launches
+  g_gemm_timeline = reinterpret_cast<unsigned long long*>(buf);
+  return TAMD_OK;
+}
 #endif
 
 static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, const void* bias, const void* R,
@@ -1329,8 +1348,10 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->tiles_n = (int)ceil_div(N, kBN);
 #ifdef TAMD_DIAG
   g->trace = g_gemm_clock;
+  g->timeline = g_gemm_timeline;
 #else
   g->trace = nullptr;
+  g->timeline = nullptr;
 #endif
   g->ws = nullptr;
   g->splits = 1;

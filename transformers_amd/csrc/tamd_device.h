@@ -247,6 +247,8 @@ __device__ __forceinline__ void setprio_lo() { __builtin_amdgcn_s_setprio(0); }
 __device__ __forceinline__ unsigned long long device_clock() { return __builtin_amdgcn_s_memtime(); }
 // constant-rate (100 MHz) counter: shader-clock ticks / real-time ticks = the clock a kernel actually ran at
 __device__ __forceinline__ unsigned long long device_realtime() { return __builtin_amdgcn_s_memrealtime(); }
+// the XCD this wave runs on (HW_REG_XCC_ID = 20, bits 3:0), for the diagnostic timelines
+__device__ __forceinline__ unsigned device_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xfu; }
 
 
 // fast transcendental pieces

@@ -870,29 +870,36 @@ def dropout_seed() -> int:
 
 
 def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int, p: float) -> torch.Tensor:
-    """The attention kernels' keep mask [B,H,Sq,Sk] (bool), rebuilt on the host (csrc/dropout.h: one hash decides a 2 x 2
-    block -- query pair x key pair -- of the probability matrix, 16 bits per element; include/tamd.h
-    tamd_attn_dropout_field is the same function element by element) -- for tests/debugging."""
+    """The attention kernels' keep mask [B,H,Sq,Sk] (bool), rebuilt on the host (csrc/dropout.h: the seed is mixed once by
+    splitmix64; one 64-bit mix of 24-bit multiplies decides a 2 x 2 block -- query pair x key pair -- of the probability
+    matrix, 16 bits per element; include/tamd.h tamd_attn_dropout_field is the same function element by element) -- for
+    tests/debugging."""
     import numpy as np
 
+    m64 = (1 << 64) - 1
+    z = int(seed) & m64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m64
+    z ^= z >> 31
+    s0, s1 = np.uint32(z & 0xFFFFFFFF), np.uint32(z >> 32)
     csq, csk = (seq_q + 1) // 2, (seq_k + 1) // 2
     bh = np.arange(batch * heads, dtype=np.uint64)[:, None, None]
     qb = (np.arange(seq_q, dtype=np.uint64) >> np.uint64(1))[None, :, None]
     kb = (np.arange(seq_k, dtype=np.uint64) >> np.uint64(1))[None, None, :]
     idx = (bh * np.uint64(csq) + qb) * np.uint64(csk) + kb
     lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
-    slo, shi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+
+    def mul24(a, k24):  # v_mul_u32_u24
+        return (a & np.uint32(0xFFFFFF)) * np.uint32(k24)
+
     with np.errstate(over="ignore"):
-        x = (lo ^ slo) * np.uint32(0x9E3779B1)
+        x = lo ^ s0
+        x = mul24(x, 0x9E3779) + mul24(x >> np.uint32(8), 0x85EBCB) + (s1 + mul24(hi, 0x632BE5))
         x ^= x >> np.uint32(15)
-        x += (hi * np.uint32(0x85EBCA77)) ^ shi
-        x *= np.uint32(0xC2B2AE3D)
+        x = mul24(x, 0xC2B2AF) + mul24(x >> np.uint32(8), 0x27D4EB)
         x ^= x >> np.uint32(13)
-        x *= np.uint32(0x27D4EB2F)
-        x ^= x >> np.uint32(16)
-        y = (x ^ np.uint32(0x85EBCA77)) * np.uint32(0x9E3779B1)  # the second word (odd keys)
-        y ^= y >> np.uint32(15)
-        y *= np.uint32(0xC2B2AE3D)
+        t = x ^ np.uint32(0x165667B1)
+        y = mul24(t, 0xD3A265) + mul24(t >> np.uint32(8), 0x7F4A7D)  # the second word (odd keys)
         y ^= y >> np.uint32(16)
     k_odd = (np.arange(seq_k) & 1).astype(bool)[None, None, :]
     q_odd = (np.arange(seq_q) & 1).astype(bool)[None, :, None]
