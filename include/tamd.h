@@ -240,9 +240,9 @@ int tamd_gemm(const void* A, const void* B, void* C, const void* bias, const voi
               int dtype, tamd_stream_t stream);
 /* Same product with an optional fp32 workspace that allows split-K: tile grids too small to fill the GPU (weight
  * gradients of narrow layers) are cut along K, partial tiles go to the workspace and a second kernel reduces and rounds
- * them.  tamd_gemm_workspace_bytes() returns the size that enables it (0: split-K would not be used; TAMD_EPI_NONE /
- * TAMD_EPI_ACCUM only).  With workspace == NULL this is tamd_gemm.  Results differ from the unsplit kernel only by
- * fp32 summation order. */
+ * them.  tamd_gemm_workspace_bytes() returns the size that enables it (0: split-K would not be used; every epilogue
+ * but TAMD_EPI_BIAS_ACT splits: the reduction applies bias / residual / accumulate with the unsplit kernel's roundings).
+ * With workspace == NULL this is tamd_gemm.  Results differ from the unsplit kernel only by fp32 summation order. */
 size_t tamd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int flags, int epilogue);
 int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N, int64_t K,
                  int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act, int dtype,

@@ -326,7 +326,8 @@ def test_gemm_split_k(env):
     assert lib.tamd_gemm_workspace_bytes(256, 256, 2048, 3, ops.EPI_NONE) > 0   # the same product as a weight gradient: split
     for (m, n, k) in shapes:
         assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE) > 0
-        assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_BIAS) == 0      # only plain / accumulate split
+        assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_BIAS) > 0       # (round 4: the reduction applies the epilogue)
+        assert lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_BIAS_ACT) == 0  # ... except an activation
         x = torch.randn(m, k).bfloat16().to(dev)
         w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
         ref = x.float() @ w.float().t()
@@ -340,10 +341,22 @@ def test_gemm_split_k(env):
         out = res.clone()
         ops.raw_gemm(xt, wt, a_km=True, b_kn=True, epilogue=ops.EPI_ACCUM, out=out)
         assert rel_err(out, ref.bfloat16().float() + res.float()) < 0.0035
+        # bias / residual (+ bias) epilogues through the split: the unsplit kernel's roundings (CLIP fc2, o_proj / down_proj of a
+        # short prompt: modeling_clip.py:346-350, modeling_llama.py:280, :176)
+        bias = torch.randn(n).bfloat16().to(dev)
+        for kw2 in (dict(bias=bias, epilogue=ops.EPI_BIAS), dict(residual=res, epilogue=ops.EPI_RESIDUAL),
+                    dict(bias=bias, residual=res, epilogue=ops.EPI_RESIDUAL)):
+            c = ops.raw_gemm(x, w, **kw2)
+            unsplit = ops.raw_gemm(x, w, sched="fl", **kw2)
+            want = ref + (bias.float() if "bias" in kw2 else 0)
+            if "residual" in kw2:
+                want = want.bfloat16().float() + res.float()
+            assert rel_err(c, want) < 0.0034, (m, n, k, list(kw2))
+            assert rel_err(c, unsplit) < 0.00015 and (c != unsplit).float().mean() < 0.2, (m, n, k, list(kw2))
     assert lib.tamd_gemm_workspace_bytes(32768, 4096, 4096, 0, ops.EPI_NONE) == 0  # enough tiles: no split
     for (m, n, k) in [(768, 3072, 16384), (768, 768, 512), (256, 256, 2048), (2304, 768, 16384), (4096, 4096, 32768),
                       (30522, 768, 16384), (264, 136, 2560), (128, 4, 4096), (1000, 1000, 1000)]:
-        for epi in (ops.EPI_NONE, ops.EPI_ACCUM, ops.EPI_BIAS):  # the host-side mirror of the policy stays in step
+        for epi in (ops.EPI_NONE, ops.EPI_ACCUM, ops.EPI_BIAS, ops.EPI_RESIDUAL, ops.EPI_BIAS_ACT):  # the host-side mirror stays in step
             assert ops.gemm_workspace_bytes(m, n, k, epi) == lib.tamd_gemm_workspace_bytes(m, n, k, 0, epi), (m, n, k, epi)
             assert ops.gemm_workspace_bytes(m, n, k, epi, 3) == lib.tamd_gemm_workspace_bytes(m, n, k, 3, epi), (m, n, k, epi)
 
@@ -832,16 +845,16 @@ def test_attention_backward_rope_epilogue_is_bit_identical_to_unfused(env):
 
 
 def test_residual_epilogue_on_a_small_grid_goes_through_split_k(env):
-    """o_proj / down_proj of a short prompt (80 tiles of 256 x 256 on 256 CUs): ops.raw_gemm turns the residual epilogue
-    into copy + accumulate so that split-K applies: the roundings of the one-kernel residual epilogue (the fp32 partial
-    sums of the K ranges are added in a different order)."""
+    """o_proj / down_proj of a short prompt (80 tiles of 256 x 256 on 256 CUs) go through split-K, whose reduction applies the
+    residual: the roundings of the one-kernel residual epilogue (the fp32 partial sums of the K ranges are added in a
+    different order)."""
     torch.manual_seed(47)
     dev = env.device
     for (m, n, k) in ([(1088, 4096, 11008), (577, 1024, 4096)] if env.big else [(200, 264, 4096)]):
         x = torch.randn(m, k).bfloat16().to(dev)
         w = (torch.randn(n, k) * 0.05).bfloat16().to(dev)
         r = torch.randn(m, n).bfloat16().to(dev)
-        assert ops.gemm_workspace_bytes(m, n, k, ops.EPI_ACCUM) > 0
+        assert ops.gemm_workspace_bytes(m, n, k, ops.EPI_RESIDUAL) > 0
         ref = ops.raw_gemm(x, w, residual=r, epilogue=ops.EPI_RESIDUAL, sched="fl")  # a schedule hint turns split-K off
         got = ops.raw_gemm(x, w, residual=r, epilogue=ops.EPI_RESIDUAL)
         # split-K sums the fp32 partials of the K ranges: not the bits of the unsplit order, but the same roundings

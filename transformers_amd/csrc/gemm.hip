@@ -1133,31 +1133,41 @@ __global__ __launch_bounds__(kTwThreads, 2) void gemm_tw_kernel(GemmArgs g) {
   gemm_epilogue16n<T, EPI, ACT>(g, acc, smem, (unsigned)wave * (64u * (64 * 2 + 16)), m0 + wm * 128, n0 + wn * 64, lane);
 }
 
-// out[m][n] = round(sum_s ws[s][m][n] (+ out[m][n] if ACCUM)): 4 columns per thread (16-byte reads, 8-byte stores)
-template <typename T, bool ACCUM>
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, int64_t M, int64_t N, int64_t ldc,
-                                     int splits) {
+// out[m][n] = epilogue(sum_s ws[s][m][n]): 4 columns per thread (16-byte reads, 8-byte stores).  The reduction applies the
+// product's epilogue with the roundings of the unsplit kernel -- MODE = TAMD_EPI_NONE round(acc); TAMD_EPI_BIAS
+// round(acc + bias); TAMD_EPI_RESIDUAL round(round(acc [+ bias]) + R); TAMD_EPI_ACCUM round(round(acc) + C_old) -- so a
+// bias / residual product on a grid that cannot fill the GPU (CLIP fc2: 12 tiles over K = 4096; o_proj / down_proj of a
+// short prompt) splits like a plain one (round 3 sent those to the 128 x 128 kernel, or copied the residual into C first and
+// accumulated onto it: 41 us against hipBLASLt's 19 for CLIP fc2, profiles/r04b_gemm_tw_ab.jsonl).
+template <typename T, int MODE>
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, const T* __restrict__ bias,
+                                     const T* __restrict__ R, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int splits) {
+  typedef typename elem<T>::raw raw;
   const int64_t nvec = M * (N / 4);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nvec; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = idx / (N / 4), n = (idx % (N / 4)) * 4;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int sidx = 0; sidx < splits; ++sidx) {
       const u32x4 v = ld16(ws + ((int64_t)sidx * M + m) * N + n);
-      a0 += u32_as_f32(v[0]);
-      a1 += u32_as_f32(v[1]);
-      a2 += u32_as_f32(v[2]);
-      a3 += u32_as_f32(v[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += u32_as_f32(v[e]);
     }
     T* out = C + m * ldc + n;
-    if (ACCUM) {  // TAMD_EPI_ACCUM: round(acc) + C_old, as the unsplit epilogue does
-      const u32x2 o = ld8(out);
-      typedef typename elem<T>::raw raw;
-      a0 = round_through<T>(a0) + elem<T>::to_f32((raw)(o[0] & 0xffffu));
-      a1 = round_through<T>(a1) + elem<T>::to_f32((raw)(o[0] >> 16));
-      a2 = round_through<T>(a2) + elem<T>::to_f32((raw)(o[1] & 0xffffu));
-      a3 = round_through<T>(a3) + elem<T>::to_f32((raw)(o[1] >> 16));
+    if ((MODE == TAMD_EPI_BIAS || MODE == TAMD_EPI_RESIDUAL) && bias != nullptr) {
+      const u32x2 bq = ld8(bias + n);
+      a[0] += elem<T>::to_f32((raw)(bq[0] & 0xffffu));
+      a[1] += elem<T>::to_f32((raw)(bq[0] >> 16));
+      a[2] += elem<T>::to_f32((raw)(bq[1] & 0xffffu));
+      a[3] += elem<T>::to_f32((raw)(bq[1] >> 16));
     }
-    st8(out, u32x2{pack2<T>(a0, a1), pack2<T>(a2, a3)});
+    if (MODE == TAMD_EPI_ACCUM || MODE == TAMD_EPI_RESIDUAL) {
+      const u32x2 o = ld8(MODE == TAMD_EPI_ACCUM ? (const T*)out : R + m * ldr + n);
+      a[0] = round_through<T>(a[0]) + elem<T>::to_f32((raw)(o[0] & 0xffffu));
+      a[1] = round_through<T>(a[1]) + elem<T>::to_f32((raw)(o[0] >> 16));
+      a[2] = round_through<T>(a[2]) + elem<T>::to_f32((raw)(o[1] & 0xffffu));
+      a[3] = round_through<T>(a[3]) + elem<T>::to_f32((raw)(o[1] >> 16));
+    }
+    st8(out, u32x2{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3])});
   }
 }
 
@@ -1248,7 +1258,8 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
 #undef TAMD_G
 }
 
-// split-K: partial tiles into the fp32 workspace, then the reduction (TAMD_EPI_NONE / TAMD_EPI_ACCUM only)
+// split-K: partial tiles into the fp32 workspace, then the reduction, which applies the epilogue (plain / bias / residual /
+// accumulate)
 template <typename T, bool A_KM, bool B_KN>
 static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n * g.splits)), block(kFlThreads);
@@ -1256,12 +1267,16 @@ static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, hipStream_t s
   const int64_t nvec = g.M * (g.N / 4);
   int64_t blocks = ceil_div(nvec, 256);
   if (blocks > 4096) blocks = 4096;
-  if (epilogue == TAMD_EPI_ACCUM)
-    hipLaunchKernelGGL((splitk_reduce_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, g.ws, (T*)g.C, g.M, g.N,
-                       g.ldc, g.splits);
-  else
-    hipLaunchKernelGGL((splitk_reduce_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, g.ws, (T*)g.C, g.M,
-                       g.N, g.ldc, g.splits);
+#define TAMD_RK(MODE_)                                                                                                   \
+  hipLaunchKernelGGL((splitk_reduce_kernel<T, MODE_>), dim3((unsigned)blocks), dim3(256), 0, s, g.ws, (T*)g.C,          \
+                     (const T*)g.bias, (const T*)g.R, g.M, g.N, g.ldc, g.ldr, g.splits)
+  switch (epilogue) {
+    case TAMD_EPI_ACCUM: TAMD_RK(TAMD_EPI_ACCUM); break;
+    case TAMD_EPI_BIAS: TAMD_RK(TAMD_EPI_BIAS); break;
+    case TAMD_EPI_RESIDUAL: TAMD_RK(TAMD_EPI_RESIDUAL); break;
+    default: TAMD_RK(TAMD_EPI_NONE); break;
+  }
+#undef TAMD_RK
   return launch_status();
 }
 
@@ -1394,7 +1409,7 @@ extern "C" int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M,
 //     split-K wins, 58 vs 65 us at K = 4096 and 105 vs 158 at 11008: profiles/r03q_gemm_sm_ab.jsonl)
 static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int flags, int epilogue, int* stages_per_split) {
   *stages_per_split = 0;
-  if (K % kXK != 0 || (N % 4) != 0 || (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM)) return 1;
+  if (K % kXK != 0 || (N % 4) != 0 || epilogue == TAMD_EPI_BIAS_ACT || epilogue < TAMD_EPI_NONE || epilogue > TAMD_EPI_ACCUM) return 1;
   const int64_t tiles = ceil_div(M, kBM) * ceil_div(N, kBN), nst = K / kXK;
   if (nst < 32) return 1;
   if ((flags & (TAMD_GEMM_A_KM | TAMD_GEMM_B_KN)) == 0 && tiles <= kSmMaxBigTiles && nst < 64) return 1;

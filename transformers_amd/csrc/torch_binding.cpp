@@ -496,21 +496,8 @@ Tensor k_gemm(const Tensor& a, const Tensor& b, bool a_km, bool b_kn, const OptT
                 "tamd: gemm residual must be a 2-D row-major view with a 16-byte aligned base and a row stride that is a "
                 "multiple of 8 elements");
   }
-  if (sched == 0) {
-    // a residual epilogue on a tile grid that cannot fill the GPU (o_proj / down_proj of a short prompt: 80 tiles on 256
-    // CUs): the residual goes into C first and the product is accumulated onto it, which split-K can do -- the same
-    // roundings, round(round(acc) + R), for the price of copying a small C
-    if (epilogue == TAMD_EPI_RESIDUAL && !bias && residual.defined() && residual.sizes() == out.sizes()) {
-      ws_bytes = api().tamd_gemm_workspace_bytes(m, n, k_a, flags & 3, TAMD_EPI_ACCUM);
-      if (ws_bytes) {
-        out.copy_(residual);
-        residual = Tensor();
-        epilogue = TAMD_EPI_ACCUM;
-      }
-    } else {
-      ws_bytes = api().tamd_gemm_workspace_bytes(m, n, k_a, flags & 3, (int)epilogue);
-    }
-  }
+  if (sched == 0)  // split-K when the tile grid cannot fill the GPU (the reduction applies bias / residual / accumulate)
+    ws_bytes = api().tamd_gemm_workspace_bytes(m, n, k_a, flags & 3, (int)epilogue);
   const int64_t ldr = residual.defined() ? residual.stride(0) : 0;
   GemmTimerScope timer(2.0 * (double)m * (double)n * (double)k_a, 2.0 * ((double)m * k_a + (double)n * k_a + (double)m * n),
                        L.stream);

@@ -219,7 +219,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int, flags: int = 0) 
     """Host-side mirror of tamd_gemm_workspace_bytes (csrc/gemm.hip gemm_choose_splits): one ctypes round trip per
     GEMM is ~10 us, which small-model steps (hundreds of 30-us kernels) cannot hide.  tests/test_kernels.py keeps the
     two in step."""
-    if k % 64 or n % 4 or epilogue not in (EPI_NONE, EPI_ACCUM):
+    if k % 64 or n % 4 or epilogue not in (EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_ACCUM):
         return 0
     tiles, nst = -(-m // 256) * -(-n // 256), k // 64
     if nst < 32:
