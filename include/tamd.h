@@ -335,6 +335,15 @@ struct tamd_attn_params {
 };
 int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream);
 
+/* ABI 8.  The same attention for DECODE shapes -- a few query rows (one new token per sequence, or a short speculative /
+ * chunked block) over a long key range: the KV cache of `generate` (cache_utils.py:1730, :1822; modeling_llama.py:243-281).
+ * Same parameter block and result as tamd_attn_fwd (dropout_p must be 0, q_start NULL), different schedule: with one query row
+ * and grouped-query attention the query heads of a KV head share one pass over its keys, and the key range is split over
+ * enough workgroups to fill the GPU (split-KV; fp32 partial rows in `workspace`, merged by a second kernel).
+ * workspace: tamd_attn_decode_workspace_bytes(p) bytes, 16-byte aligned. */
+size_t tamd_attn_decode_workspace_bytes(const struct tamd_attn_params* p);
+int tamd_attn_decode(const struct tamd_attn_params* p, void* workspace, size_t workspace_bytes, tamd_stream_t stream);
+
 /* Backward (SURVEY §8a "Attention"): delta = rowsum(dO*O); dV = P^T dO; dS = P*(dP - delta);
  * dQ = scale dS K; dK = scale dS^T Q; GQA sums dK/dV over the query heads of a group. */
 struct tamd_attn_bwd_params {

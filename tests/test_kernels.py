@@ -1017,3 +1017,76 @@ def test_bias_act_backward_accumulates_the_bias_gradient(env, act):
         dx, db = ops.raw_bias_act_bwd(x, bias, dy, code, need_colsum=True)
         assert torch.equal(dx, ops.raw_bias_act_bwd(x, bias, dy, code))
         assert rel_err(db, dx.float().sum(0)) < 0.0034
+
+
+DECODE_CASES_SMALL = [
+    # b, sq, sk, hq, hkv, d, causal, mask
+    (2, 1, 300, 4, 2, 128, True, False),    # one new token, GQA: the heads of a KV head become the rows of a query tile
+    (1, 1, 200, 4, 4, 64, True, True),      # MHA, left-padded cache
+    (2, 5, 260, 4, 2, 64, True, False),     # a short block of new tokens: causal inside the block
+    (1, 1, 129, 2, 1, 128, False, True),    # cross-attention style (not causal), ragged key count, padding
+]
+DECODE_CASES_BIG = [
+    (1, 1, 4096, 32, 8, 128, True, False),   # Llama-3-8B, one sequence, 4k cache
+    (8, 1, 8192, 32, 8, 128, True, True),    # batch 8, 8k cache, padded
+    (2, 1, 1088, 32, 32, 128, True, False),  # Llama-2-7B-shaped (LLaVA): MHA
+    (4, 16, 2000, 12, 12, 64, True, False),  # 16 new rows, ragged
+    (3, 7, 515, 16, 4, 64, False, True),
+]
+
+
+def test_attention_decode_split_kv(env):
+    """tamd_attn_decode (few query rows over a KV cache: cache_utils.py:1730, 1822; modeling_llama.py:243-281): the split-KV
+    schedule -- query heads of a KV head as tile rows, key range split over workgroups, fp32 partials merged -- returns what
+    the training kernel returns (same roundings of P; the pieces are summed in a different order) and what fp32 eager
+    attention returns, and is what `torch.ops.tamd.attention` runs for such shapes."""
+    import ctypes
+
+    from transformers_amd import _cabi
+
+    dev = env.device
+    be = ops.backend()
+    lib = be.lib
+    for case in (DECODE_CASES_BIG if env.big else DECODE_CASES_SMALL):
+        b, sq, sk, hq, hkv, d, causal, use_mask = case
+        torch.manual_seed(81)
+        q = torch.randn(b, sq, hq, d).bfloat16().to(dev)
+        kc = torch.randn(b, sk + 40, hkv, d).bfloat16().to(dev)  # a pre-allocated cache: the first sk slots are in use
+        vc = torch.randn(b, sk + 40, hkv, d).bfloat16().to(dev)
+        k, v = kc[:, :sk], vc[:, :sk]
+        kv = None
+        if use_mask:
+            kv = torch.ones(b, sk, dtype=torch.bool, device=dev)
+            kv[0, :37] = False  # left padding
+        scale = d ** -0.5
+        ref = ref_attention(q, k, v, scale, causal, kv)
+        o = torch.empty(b, sq, hq, d, dtype=torch.bfloat16, device=dev)
+        lse = torch.empty(b, hq, sq, dtype=torch.float32, device=dev)
+        ap = _cabi.AttnParams()
+        ap.q, ap.k, ap.v, ap.o, ap.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
+        kvb = None if kv is None else kv.to(torch.uint8).contiguous()
+        ap.key_valid, ap.q_start = (None if kvb is None else kvb.data_ptr()), None
+        ap.batch, ap.seq_q, ap.heads_q, ap.head_dim, ap.seq_k, ap.heads_kv = b, sq, hq, d, sk, hkv
+        for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
+            setattr(ap, f"{name}_stride_b", t.stride(0))
+            setattr(ap, f"{name}_stride_s", t.stride(1))
+            setattr(ap, f"{name}_stride_h", t.stride(2))
+        ap.scale, ap.causal, ap.dtype, ap.dropout_p, ap.dropout_seed, ap.q_prescaled = scale, int(causal), _cabi.TAMD_BF16, 0.0, 0, 0
+        nbytes = lib.tamd_attn_decode_workspace_bytes(ctypes.byref(ap))
+        assert nbytes > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        st = be.stream(q)
+        stream = ctypes.c_void_p(st) if st else None
+        lib.check(lib.tamd_attn_decode(ctypes.byref(ap), ws.data_ptr(), nbytes, stream), "decode")
+        o_train = torch.empty_like(o)
+        lse_train = torch.empty_like(lse)
+        ap.o, ap.lse = o_train.data_ptr(), lse_train.data_ptr()
+        lib.check(lib.tamd_attn_fwd(ctypes.byref(ap), stream), "fwd")
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        assert rel_err(o, ref) < 0.0045, case
+        assert rel_err(o, o_train) < 0.0035, case       # same P roundings, another summation order (+ one output rounding)
+        assert max_err(lse, lse_train) < 2e-3, case
+        # the dispatcher op takes this path for cache-shaped calls
+        o2 = ops.attention(q, k, v, scale, causal, kv)
+        assert torch.equal(o2, o), case

@@ -79,6 +79,8 @@ SIGNATURES = {
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),
     "tamd_attn_dropout_field": (ctypes.c_uint32, [ctypes.c_uint64] * 6),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),
+    "tamd_attn_decode_workspace_bytes": (c_size_t, [POINTER(AttnParams)]),
+    "tamd_attn_decode": (c_int, [POINTER(AttnParams), P, c_size_t, P]),
     "tamd_attn_bwd": (c_int, [POINTER(AttnBwdParams), P]),
 }
 

@@ -67,6 +67,20 @@ int attn_fwd_launch(const AttnArgs& a, bool causal, hipStream_t s) {
   return launch_status();
 }
 
+// split-KV forward + merge (tamd_attn_decode).  No dropout, no packed sequences (checked by the caller).
+template <typename T, int D>
+int attn_decode_launch(const AttnArgs& a, bool causal, hipStream_t s) {
+  const size_t smem = (size_t)4 * kKB * D * 2;
+  dim3 grid((unsigned)(a.nqt * a.heads_q * a.batch * a.kv_splits)), block(kAttnThreads);
+  if (causal)
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D, true, true, false, true>), grid, block, smem, s, a);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D, false, true, false, true>), grid, block, smem, s, a);
+  const int rows = a.batch * a.seq_q * a.heads_q;
+  hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, a);
+  return launch_status();
+}
+
 int attn_check(const tamd_attn_params* p) {
   if (!p || !p->q || !p->k || !p->v || !p->o) return TAMD_E_NULL;
   if (p->head_dim != 64 && p->head_dim != 128) return TAMD_E_SHAPE;
@@ -122,6 +136,10 @@ AttnArgs make_args(const tamd_attn_params* p) {
   a.nqt = (int)ceil_div(p->seq_q, kQB);
   a.xcd_map = ((p->batch * p->heads_kv) % 8 == 0) ? 1 : 0;
   a.q_prescaled = p->q_prescaled != 0;
+  a.o_part = nullptr;
+  a.lse_part = nullptr;
+  a.kv_splits = 1;
+  a.tiles_per_split = 0;
 #ifdef TAMD_DIAG
   a.trace = g_attn_trace;
 #else
@@ -159,6 +177,72 @@ extern "C" int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t str
     TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 128>(a, p->causal != 0, s)));
   } else {
     TAMD_DISPATCH_HALF(p->dtype, return (attn_fwd_launch<T, 64>(a, p->causal != 0, s)));
+  }
+  return TAMD_E_DTYPE;
+}
+
+// ---- decode: few query rows (one new token per sequence, or a short speculative / chunked block) over a long key range
+// (cache_utils.py:1730, :1822: the KV cache the reference attends over in `generate`; models/llama/modeling_llama.py:243-281).
+// The training kernel gives such a call batch x heads workgroups that each walk the whole cache; here
+//   * one new token per sequence and grouped-query attention: the `group` query heads of a KV head become the ROWS of one
+//     query tile (a re-striding of q and o, no copy), so K / V are read once per KV head instead of once per query head;
+//   * the key range is split over enough workgroups to fill the GPU (split-KV), each writing a normalised fp32 partial row
+//     and its log-sum-exp into the workspace, merged by attn_combine_kernel.
+struct DecodePlan {
+  tamd_attn_params p;  // the (possibly re-strided) problem
+  int splits, tiles_per_split;
+};
+static DecodePlan decode_plan(const tamd_attn_params* p0) {
+  DecodePlan d;
+  d.p = *p0;
+  tamd_attn_params& p = d.p;
+  const int64_t group = p.heads_q / p.heads_kv;
+  if (p.seq_q == 1 && group > 1) {  // rows = the query heads of a KV head; one "head" per KV head; every key visible
+    p.seq_q = group;
+    p.q_stride_s = p0->q_stride_h;
+    p.o_stride_s = p0->o_stride_h;
+    p.q_stride_h = group * p0->q_stride_h;
+    p.o_stride_h = group * p0->o_stride_h;
+    p.heads_q = p.heads_kv;
+    p.causal = 0;
+  }
+  int64_t kend = p.seq_k;  // (causal: the last query row sees every key of the range; rows before it fewer)
+  const int64_t nkt = ceil_div(kend, kKB), nqt = ceil_div(p.seq_q, kQB);
+  const int64_t base = nqt * p.heads_q * p.batch;
+  int64_t splits = ceil_div(768, base);  // ~3 workgroups per CU
+  if (splits > nkt) splits = nkt;
+  if (splits > 256) splits = 256;
+  if (splits < 1) splits = 1;
+  d.tiles_per_split = (int)ceil_div(nkt, splits);
+  d.splits = (int)ceil_div(nkt, d.tiles_per_split);  // no empty split
+  return d;
+}
+extern "C" size_t tamd_attn_decode_workspace_bytes(const struct tamd_attn_params* p) {
+  if (!p || p->heads_kv <= 0 || p->heads_q % p->heads_kv != 0 || p->seq_q <= 0 || p->seq_k <= 0) return 0;
+  const DecodePlan d = decode_plan(p);
+  const size_t rows = (size_t)d.splits * (size_t)d.p.batch * (size_t)d.p.seq_q * (size_t)d.p.heads_q;
+  return rows * ((size_t)d.p.head_dim + 1) * sizeof(float);
+}
+extern "C" int tamd_attn_decode(const struct tamd_attn_params* p0, void* workspace, size_t workspace_bytes,
+                                tamd_stream_t stream) {
+  const int chk = attn_check(p0);
+  if (chk != TAMD_OK) return chk;
+  if (p0->dropout_p != 0.f || p0->q_start != nullptr) return TAMD_E_ARG;
+  if (!workspace) return TAMD_E_NULL;
+  if (workspace_bytes < tamd_attn_decode_workspace_bytes(p0) || !aligned16(workspace)) return TAMD_E_WORKSPACE;
+  const DecodePlan d = decode_plan(p0);
+  AttnArgs a = make_args(&d.p);
+  a.xcd_map = 0;
+  a.kv_splits = d.splits;
+  a.tiles_per_split = d.tiles_per_split;
+  const size_t rows = (size_t)d.splits * (size_t)d.p.batch * (size_t)d.p.seq_q * (size_t)d.p.heads_q;
+  a.o_part = reinterpret_cast<float*>(workspace);
+  a.lse_part = a.o_part + rows * (size_t)d.p.head_dim;
+  hipStream_t s = TAMD_STREAM(stream);
+  if (d.p.head_dim == 128) {
+    TAMD_DISPATCH_HALF(d.p.dtype, return (attn_decode_launch<T, 128>(a, d.p.causal != 0, s)));
+  } else {
+    TAMD_DISPATCH_HALF(d.p.dtype, return (attn_decode_launch<T, 64>(a, d.p.causal != 0, s)));
   }
   return TAMD_E_DTYPE;
 }

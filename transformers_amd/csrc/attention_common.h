@@ -39,6 +39,12 @@ struct AttnArgs {
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
   int q_prescaled;   // 1: q already carries scale*log2(e) (include/tamd.h): no operand is scaled and re-rounded here
   unsigned long long* trace;  // diagnostic build: per-phase shader-clock sums of workgroup 0 (tamd_attn_set_trace), else null
+  // split-KV forward (tamd_attn_decode: few query rows over a long key range): workgroup = (query tile, head, batch, split);
+  // split s visits key tiles [s * tiles_per_split, ...) and writes its normalised fp32 output rows and their log-sum-exp to
+  // o_part [splits][B][Sq][Hq][D] / lse_part [splits][B][Hq][Sq]; attn_combine_kernel merges them
+  float* o_part;
+  float* lse_part;
+  int kv_splits, tiles_per_split;
 };
 
 // Diagnostic build only: phase i of the forward tile loop ends here (s_memtime stamps of workgroup 0, summed per wave)

@@ -43,7 +43,8 @@ using OptTensor = std::optional<at::Tensor>;
   X(tamd_bert_embeddings_fwd) X(tamd_swiglu_fwd) X(tamd_swiglu_bwd) X(tamd_bias_act_fwd) X(tamd_bias_act_bwd)         \
   X(tamd_add) X(tamd_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
   X(tamd_cross_entropy_fwd) X(tamd_cross_entropy_bwd) X(tamd_gemm) X(tamd_gemm_workspace_bytes) X(tamd_gemm_ws)       \
-  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_attn_fwd) X(tamd_attn_bwd)
+  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
+  X(tamd_attn_decode_workspace_bytes) X(tamd_attn_decode)
 
 struct Api {
   void* handle = nullptr;
@@ -647,6 +648,11 @@ void fill_attn_params(tamd_attn_params* ap, const Tensor& q, const Tensor& k, co
   ap->q_prescaled = q_prescaled ? 1 : 0;
 }
 
+// tamd_attn_decode for q of at most kDecodeMaxRows rows over at least kDecodeMinKeys keys (TAMD_DECODE_KERNEL=0: always the
+// training kernel -- the A/B switch of tools/decode_bench.py)
+const bool kDecodeKernel = [] { const char* e = getenv("TAMD_DECODE_KERNEL"); return e == nullptr || std::string(e) != "0"; }();
+constexpr int64_t kDecodeMaxRows = 16, kDecodeMinKeys = 128;
+
 // [batch, seq_k] key-validity plane (1 = attend): the kernels index it as key_valid[b * seq_k + key]
 Tensor checked_key_valid(const OptTensor& key_valid, const Tensor& q, const Tensor& k) {
   if (!key_valid) return Tensor();
@@ -675,6 +681,13 @@ std::tuple<Tensor, Tensor> k_attn_fwd(const Tensor& q, const Tensor& k, const Te
   Tensor q_start = checked_q_start(q_start_, q, causal);
   tamd_attn_params ap;
   fill_attn_params(&ap, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start, q_prescaled);
+  // decode shapes (a KV cache: a few query rows over a long key range) take the split-KV schedule
+  if (kDecodeKernel && q.size(1) <= kDecodeMaxRows && k.size(1) >= kDecodeMinKeys && dropout_p == 0.0 && !q_start.defined()) {
+    const size_t nbytes = api().tamd_attn_decode_workspace_bytes(&ap);
+    Tensor ws = at::empty({(int64_t)nbytes}, q.options().dtype(at::kByte));
+    check(api().tamd_attn_decode(&ap, mptr(ws), nbytes, L.stream), "tamd_attn_decode");
+    return {o, lse};
+  }
   check(api().tamd_attn_fwd(&ap, L.stream), "tamd_attn_fwd");
   return {o, lse};
 }
