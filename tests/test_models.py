@@ -739,9 +739,15 @@ def test_clip_vision_tower_hidden_states(env):
         a = ref(pixel_values=px.bfloat16(), output_hidden_states=True)
         a32 = ref32(pixel_values=px, output_hidden_states=True)
         transformers_amd.accelerate(fast)
+        transformers_amd.fallback_calls(reset=True)
         c = fast(pixel_values=px.bfloat16().to(env.device), output_hidden_states=True)
     assert len(c.hidden_states) == cfg.num_hidden_layers + 1
     assert c.hidden_states[-2].shape[1] == (cfg.image_size // 14) ** 2 + 1  # 577 tokens at 336 px: ragged tiles
+    # the patch embedding ran as a GEMM over non-overlapping patches (modeling_clip.py:148-154, 209-218): the embeddings are
+    # the reference's up to the summation order of 588 products (fp32 accumulation on both sides, one rounding)
+    assert any(type(m).__name__ == "TamdCLIPVisionEmbeddings" for m in fast.modules())
+    assert not any(k.startswith("TamdCLIPVisionEmbeddings") for k in transformers_amd.fallback_calls())
+    assert rel_err(c.hidden_states[0], a32.hidden_states[0]) <= 1.1 * rel_err(a.hidden_states[0], a32.hidden_states[0]) + 1e-3
     e_fast = rel_err(c.hidden_states[-2], a32.hidden_states[-2])
     e_ref = rel_err(a.hidden_states[-2], a32.hidden_states[-2])
     assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)

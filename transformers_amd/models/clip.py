@@ -92,7 +92,58 @@ class TamdCLIPEncoderLayer(ref.CLIPEncoderLayer):
         return ops.linear(hmid, mlp.fc2.weight, mlp.fc2.bias, residual=x)
 
 
+class TamdCLIPVisionEmbeddings(ref.CLIPVisionEmbeddings):
+    """CLIPVisionEmbeddings.forward, modeling_clip.py:209-218: the patch embedding is a convolution whose stride equals its
+    kernel (14 x 14 patches of a 336 x 336 image, no bias, :148-154) -- i.e. a GEMM over non-overlapping patches:
+        patches [B * 576, 3*14*14 = 588]  .  weight [1024, 588]^T
+    with K zero-padded to a multiple of 64 (640) on both operands so that the MFMA kernels' 64-deep stages apply.  One
+    permuting copy of the pixels replaces the convolution (MIOpen's `naive_conv_ab_nonpacked_fwd_nchw`: 0.34 ms of a 21 ms
+    LLaVA-1.5-7B forward, profiles/r03r_llava_kernel_stats.csv); the class token, the concatenation and the position
+    embedding stay the reference's own lines.  Forward only (no gradient reaches the convolution's weight through the
+    padded copy): when a gradient is needed the reference's convolution runs."""
+
+    def _padded_weight(self):
+        w = self.patch_embedding.weight
+        key = (w.data_ptr(), w._version, w.dtype, w.device)
+        cached = self.__dict__.get("_tamd_patch_w")
+        if cached is None or cached[0] != key:
+            n, k = w.shape[0], w[0].numel()
+            kp = -(-k // 64) * 64
+            wp = w.new_zeros(n, kp)
+            wp[:, :k].copy_(w.detach().reshape(n, k))
+            cached = (key, wp)
+            self.__dict__["_tamd_patch_w"] = cached
+        return cached[1]
+
+    def forward(self, pixel_values, interpolate_pos_encoding=False):
+        w = self.patch_embedding.weight
+        p = self.patch_size
+        b, c, height, width = pixel_values.shape
+        fast = (_gpu(pixel_values) and w.dtype in (torch.bfloat16, torch.float16) and self.patch_embedding.bias is None
+                and not (torch.is_grad_enabled() and (w.requires_grad or pixel_values.requires_grad))
+                and height % p == 0 and width % p == 0 and w.shape[0] % 8 == 0
+                and tuple(self.patch_embedding.stride) == (p, p) and tuple(self.patch_embedding.kernel_size) == (p, p)
+                and tuple(self.patch_embedding.padding) == (0, 0) and self.patch_embedding.groups == 1
+                and not (not interpolate_pos_encoding and (height != self.image_size or width != self.image_size)))
+        if not fast:
+            note_fallback(self, pixel_values)
+            return super().forward(pixel_values, interpolate_pos_encoding=interpolate_pos_encoding)
+        gh, gw = height // p, width // p
+        wp = self._padded_weight()
+        k = c * p * p
+        patches = pixel_values.new_zeros((b * gh * gw, wp.shape[1]), dtype=w.dtype)
+        # [B, C, gh, p, gw, p] -> [B, gh, gw, C, p, p]: one copy (with the dtype cast of `pixel_values.to(target_dtype)`)
+        patches[:, :k].view(b, gh, gw, c, p, p).copy_(pixel_values.view(b, c, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5))
+        patch_embeds = ops.raw_gemm(patches, wp).view(b, gh * gw, w.shape[0])  # = conv(...).flatten(2).transpose(1, 2)
+        class_embeds = self.class_embedding.expand(b, 1, -1)
+        embeddings = torch.cat([class_embeds, patch_embeds], dim=1)
+        if interpolate_pos_encoding:
+            return embeddings + self.interpolate_pos_encoding(embeddings, height, width)
+        return embeddings + self.position_embedding(self.position_ids)
+
+
 REPLACEMENTS = {
+    ref.CLIPVisionEmbeddings: TamdCLIPVisionEmbeddings,
     ref.CLIPAttention: TamdCLIPAttention,
     ref.CLIPMLP: TamdCLIPMLP,
     ref.CLIPEncoderLayer: TamdCLIPEncoderLayer,
