@@ -104,14 +104,15 @@ int tamd_layernorm_bwd(const void* dy, const void* h, const void* w, const float
  * it; kept elements are scaled by 1/(1-p) and rounded to the storage type before the residual is added, as the
  * reference's bf16 ops do.  Backward: dx = d loss / d h (the gradient of the residual input), dx_drop = the gradient of
  * x (dx masked and scaled); dres as in tamd_layernorm_bwd; dcolsum (ABI 8, nullable, needs dres == NULL): the column
- * sums of dx_drop = the bias gradient of the dense layer that produced x. */
+ * sums of dx_drop = the bias gradient of the dense layer that produced x.  seed_dev (ABI 8, nullable): the seed as one
+ * 64-bit word in device memory, replacing `seed` (graph-replay-safe dropout: see tamd_attn_params.dropout_seed_dev). */
 int tamd_layernorm_dropout_fwd(const void* x, const void* residual, const void* w, const void* b, void* y, void* h_out,
                                float* mean, float* rstd, int64_t rows, int64_t cols, float eps, float dropout_p,
-                               uint64_t seed, int dtype, tamd_stream_t stream);
+                               uint64_t seed, const uint64_t* seed_dev, int dtype, tamd_stream_t stream);
 int tamd_layernorm_dropout_bwd(const void* dy, const void* h, const void* w, const float* mean, const float* rstd,
                                const void* dres, void* dx, void* dx_drop, void* dw, void* db, void* dcolsum,
                                void* workspace, size_t workspace_bytes, int64_t rows, int64_t cols, float dropout_p,
-                               uint64_t seed, int dtype, tamd_stream_t stream);
+                               uint64_t seed, const uint64_t* seed_dev, int dtype, tamd_stream_t stream);
 
 /* ------------------------------------------------------------------ rotary */
 
@@ -332,6 +333,11 @@ struct tamd_attn_params {
    * rounding.  `scale` stays the softmax scale of the UNSCALED q; the backward's dq / dk are gradients with respect to
    * the unscaled q and to k. */
   int32_t q_prescaled;
+  /* ABI 8.  Non-NULL: the dropout seed is read from DEVICE memory (one 64-bit word) instead of `dropout_seed`, by the forward
+   * and both backward kernels -- so a training step captured in a HIP graph draws a fresh mask on every replay when the word is
+   * written by a captured RNG kernel (torch: `torch.empty(1, dtype=int64, device=...).random_()`, whose philox offset
+   * advances per replay).  The mask of seed value s is the same whichever way s arrives. */
+  const uint64_t* dropout_seed_dev;
 };
 int tamd_attn_fwd(const struct tamd_attn_params* p, tamd_stream_t stream);
 

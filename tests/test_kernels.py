@@ -1090,3 +1090,39 @@ def test_attention_decode_split_kv(env):
         # the dispatcher op takes this path for cache-shaped calls
         o2 = ops.attention(q, k, v, scale, causal, kv)
         assert torch.equal(o2, o), case
+
+
+def test_dropout_seed_from_device_memory_is_the_same_mask(env):
+    """ABI 8: a dropout seed read from device memory (tamd_attn_params.dropout_seed_dev, `seed_dev` of the LayerNorm-dropout
+    entry points: what a captured training step uses, ops.dropout_seed_tensor) gives the bits of the same seed passed by
+    value -- forward and backward, attention and hidden-state dropout."""
+    torch.manual_seed(91)
+    dev = env.device
+    seed = 0x3A5C_7E91_2B4D_6F80 & ((1 << 62) - 1)
+    sd = torch.tensor([seed], dtype=torch.int64, device=dev)
+    b, s, hq, hkv, d = (2, 512, 12, 12, 64) if env.big else (1, 100, 2, 1, 64)
+    q = torch.randn(b, s, hq, d).bfloat16().to(dev)
+    k = torch.randn(b, s, hkv, d).bfloat16().to(dev)
+    v = torch.randn(b, s, hkv, d).bfloat16().to(dev)
+    do = torch.randn(b, s, hq, d).bfloat16().to(dev)
+    o1, l1 = ops.raw_attn_fwd(q, k, v, d ** -0.5, False, dropout_p=0.1, seed=seed)
+    o2, l2 = ops.raw_attn_fwd(q, k, v, d ** -0.5, False, dropout_p=0.1, seed=12345, seed_dev=sd)  # (the value is ignored)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    g1 = ops.raw_attn_bwd(q, k, v, o1, l1, do, d ** -0.5, False, dropout_p=0.1, seed=seed)
+    g2 = ops.raw_attn_bwd(q, k, v, o1, l1, do, d ** -0.5, False, dropout_p=0.1, seed=0, seed_dev=sd)
+    assert all(torch.equal(a, c) for a, c in zip(g1, g2))
+    o3, _ = ops.raw_attn_fwd(q, k, v, d ** -0.5, False, dropout_p=0.1, seed=0, seed_dev=sd + 1)
+    assert not torch.equal(o3, o1)
+    rows, cols = (1024, 768) if env.big else (24, 128)
+    x = torch.randn(rows, cols).bfloat16().to(dev)
+    r = torch.randn(rows, cols).bfloat16().to(dev)
+    w = (torch.rand(cols) + 0.5).bfloat16().to(dev)
+    bb = torch.randn(cols).bfloat16().to(dev)
+    f1 = ops.raw_layernorm_dropout_fwd(x, w, bb, 1e-12, r, 0.1, seed)
+    f2 = ops.raw_layernorm_dropout_fwd(x, w, bb, 1e-12, r, 0.1, 777, seed_dev=sd)
+    assert all(torch.equal(a, c) for a, c in zip(f1, f2))
+    dy = torch.randn(rows, cols).bfloat16().to(dev)
+    y, h, mean, rstd = f1
+    b1 = ops.raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, 0.1, seed)
+    b2 = ops.raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, 0.1, 0, seed_dev=sd)
+    assert all(torch.equal(a, c) for a, c in zip(b1, b2))

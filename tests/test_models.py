@@ -965,3 +965,66 @@ def test_bert_layer_op_matches_reference_layer(env, p_hidden):
             continue
         assert p.grad is not None, n
         assert rel_err(p.grad, gr[n].grad) < 1.5e-2, n
+
+
+@pytest.mark.gpu
+def test_captured_training_step_draws_fresh_dropout_masks():
+    """VERDICT r3 "graph-safe dropout" (modeling_bert.py:131, 289-293; modeling_llama.py:209): a BERT training step with the
+    shipped dropout 0.1 / 0.1 captured in ONE HIP graph.  While the stream is capturing the dropout seeds are device words
+    written by torch's own (graph-safe) RNG kernel, so every replay draws new masks -- a host-drawn seed would be baked into
+    the graph and replay one mask for ever -- and reseeding the generator repeats a replay bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    from transformers import BertConfig, BertForMaskedLM
+    from transformers_amd import ops
+
+    old = ops._set_backend(None)
+    try:
+        dev = torch.device("cuda:0")
+        torch.manual_seed(21)
+        cfg = BertConfig(vocab_size=1000, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                         max_position_embeddings=128, attn_implementation="eager")
+        model = transformers_amd.accelerate(BertForMaskedLM(cfg).bfloat16().to(dev)).train()
+        ids = torch.randint(1, 1000, (4, 128), device=dev)
+        params = [p for p in model.parameters()]
+
+        def step():
+            out = model(input_ids=ids, labels=ids)
+            out.loss.backward()
+            return out.loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up on a side stream (allocator, autograd)
+            for _ in range(2):
+                step()
+                model.zero_grad(set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        grads = [p.grad for p in params if p.grad is not None]
+
+        def replay(seed):
+            torch.manual_seed(seed)
+            for g in grads:
+                g.zero_()  # (the captured backward accumulates into the static .grad tensors)
+            graph.replay()
+            torch.cuda.synchronize()
+            return static_loss.item(), [g.clone() for g in grads]
+
+        l1, g1 = replay(5)
+        l2, g2 = replay(5)
+        l3, g3 = replay(6)
+        assert l1 == l2 and all(torch.equal(a, b) for a, b in zip(g1, g2))      # same generator state: the same masks
+        assert l1 != l3 and any(not torch.equal(a, b) for a, b in zip(g1, g3))  # another state: other masks
+        torch.manual_seed(5)
+        for g in grads:
+            g.zero_()
+        graph.replay()
+        graph.replay()  # consecutive replays advance the generator: the second differs from the first
+        torch.cuda.synchronize()
+        assert static_loss.item() != l1
+        assert all(torch.isfinite(g).all() for g in grads)
+    finally:
+        ops._set_backend(old)

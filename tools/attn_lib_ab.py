@@ -21,7 +21,7 @@ from transformers_amd._cabi import AttnBwdParams, AttnParams, TamdLib, TAMD_BF16
 # parameter blocks as an ABI-6 build lays them out (tamd_attn_params grew by q_prescaled in ABI 7, which moves every field
 # of tamd_attn_bwd_params behind the embedded block)
 class AttnParamsV6(ctypes.Structure):
-    _fields_ = [f for f in AttnParams._fields_ if f[0] != "q_prescaled"]
+    _fields_ = [f for f in AttnParams._fields_ if f[0] not in ("q_prescaled", "dropout_seed_dev")]
 
 
 class AttnBwdParamsV6(ctypes.Structure):

@@ -30,6 +30,7 @@ class AttnParams(Structure):
         ("o_stride_b", I64), ("o_stride_s", I64), ("o_stride_h", I64),
         ("scale", c_float), ("causal", c_int), ("dtype", c_int),
         ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint64), ("q_start", P), ("q_prescaled", ctypes.c_int32),
+        ("dropout_seed_dev", P),
     ]
 
 
@@ -47,9 +48,9 @@ SIGNATURES = {
     "tamd_rmsnorm_bwd": (c_int, [P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_int, P]),
     "tamd_layernorm_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_int, P]),
     "tamd_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_int, P]),
-    "tamd_layernorm_dropout_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_float, ctypes.c_uint64, c_int, P]),
+    "tamd_layernorm_dropout_fwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, c_float, ctypes.c_uint64, P, c_int, P]),
     "tamd_layernorm_dropout_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, I64, I64, c_float,
-                                           ctypes.c_uint64, c_int, P]),
+                                           ctypes.c_uint64, P, c_int, P]),
     "tamd_rope_inplace": (c_int, [P, P, P, I64, I64, I64, I64, I64, I64, c_int, I64, c_float, c_int, P]),
     "tamd_embedding_fwd": (c_int, [P, P, P, I64, I64, I64, P, c_int, P]),
     "tamd_embedding_bwd_workspace_bytes": (c_size_t, [I64, I64]),

@@ -133,6 +133,7 @@ AttnArgs make_args(const tamd_attn_params* p) {
   const unsigned long long mixed = attn_seed_mix(p->dropout_seed);  // (dropout.h: the kernels' block mix takes a mixed seed)
   a.seed_lo = (unsigned)mixed;
   a.seed_hi = (unsigned)(mixed >> 32);
+  a.seed_dev = reinterpret_cast<const unsigned long long*>(p->dropout_seed_dev);
   a.nqt = (int)ceil_div(p->seq_q, kQB);
   a.xcd_map = ((p->batch * p->heads_kv) % 8 == 0) ? 1 : 0;
   a.q_prescaled = p->q_prescaled != 0;

@@ -139,8 +139,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   bool key_ok = krow < a.seq_k;
   if (HAS_MASK && a.key_valid != nullptr)
     key_ok = key_ok && a.key_valid[(int64_t)b * a.seq_k + (krow < a.seq_k ? krow : 0)] != 0;
-  const AttnDrop drop = {a.drop_thr << 16, a.seed_lo, a.seed_hi, a.drop_scale, ((unsigned long long)a.seq_q + 1) >> 1,
-                         ((unsigned long long)a.seq_k + 1) >> 1};
+  const AttnDrop drop = attn_drop_ctx(a);
   // lane part of a block index: this lane's key pair + the 2 * hi query pairs its rows sit above the chunk's first one
   // (rows / keys past the end index blocks of other rows: their probabilities are zero anyway)
   const unsigned long long drop_lane = (unsigned long long)(krow >> 1) + (unsigned long long)(2 * hi) * drop.csk;

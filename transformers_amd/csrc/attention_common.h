@@ -35,6 +35,8 @@ struct AttnArgs {
   unsigned drop_thr;  // keep iff the element's 16-bit hash field >= drop_thr (0 = no dropout); dropout.h AttnDrop
   float drop_scale;   // 65536 / (65536 - drop_thr): 1 / (1 - p) of the quantised p (attention.hip make_args)
   unsigned seed_lo, seed_hi;  // the halves of attn_seed_mix(dropout seed) (dropout.h)
+  const unsigned long long* seed_dev;  // non-null: the (unmixed) seed lives in device memory and replaces seed_lo / seed_hi
+                                       // (tamd_attn_params.dropout_seed_dev: graph-replay-safe dropout)
   int nqt;           // query tiles per (b, h)
   int xcd_map;       // 1: (b,kv-head) groups pinned to XCDs
   int q_prescaled;   // 1: q already carries scale*log2(e) (include/tamd.h): no operand is scaled and re-rounded here
@@ -60,6 +62,19 @@ struct AttnArgs {
 #else
 #define TAMD_ATTN_PHASE(i_)
 #endif
+
+// the dropout context of a kernel: thresholds, the mixed seed (from the host, or mixed here from the device-resident word:
+// a wave-uniform scalar load and a dozen scalar instructions per workgroup), block-index geometry
+__device__ __forceinline__ AttnDrop attn_drop_ctx(const AttnArgs& a) {
+  unsigned s0 = a.seed_lo, s1 = a.seed_hi;
+  if (a.seed_dev != nullptr) {
+    const unsigned long long mixed = attn_seed_mix(*a.seed_dev);
+    s0 = (unsigned)mixed;
+    s1 = (unsigned)(mixed >> 32);
+  }
+  return AttnDrop{a.drop_thr << 16, s0, s1, a.drop_scale, ((unsigned long long)a.seq_q + 1) >> 1,
+                  ((unsigned long long)a.seq_k + 1) >> 1};
+}
 
 // One swizzle serves both read patterns of a [rows][D] tile (rows = keys or queries):
 //   ds_read_b128 of 16 distinct rows at one logical slot  -> needs a bijection of the row bits onto slots,

@@ -23,9 +23,22 @@ __host__ __device__ __forceinline__ unsigned dropout_hash(unsigned seed_lo, unsi
 struct DropCtx {
   unsigned thr, seed_lo, seed_hi;
   float scale;
+  // non-null: the seed lives in DEVICE memory (one 64-bit word) and replaces seed_lo / seed_hi -- a train step captured in a
+  // HIP graph draws a fresh mask on every replay (the word is written by a captured RNG kernel: ops.dropout_seed_tensor)
+  const unsigned long long* seed_dev = nullptr;
   __device__ __forceinline__ float factor(unsigned long long base, int k) const {
     const unsigned long long idx = base + (unsigned long long)k;
     return dropout_hash(seed_lo, seed_hi, (unsigned)idx, (unsigned)(idx >> 32)) >= thr ? scale : 0.f;
+  }
+  // the context the kernel works with: the device seed, if any, read once (wave-uniform address: a scalar load)
+  __device__ __forceinline__ DropCtx resolved() const {
+    DropCtx d = *this;
+    if (seed_dev != nullptr) {
+      const unsigned long long s = *seed_dev;
+      d.seed_lo = (unsigned)s;
+      d.seed_hi = (unsigned)(s >> 32);
+    }
+    return d;
   }
 };
 

@@ -234,7 +234,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_bwd(const Tensor& dy, con
 // h = dropout(x, p) + residual; y = LayerNorm(h)  ->  (y, h, mean, rstd)
 std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_fwd(const Tensor& x, const Tensor& w_, const OptTensor& b_,
                                                                    double eps, const Tensor& residual, double dropout_p,
-                                                                   int64_t seed) {
+                                                                   int64_t seed, const uint64_t* seed_dev = nullptr) {
   const int64_t cols = x.size(-1);
   Tensor x2 = contig(x).view({-1, cols}), r2 = contig(residual).view({-1, cols});
   Launch L({&x2, &w_, p(b_), &r2});
@@ -244,7 +244,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_fwd(const Tensor&
   Tensor mean = f32_like(x2, {x2.size(0)}), rstd = f32_like(x2, {x2.size(0)});
   check(api().tamd_layernorm_dropout_fwd(ptr(x2), ptr(r2), ptr(w), ptr(b), mptr(y), mptr(h), (float*)mptr(mean),
                                          (float*)mptr(rstd), x2.size(0), cols, (float)eps, (float)dropout_p,
-                                         (uint64_t)seed, code_of(x2), L.stream),
+                                         (uint64_t)seed, seed_dev, code_of(x2), L.stream),
         "tamd_layernorm_dropout_fwd");
   return {y.view(x.sizes()), h.view(x.sizes()), mean, rstd};
 }
@@ -255,7 +255,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_bwd(const
                                                                            const Tensor& mean, const Tensor& rstd,
                                                                            double dropout_p, int64_t seed,
                                                                            const OptTensor& dres, bool need_db,
-                                                                           bool need_colsum = false) {
+                                                                           bool need_colsum = false,
+                                                                           const uint64_t* seed_dev = nullptr) {
   const int64_t cols = h.size(-1);
   Tensor dy2 = contig(dy).view({-1, cols}), h2 = contig(h).view({-1, cols});
   Tensor dr2 = dres ? contig(*dres).view({-1, cols}) : Tensor();
@@ -269,7 +270,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> k_layernorm_dropout_bwd(const
   Tensor ws = at::empty({(int64_t)nbytes}, h.options().dtype(at::kByte));
   check(api().tamd_layernorm_dropout_bwd(ptr(dy2), ptr(h2), ptr(w), (const float*)ptr(mean), (const float*)ptr(rstd),
                                          ptr(dr2), mptr(dx), mptr(dxd), mptr(dw), mptr(db), mptr(dc), mptr(ws), nbytes, rows,
-                                         cols, (float)dropout_p, (uint64_t)seed, code_of(h2), L.stream),
+                                         cols, (float)dropout_p, (uint64_t)seed, seed_dev, code_of(h2), L.stream),
         "tamd_layernorm_dropout_bwd");
   return {dx.view(h.sizes()), dxd.view(h.sizes()), dw, db, dc};
 }
@@ -620,7 +621,7 @@ Tensor k_gemm_rope(const Tensor& x2, const Tensor& wqkv, const Tensor& cos_, con
 // ---- attention
 void fill_attn_params(tamd_attn_params* ap, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
                       const Tensor& lse, const Tensor& key_valid, double scale, bool causal, double dropout_p, int64_t seed,
-                      const Tensor& q_start, bool q_prescaled = false) {
+                      const Tensor& q_start, bool q_prescaled = false, const uint64_t* seed_dev = nullptr) {
   ap->q = ptr(q);
   ap->k = ptr(k);
   ap->v = ptr(v);
@@ -646,6 +647,15 @@ void fill_attn_params(tamd_attn_params* ap, const Tensor& q, const Tensor& k, co
   ap->dropout_seed = (uint64_t)seed;
   ap->q_start = (const int32_t*)ptr(q_start);
   ap->q_prescaled = q_prescaled ? 1 : 0;
+  ap->dropout_seed_dev = seed_dev;
+}
+
+// word `site` of a device-resident seed tensor (int64, ops.dropout_seed_tensor) or NULL: graph-replay-safe dropout
+const uint64_t* seed_word(const OptTensor& seeds, int64_t site) {
+  if (!seeds || !seeds->defined() || seeds->numel() == 0) return nullptr;
+  TORCH_CHECK(seeds->scalar_type() == at::kLong && seeds->is_contiguous() && seeds->numel() > site,
+              "tamd: a device seed tensor must be contiguous int64 with one word per dropout site");
+  return reinterpret_cast<const uint64_t*>(seeds->const_data_ptr()) + site;
 }
 
 // tamd_attn_decode for q of at most kDecodeMaxRows rows over at least kDecodeMinKeys keys (TAMD_DECODE_KERNEL=0: always the
@@ -673,14 +683,15 @@ Tensor checked_q_start(const OptTensor& q_start, const Tensor& q, bool causal) {
 // q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32 or undefined
 std::tuple<Tensor, Tensor> k_attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale, bool causal,
                                       const OptTensor& key_valid_, bool need_lse, double dropout_p, int64_t seed,
-                                      const OptTensor& q_start_, bool q_prescaled = false) {
+                                      const OptTensor& q_start_, bool q_prescaled = false,
+                                      const uint64_t* seed_dev = nullptr) {
   Launch L({&q, &k, &v, p(key_valid_)});
   Tensor o = at::empty({q.size(0), q.size(1), q.size(2), q.size(3)}, q.options());
   Tensor lse = need_lse ? f32_like(q, {q.size(0), q.size(2), q.size(1)}) : Tensor();
   Tensor key_valid = checked_key_valid(key_valid_, q, k);
   Tensor q_start = checked_q_start(q_start_, q, causal);
   tamd_attn_params ap;
-  fill_attn_params(&ap, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start, q_prescaled);
+  fill_attn_params(&ap, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start, q_prescaled, seed_dev);
   // decode shapes (a KV cache: a few query rows over a long key range) take the split-KV schedule
   if (kDecodeKernel && q.size(1) <= kDecodeMaxRows && k.size(1) >= kDecodeMinKeys && dropout_p == 0.0 && !q_start.defined()) {
     const size_t nbytes = api().tamd_attn_decode_workspace_bytes(&ap);
@@ -698,7 +709,8 @@ std::tuple<Tensor, Tensor, Tensor> k_attn_bwd(const Tensor& q, const Tensor& k, 
                                               const Tensor& lse, const Tensor& dout_, double scale, bool causal,
                                               const OptTensor& key_valid_, Tensor dq, Tensor dk, Tensor dv, double dropout_p,
                                               int64_t seed, const OptTensor& q_start_, const Tensor& rope_cos_,
-                                              const Tensor& rope_sin_, bool q_prescaled = false) {
+                                              const Tensor& rope_sin_, bool q_prescaled = false,
+                                              const uint64_t* seed_dev = nullptr) {
   Launch L({&q, &k, &v, &o, &lse, &dout_, p(key_valid_)});
   Tensor dout = dout_;
   if (dout.strides() != o.strides()) dout = o.is_contiguous() ? dout.contiguous() : dout.clone(at::MemoryFormat::Preserve);
@@ -713,7 +725,7 @@ std::tuple<Tensor, Tensor, Tensor> k_attn_bwd(const Tensor& q, const Tensor& k, 
   dshape.insert(dshape.begin(), 2);
   Tensor delta = at::empty(dshape, lse.options());  // -delta | -lse*log2(e) (written by the dQ kernel)
   tamd_attn_bwd_params bp;
-  fill_attn_params(&bp.fwd, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start, q_prescaled);
+  fill_attn_params(&bp.fwd, q, k, v, o, lse, key_valid, scale, causal, dropout_p, seed, q_start, q_prescaled, seed_dev);
   bp.dout = ptr(dout);
   bp.dq = mptr(dq);
   bp.dk = mptr(dk);
@@ -759,9 +771,15 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> op_layernorm_dropout_bwd(cons
                                                                             const Tensor& mean, const Tensor& rstd,
                                                                             double dropout_p, int64_t seed,
                                                                             const OptTensor& dres, bool need_db,
-                                                                            bool need_colsum) {
-  auto [dx, dxd, dw, db, dc] = k_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres, need_db, need_colsum);
+                                                                            bool need_colsum, const OptTensor& seed_dev) {
+  auto [dx, dxd, dw, db, dc] = k_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres, need_db, need_colsum,
+                                                       seed_word(seed_dev, 0));
   return {dx, dxd, dw, db.defined() ? db : nothing(w), dc.defined() ? dc : nothing(w)};
+}
+std::tuple<Tensor, Tensor, Tensor, Tensor> op_layernorm_dropout_fwd(const Tensor& x, const Tensor& w, const OptTensor& b,
+                                                                    double eps, const Tensor& residual, double dropout_p,
+                                                                    int64_t seed, const OptTensor& seed_dev) {
+  return k_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed, seed_word(seed_dev, 0));
 }
 std::tuple<Tensor, Tensor> op_bias_act_bwd(const Tensor& x, const OptTensor& bias, const Tensor& dy, int64_t act,
                                            bool need_colsum) {
@@ -815,25 +833,25 @@ Tensor op_gemm_rope(const Tensor& x2, const Tensor& wqkv, const Tensor& cos, con
 }
 std::tuple<Tensor, Tensor> op_attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale, bool causal,
                                        const OptTensor& key_valid, bool need_lse, double dropout_p, int64_t seed,
-                                       const OptTensor& q_start) {
-  auto [o, lse] = k_attn_fwd(q, k, v, scale, causal, key_valid, need_lse, dropout_p, seed, q_start);
+                                       const OptTensor& q_start, const OptTensor& seed_dev) {
+  auto [o, lse] = k_attn_fwd(q, k, v, scale, causal, key_valid, need_lse, dropout_p, seed, q_start, false, seed_word(seed_dev, 0));
   return {o, lse.defined() ? lse : nothing(q)};
 }
 std::tuple<Tensor, Tensor, Tensor> op_attn_bwd(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
                                                const Tensor& lse, const Tensor& dout, double scale, bool causal,
                                                const OptTensor& key_valid, double dropout_p, int64_t seed,
                                                const OptTensor& q_start, const OptTensor& rope_cos,
-                                               const OptTensor& rope_sin) {
+                                               const OptTensor& rope_sin, const OptTensor& seed_dev) {
   return k_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid, Tensor(), Tensor(), Tensor(), dropout_p, seed, q_start,
-                    rope_cos ? *rope_cos : Tensor(), rope_sin ? *rope_sin : Tensor());
+                    rope_cos ? *rope_cos : Tensor(), rope_sin ? *rope_sin : Tensor(), false, seed_word(seed_dev, 0));
 }
 // the same, gradients written into caller-provided views (one fused d_qkv buffer)
 void op_attn_bwd_out(Tensor& dq, Tensor& dk, Tensor& dv, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
                      const Tensor& lse, const Tensor& dout, double scale, bool causal, const OptTensor& key_valid,
                      double dropout_p, int64_t seed, const OptTensor& q_start, const OptTensor& rope_cos,
-                     const OptTensor& rope_sin) {
+                     const OptTensor& rope_sin, const OptTensor& seed_dev) {
   k_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid, dq, dk, dv, dropout_p, seed, q_start,
-             rope_cos ? *rope_cos : Tensor(), rope_sin ? *rope_sin : Tensor());
+             rope_cos ? *rope_cos : Tensor(), rope_sin ? *rope_sin : Tensor(), false, seed_word(seed_dev, 0));
 }
 
 // ---- forward implementations of the differentiable ops (backward formulas: Python, torch.library.register_autograd)
@@ -856,8 +874,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> op_add_layernorm(const Tensor& x, con
 }
 std::tuple<Tensor, Tensor, Tensor, Tensor> op_dropout_add_layernorm(const Tensor& x, const Tensor& residual, const Tensor& w,
                                                                     const OptTensor& b, double eps, double dropout_p,
-                                                                    int64_t seed) {
-  return k_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed);
+                                                                    int64_t seed, const OptTensor& seed_dev) {
+  return k_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed, seed_word(seed_dev, 0));
 }
 
 // y = act(x W^T + b) [+ residual] on the MFMA GEMM -> (y, pre-activation or empty)
@@ -915,8 +933,8 @@ Tensor op_rope(const Tensor& x, const Tensor& cos, const Tensor& sin, int64_t nh
 
 std::tuple<Tensor, Tensor> op_attention(const Tensor& q, const Tensor& k, const Tensor& v, const OptTensor& key_valid,
                                         double scale, bool causal, double dropout_p, int64_t seed, const OptTensor& q_start,
-                                        bool train) {
-  auto [o, lse] = k_attn_fwd(q, k, v, scale, causal, key_valid, train, dropout_p, seed, q_start);
+                                        bool train, const OptTensor& seed_dev) {
+  auto [o, lse] = k_attn_fwd(q, k, v, scale, causal, key_valid, train, dropout_p, seed, q_start, false, seed_word(seed_dev, 0));
   return {o, lse.defined() ? lse : nothing(q)};
 }
 
@@ -1144,7 +1162,7 @@ BertLayerOut op_bert_layer(const Tensor& h_in, const OptTensor& key_valid, const
                            const Tensor& ln1_b, const Tensor& wi, const Tensor& bi, const Tensor& wo2, const Tensor& bo2,
                            const Tensor& ln2_w, const Tensor& ln2_b, double eps, int64_t heads, int64_t d, double scale,
                            int64_t act, double p_attn, double p_hidden, int64_t seed_attn, int64_t seed1, int64_t seed2,
-                           bool train) {
+                           bool train, const OptTensor& seeds_dev) {  // seeds_dev: int64[3] = (attention, hidden 1, hidden 2)
   const int64_t b = h_in.size(0), s = h_in.size(1), hd = h_in.size(2), t = b * s;
   Tensor x = contig(h_in).view({t, hd});
   // the query columns leave the q|k|v GEMM carrying scale*log2(e) before their one rounding (tamd_gemm_colscale): the
@@ -1152,18 +1170,19 @@ BertLayerOut op_bert_layer(const Tensor& h_in, const OptTensor& key_valid, const
   Tensor qkv = kBertPrescale ? k_gemm_colscale(x, wqkv, bqkv, heads * d, scale * kLog2e)
                              : gemm_plain(x, wqkv, false, false, bqkv, {}, TAMD_EPI_BIAS);
   Qkv p3 = split_qkv(qkv, b, s, heads, heads, d);
-  auto [o, lse] = k_attn_fwd(p3.q, p3.k, p3.v, scale, false, key_valid, train, p_attn, seed_attn, {}, kBertPrescale);
+  auto [o, lse] = k_attn_fwd(p3.q, p3.k, p3.v, scale, false, key_valid, train, p_attn, seed_attn, {}, kBertPrescale,
+                             seed_word(seeds_dev, 0));
   auto dense_add_ln = [&](const Tensor& inp, const Tensor& w, const Tensor& bias, const Tensor& res, const Tensor& ln_w,
-                          const Tensor& ln_b, int64_t seed) -> std::tuple<Tensor, Tensor, Tensor, Tensor> {
+                          const Tensor& ln_b, int64_t seed, int site) -> std::tuple<Tensor, Tensor, Tensor, Tensor> {
     if (p_hidden > 0.0) {
       Tensor a = gemm_plain(inp, w, false, false, bias, {}, TAMD_EPI_BIAS);
-      return k_layernorm_dropout_fwd(a, ln_w, ln_b, eps, res, p_hidden, seed);  // (y, pre-norm sum, mean, rstd)
+      return k_layernorm_dropout_fwd(a, ln_w, ln_b, eps, res, p_hidden, seed, seed_word(seeds_dev, site));  // (y, pre-norm sum, mean, rstd)
     }
     Tensor y = gemm_plain(inp, w, false, false, bias, res, TAMD_EPI_RESIDUAL);
     auto [out, h_unused, mean, rstd] = k_layernorm_fwd(y, ln_w, ln_b, eps, {});
     return {out, y, mean, rstd};
   };
-  auto [h1, y1, mean1, rstd1] = dense_add_ln(o.view({t, hd}), wo, bo, x, ln1_w, ln1_b, seed1);
+  auto [h1, y1, mean1, rstd1] = dense_add_ln(o.view({t, hd}), wo, bo, x, ln1_w, ln1_b, seed1, 1);
   Tensor pre, inter;
   if (train) {  // the pre-activation is what the activation's backward needs
     std::tie(inter, pre) = linear_act_pre(h1, wi, bi, act);
@@ -1171,7 +1190,7 @@ BertLayerOut op_bert_layer(const Tensor& h_in, const OptTensor& key_valid, const
     pre = nothing(h_in);
     inter = gemm_plain(h1, wi, false, false, bi, {}, TAMD_EPI_BIAS_ACT, act);
   }
-  auto [out, y2, mean2, rstd2] = dense_add_ln(inter, wo2, bo2, h1, ln2_w, ln2_b, seed2);
+  auto [out, y2, mean2, rstd2] = dense_add_ln(inter, wo2, bo2, h1, ln2_w, ln2_b, seed2, 2);
   Tensor out3 = out.view({b, s, hd});
   if (!train) {
     auto e = [&] { return nothing(h_in); };
@@ -1185,20 +1204,22 @@ BertLayerOut op_bert_layer_bwd(const Tensor& d_out, const Tensor& h_in, const Op
                                const Tensor& qkv, const Tensor& o, const Tensor& lse, const Tensor& y1, const Tensor& mean1,
                                const Tensor& rstd1, const Tensor& h1, const Tensor& pre, const Tensor& inter, const Tensor& y2,
                                const Tensor& mean2, const Tensor& rstd2, int64_t heads, int64_t d, double scale, int64_t act,
-                               double p_attn, double p_hidden, int64_t seed_attn, int64_t seed1, int64_t seed2) {
+                               double p_attn, double p_hidden, int64_t seed_attn, int64_t seed1, int64_t seed2,
+                               const OptTensor& seeds_dev) {
   const int64_t b = h_in.size(0), s = h_in.size(1), hd = h_in.size(2), t = b * s;
   Tensor x = contig(h_in).view({t, hd});
   Tensor dy = contig(d_out).view({t, hd});
   // -> (gradient of the residual input, of the dense output, dw, db, column sums of the dense output's gradient = the
   //     dense layer's bias gradient, accumulated by the same kernel)
   auto ln_bwd = [&](const Tensor& g, const Tensor& y, const Tensor& ln_w, const Tensor& mean, const Tensor& rstd,
-                    int64_t seed) -> std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> {
-    if (p_hidden > 0.0) return k_layernorm_dropout_bwd(g, y, ln_w, mean, rstd, p_hidden, seed, {}, true, true);
+                    int64_t seed, int site) -> std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> {
+    if (p_hidden > 0.0)
+      return k_layernorm_dropout_bwd(g, y, ln_w, mean, rstd, p_hidden, seed, {}, true, true, seed_word(seeds_dev, site));
     auto [dx, dw, db, dc] = k_layernorm_bwd(g, y, ln_w, mean, rstd, {}, true, true);
     return {dx, dx, dw, db, dc};
   };
   // ---- BertOutput / BertIntermediate
-  auto [d_h1_res, d_b, dw_ln2, db_ln2, dbo2] = ln_bwd(dy, y2, ln2_w, mean2, rstd2, seed2);
+  auto [d_h1_res, d_b, dw_ln2, db_ln2, dbo2] = ln_bwd(dy, y2, ln2_w, mean2, rstd2, seed2, 2);
   Tensor dwo2 = gemm_plain(d_b, inter, true, true);  // [hd, I]
   Tensor d_inter = gemm_plain(d_b, wo2, false, true);  // [T, I]
   auto [d_pre, dbi] = k_bias_act_bwd(pre, {}, d_inter, act, true);  // (+ its column sums: the intermediate bias gradient)
@@ -1207,13 +1228,13 @@ BertLayerOut op_bert_layer_bwd(const Tensor& d_out, const Tensor& h_in, const Op
   Tensor d_h1 = gemm_plain(d_pre, wi, false, true, {}, d_h1_res, TAMD_EPI_RESIDUAL);  // + the residual path's gradient
   d_pre = Tensor();
   // ---- BertSelfOutput / BertSelfAttention
-  auto [d_x_res, d_a, dw_ln1, db_ln1, dbo] = ln_bwd(d_h1, y1, ln1_w, mean1, rstd1, seed1);
+  auto [d_x_res, d_a, dw_ln1, db_ln1, dbo] = ln_bwd(d_h1, y1, ln1_w, mean1, rstd1, seed1, 1);
   Tensor dwo = gemm_plain(d_a, o.view({t, hd}), true, true);
   Tensor d_o = gemm_plain(d_a, wo, false, true);
   Tensor d_qkv = at::empty_like(qkv);
   Qkv f = split_qkv(qkv, b, s, heads, heads, d), g = split_qkv(d_qkv, b, s, heads, heads, d);
   k_attn_bwd(f.q, f.k, f.v, o, lse, d_o.view({b, s, heads, d}), scale, false, key_valid, g.q, g.k, g.v, p_attn, seed_attn, {},
-             Tensor(), Tensor(), kBertPrescale);
+             Tensor(), Tensor(), kBertPrescale, seed_word(seeds_dev, 0));
   d_o = Tensor();
   Tensor dbqkv = k_colsum(d_qkv);
   Tensor dwqkv = gemm_plain(d_qkv, x, true, true);  // [3 hd, hd]
@@ -1231,10 +1252,11 @@ TORCH_LIBRARY(tamd, m) {
   m.def("layernorm_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor? residual=None) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd, Tensor? dres=None, bool need_db=True, "
         "bool need_colsum=False) -> (Tensor, Tensor, Tensor, Tensor)");
-  m.def("layernorm_dropout_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor residual, float dropout_p, int seed) -> "
-        "(Tensor, Tensor, Tensor, Tensor)");
+  m.def("layernorm_dropout_fwd(Tensor x, Tensor w, Tensor? b, float eps, Tensor residual, float dropout_p, int seed, "
+        "Tensor? seed_dev=None) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("layernorm_dropout_bwd(Tensor dy, Tensor h, Tensor w, Tensor mean, Tensor rstd, float dropout_p, int seed, "
-        "Tensor? dres=None, bool need_db=True, bool need_colsum=False) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+        "Tensor? dres=None, bool need_db=True, bool need_colsum=False, Tensor? seed_dev=None) -> "
+        "(Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("rope_(Tensor(a!) x2d, Tensor cos, Tensor sin, int seq, int nheads, int head_dim, bool conj=False) -> ()");
   m.def("embedding_fwd(Tensor ids, Tensor table) -> Tensor");
   m.def("embedding_bwd(Tensor ids, Tensor dout, int vocab, int padding_idx=-1) -> Tensor");
@@ -1260,26 +1282,26 @@ TORCH_LIBRARY(tamd, m) {
   m.def("gemm_colscale(Tensor x2, Tensor w, Tensor? bias, int scale_cols, float col_scale) -> Tensor");
   m.def("gemm_rope(Tensor x2, Tensor wqkv, Tensor cos, Tensor sin, int seq, int rope_heads, int head_dim) -> Tensor");
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None, bool need_lse=True, "
-        "float dropout_p=0.0, int seed=0, Tensor? q_start=None) -> (Tensor, Tensor)");
+        "float dropout_p=0.0, int seed=0, Tensor? q_start=None, Tensor? seed_dev=None) -> (Tensor, Tensor)");
   m.def("attn_bwd(Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor dout, float scale, bool causal, "
         "Tensor? key_valid=None, float dropout_p=0.0, int seed=0, Tensor? q_start=None, Tensor? rope_cos=None, "
-        "Tensor? rope_sin=None) -> (Tensor, Tensor, Tensor)");
+        "Tensor? rope_sin=None, Tensor? seed_dev=None) -> (Tensor, Tensor, Tensor)");
   m.def("attn_bwd_out(Tensor(a!) dq, Tensor(b!) dk, Tensor(c!) dv, Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, "
         "Tensor dout, float scale, bool causal, Tensor? key_valid=None, float dropout_p=0.0, int seed=0, "
-        "Tensor? q_start=None, Tensor? rope_cos=None, Tensor? rope_sin=None) -> ()");
+        "Tensor? q_start=None, Tensor? rope_cos=None, Tensor? rope_sin=None, Tensor? seed_dev=None) -> ()");
   // differentiable ops (forward implementations here; fake + autograd registered from Python)
   m.def("rmsnorm(Tensor x, Tensor w, float eps) -> (Tensor, Tensor)");
   m.def("add_rmsnorm(Tensor x, Tensor residual, Tensor w, float eps) -> (Tensor, Tensor, Tensor)");
   m.def("layernorm(Tensor x, Tensor w, Tensor? b, float eps) -> (Tensor, Tensor, Tensor)");
   m.def("add_layernorm(Tensor x, Tensor residual, Tensor w, Tensor? b, float eps) -> (Tensor, Tensor, Tensor, Tensor)");
-  m.def("dropout_add_layernorm(Tensor x, Tensor residual, Tensor w, Tensor? b, float eps, float dropout_p, int seed) -> "
-        "(Tensor, Tensor, Tensor, Tensor)");
+  m.def("dropout_add_layernorm(Tensor x, Tensor residual, Tensor w, Tensor? b, float eps, float dropout_p, int seed, "
+        "Tensor? seed_dev=None) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("linear(Tensor x, Tensor w, Tensor? bias, Tensor? residual, int act, bool train) -> (Tensor, Tensor)");
   m.def("fused_linear(Tensor x, Tensor wf, Tensor? bf, Tensor[] members) -> Tensor");
   m.def("conv1d(Tensor x, Tensor w, Tensor? b) -> Tensor");
   m.def("rope(Tensor x, Tensor cos, Tensor sin, int nheads, int head_dim, bool conj=False) -> Tensor");
   m.def("attention(Tensor q, Tensor k, Tensor v, Tensor? key_valid, float scale, bool causal, float dropout_p, int seed, "
-        "Tensor? q_start, bool train) -> (Tensor, Tensor)");
+        "Tensor? q_start, bool train, Tensor? seed_dev=None) -> (Tensor, Tensor)");
   m.def("swiglu(Tensor gu) -> Tensor");
   m.def("bias_act(Tensor x, Tensor? bias, int act) -> Tensor");
   m.def("embedding(Tensor ids, Tensor table, int padding_idx=-1) -> Tensor");
@@ -1303,13 +1325,13 @@ TORCH_LIBRARY(tamd, m) {
   m.def("bert_layer(Tensor h_in, Tensor? key_valid, Tensor wqkv, Tensor bqkv, Tensor wq, Tensor wk, Tensor wv, Tensor bq, "
         "Tensor bk, Tensor bv, Tensor wo, Tensor bo, Tensor ln1_w, Tensor ln1_b, Tensor wi, Tensor bi, Tensor wo2, "
         "Tensor bo2, Tensor ln2_w, Tensor ln2_b, float eps, int heads, int d, float scale, int act, float p_attn, "
-        "float p_hidden, int seed_attn, int seed1, int seed2, bool train) -> (Tensor, Tensor, Tensor, Tensor, Tensor, "
-        "Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+        "float p_hidden, int seed_attn, int seed1, int seed2, bool train, Tensor? seeds_dev=None) -> (Tensor, Tensor, Tensor, "
+        "Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("bert_layer_bwd(Tensor d_out, Tensor h_in, Tensor? key_valid, Tensor wqkv, Tensor wo, Tensor ln1_w, Tensor wi, "
         "Tensor wo2, Tensor ln2_w, Tensor qkv, Tensor o, Tensor lse, Tensor y1, Tensor mean1, Tensor rstd1, Tensor h1, "
         "Tensor pre, Tensor inter, Tensor y2, Tensor mean2, Tensor rstd2, int heads, int d, float scale, int act, "
-        "float p_attn, float p_hidden, int seed_attn, int seed1, int seed2) -> (Tensor, Tensor, Tensor, Tensor, Tensor, "
-        "Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+        "float p_attn, float p_hidden, int seed_attn, int seed1, int seed2, Tensor? seeds_dev=None) -> (Tensor, Tensor, Tensor, "
+        "Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
 }
 
 // The implementations are registered for the CUDA key (HIP on ROCm) and for CPU: with the product library a CPU tensor is
@@ -1319,7 +1341,7 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("rmsnorm_bwd", &k_rmsnorm_bwd);                             \
   m.impl("layernorm_fwd", &op_layernorm_fwd);                        \
   m.impl("layernorm_bwd", &op_layernorm_bwd);                        \
-  m.impl("layernorm_dropout_fwd", &k_layernorm_dropout_fwd);         \
+  m.impl("layernorm_dropout_fwd", &op_layernorm_dropout_fwd);        \
   m.impl("layernorm_dropout_bwd", &op_layernorm_dropout_bwd);        \
   m.impl("rope_", &op_rope_);                                        \
   m.impl("embedding_fwd", &k_embedding_fwd);                         \

@@ -85,7 +85,7 @@ def llama_layer(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, wv, wo,
 # ============================================================================================ BertLayer as one op
 # (what the op computes: csrc/torch_binding.cpp op_bert_layer / op_bert_layer_bwd)
 def _bert_layer_fake(h_in, key_valid, wqkv, bqkv, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w,
-                     ln2_b, eps, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train):
+                     ln2_b, eps, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train, seeds_dev=None):
     b, s, hd = h_in.shape
     t = b * s
     out = h_in.new_empty(b, s, hd)
@@ -99,7 +99,7 @@ def _bert_layer_fake(h_in, key_valid, wqkv, bqkv, wq, wk, wv, bq, bk, bv, wo, bo
 
 
 def _bert_layer_bwd_fake(d_out, h_in, key_valid, wqkv, wo, ln1_w, wi, wo2, ln2_w, qkv, o, lse, y1, mean1, rstd1, h1, pre,
-                         inter, y2, mean2, rstd2, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2):
+                         inter, y2, mean2, rstd2, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, seeds_dev=None):
     vec = lambda w: w.new_empty(w.shape[0])  # noqa: E731
     return (torch.empty_like(h_in, memory_format=torch.contiguous_format), torch.empty_like(wqkv), vec(wqkv),
             torch.empty_like(wo), vec(wo), torch.empty_like(ln1_w), torch.empty_like(ln1_w), torch.empty_like(wi), vec(wi),
@@ -108,23 +108,24 @@ def _bert_layer_bwd_fake(d_out, h_in, key_valid, wqkv, wo, ln1_w, wi, wo2, ln2_w
 
 def _bert_layer_setup(ctx, inputs, output):
     (h_in, key_valid, wqkv, _bqkv, _wq, _wk, _wv, _bq, _bk, _bv, wo, _bo, ln1_w, _ln1_b, wi, _bi, wo2, _bo2, ln2_w, _ln2_b,
-     _eps, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train) = inputs
+     _eps, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train, seeds_dev) = inputs
     _out, qkv, o, lse, y1, mean1, rstd1, h1, pre, inter, y2, mean2, rstd2 = output
     ctx.save_for_backward(h_in, key_valid, wqkv, wo, ln1_w, wi, wo2, ln2_w, qkv, o, lse, y1, mean1, rstd1, h1, pre, inter,
-                          y2, mean2, rstd2)
+                          y2, mean2, rstd2, seeds_dev)
     ctx.meta = (heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train)
     ctx.set_materialize_grads(False)
 
 
 def _bert_layer_backward(ctx, d_out, *_aux):
-    none = (None,) * 31
+    none = (None,) * 32
     if d_out is None:
         return none
     heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, train = ctx.meta
     if not train:
         raise ops.TamdError("bert_layer was run with train=False but is being differentiated")
+    *saved, seeds_dev = ctx.saved_tensors
     (d_x, dwqkv, dbqkv, dwo, dbo, dw_ln1, db_ln1, dwi, dbi, dwo2, dbo2, dw_ln2, db_ln2) = T.bert_layer_bwd(
-        d_out, *ctx.saved_tensors, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2)
+        d_out, *saved, heads, d, scale, act, p_attn, p_hidden, seed_attn, seed1, seed2, seeds_dev)
     hd = dwqkv.shape[1]
     #       h_in kv    wqkv  bqkv  wq          wk                wv              bq          bk                bv
     return (d_x, None, None, None, dwqkv[:hd], dwqkv[hd:2 * hd], dwqkv[2 * hd:], dbqkv[:hd], dbqkv[hd:2 * hd], dbqkv[2 * hd:],
@@ -139,11 +140,14 @@ def bert_layer(h_in, key_valid, wqkv, bqkv, members, wo, bo, ln1_w, ln1_b, wi, b
                scale, act, p_attn, p_hidden):
     """BertLayer.forward (encoder layer) as one op.  `wqkv` / `bqkv` are the fused buffers the query / key / value
     parameters `members` = (wq, wk, wv, bq, bk, bv) are row-slice views of (fused_params.py).  Dropout seeds come from
-    torch's CPU generator (ops.dropout_seed): `torch.manual_seed` repeats them, checkpointing regenerates them."""
+    torch's generators (ops.dropout_seeds): `torch.manual_seed` repeats them, checkpointing regenerates them, a step captured
+    in a HIP graph draws fresh ones on every replay."""
     wq, wk, wv, bq, bk, bv = members
     train = ops._wants_grad(h_in, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w, ln2_b)
-    seed_attn = ops.dropout_seed() if p_attn > 0.0 else 0
-    seed1, seed2 = (ops.dropout_seed(), ops.dropout_seed()) if p_hidden > 0.0 else (0, 0)
+    seed_attn = seed1 = seed2 = 0
+    seeds_dev = None
+    if p_attn > 0.0 or p_hidden > 0.0:  # (eager: three host seeds; while a graph is being captured: three device words)
+        (seed_attn, seed1, seed2), seeds_dev = ops.dropout_seeds(3, h_in.device)
     return T.bert_layer(h_in, key_valid, wqkv, bqkv, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w,
                         ln2_b, float(eps), int(heads), int(d), float(scale), int(act), float(p_attn), float(p_hidden),
-                        int(seed_attn), int(seed1), int(seed2), train)[0]
+                        int(seed_attn), int(seed1), int(seed2), train, seeds_dev)[0]

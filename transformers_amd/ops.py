@@ -136,16 +136,17 @@ def raw_layernorm_bwd(dy, h, w, mean, rstd, dres=None, need_db=True):
     return dx, dw, (db if need_db else None)
 
 
-def raw_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed):
+def raw_layernorm_dropout_fwd(x, w, b, eps, residual, dropout_p, seed, seed_dev=None):
     """h = dropout(x, p) + residual; y = LayerNorm(h)  ->  (y, h, mean, rstd).  Keep mask: the counter-based hash of
-    (seed, flat element index), `hidden_dropout_keep_mask` on the host."""
-    return T.layernorm_dropout_fwd(x, w, b, float(eps), residual, float(dropout_p), int(seed) & 0x7FFFFFFFFFFFFFFF)
+    (seed, flat element index), `hidden_dropout_keep_mask` on the host.  seed_dev: the seed as an int64[1] device tensor
+    (replaces `seed`: what a captured training step uses)."""
+    return T.layernorm_dropout_fwd(x, w, b, float(eps), residual, float(dropout_p), int(seed) & 0x7FFFFFFFFFFFFFFF, seed_dev)
 
 
-def raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True):
+def raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True, seed_dev=None):
     """-> (dx = gradient of the residual input, dx_drop = gradient of the dropped-out input, dw, db)."""
     dx, dxd, dw, db, _ = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, float(dropout_p), int(seed) & 0x7FFFFFFFFFFFFFFF, dres,
-                                              need_db)
+                                              need_db, False, seed_dev)
     return dx, dxd, dw, (db if need_db else None)
 
 
@@ -292,15 +293,15 @@ def raw_gemm_swiglu(x2, wgu, need_gu=True):
     return (gu if need_gu else None), act
 
 
-def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None):
+def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None, seed_dev=None):
     """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32."""
     o, lse = T.attn_fwd(q, k, v, float(scale), bool(causal), key_valid, need_lse, float(dropout_p),
-                        int(seed) & 0x7FFFFFFFFFFFFFFF, q_start)
+                        int(seed) & 0x7FFFFFFFFFFFFFFF, q_start, seed_dev)
     return o, (lse if need_lse else None)
 
 
 def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, dk=None, dv=None,
-                 dropout_p=0.0, seed=0, q_start=None, rope=None):
+                 dropout_p=0.0, seed=0, q_start=None, rope=None, seed_dev=None):
     """Gradients written into dq/dk/dv (views with the strides of q/k/v) or freshly allocated.  rope = (cos, sin)
     ([seq, 128] or [batch, seq, 128], the storage dtype): q and k had been rotated before the attention, dq and dk leave
     through the transposed rotation (the same bits as raw_rope_(conj=True) on the stored gradients)."""
@@ -308,9 +309,9 @@ def raw_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid=None, dq=None, 
     seed = int(seed) & 0x7FFFFFFFFFFFFFFF
     if dq is None:
         return T.attn_bwd(q, k, v, o, lse, dout, float(scale), bool(causal), key_valid, float(dropout_p), seed, q_start,
-                          cos, sin)
+                          cos, sin, seed_dev)
     T.attn_bwd_out(dq, dk, dv, q, k, v, o, lse, dout, float(scale), bool(causal), key_valid, float(dropout_p), seed,
-                   q_start, cos, sin)
+                   q_start, cos, sin, seed_dev)
     return dq, dk, dv
 
 
@@ -353,9 +354,9 @@ register("layernorm_fwd", lambda x, w, b, eps, residual=None: (torch.empty_like(
 register("layernorm_bwd", lambda dy, h, w, mean, rstd, dres=None, need_db=True, need_colsum=False: (
     torch.empty_like(h), torch.empty_like(w), torch.empty_like(w) if need_db else _nothing(w),
     torch.empty_like(w) if need_colsum else _nothing(w)))
-register("layernorm_dropout_fwd", lambda x, w, b, eps, residual, dropout_p, seed: (
+register("layernorm_dropout_fwd", lambda x, w, b, eps, residual, dropout_p, seed, seed_dev=None: (
     torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x)), _f32(x, _rows(x))))
-register("layernorm_dropout_bwd", lambda dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True, need_colsum=False: (
+register("layernorm_dropout_bwd", lambda dy, h, w, mean, rstd, dropout_p, seed, dres=None, need_db=True, need_colsum=False, seed_dev=None: (
     torch.empty_like(h), torch.empty_like(h), torch.empty_like(w), torch.empty_like(w) if need_db else _nothing(w),
     torch.empty_like(w) if need_colsum else _nothing(w)))
 register("rope_", lambda x2d, cos, sin, seq, nheads, head_dim, conj=False: None)
@@ -395,15 +396,15 @@ register("gemm_out", lambda out, a, b, a_km=False, b_kn=False, bias=None, residu
 register("gemm_swiglu", lambda x2, wgu, need_gu=True: (x2.new_empty(x2.shape[0], wgu.shape[0]) if need_gu else _nothing(x2),
                                                        x2.new_empty(x2.shape[0], wgu.shape[0] // 2)))
 register("gemm_rope", lambda x2, wqkv, cos, sin, seq, rope_heads, head_dim: x2.new_empty(x2.shape[0], wqkv.shape[0]))
-register("attn_fwd", lambda q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None: (
+register("attn_fwd", lambda q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None, seed_dev=None: (
     q.new_empty(q.shape), _f32(q, q.shape[0], q.shape[2], q.shape[1]) if need_lse else _nothing(q)))
 register("attn_bwd", lambda q, k, v, o, lse, dout, scale, causal, key_valid=None, dropout_p=0.0, seed=0, q_start=None,
-         rope_cos=None, rope_sin=None: (
+         rope_cos=None, rope_sin=None, seed_dev=None: (
              torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device),
              torch.empty_strided(k.shape, k.stride(), dtype=k.dtype, device=k.device),
              torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)))
 register("attn_bwd_out", lambda dq, dk, dv, q, k, v, o, lse, dout, scale, causal, key_valid=None, dropout_p=0.0, seed=0,
-         q_start=None, rope_cos=None, rope_sin=None: None)
+         q_start=None, rope_cos=None, rope_sin=None, seed_dev=None: None)
 
 
 # ---- differentiable ops --------------------------------------------------------------------------------------
@@ -490,24 +491,24 @@ register("add_layernorm", lambda x, residual, w, b, eps: (torch.empty_like(x), t
 # y = LayerNorm(dropout(x, p) + residual) -> (y, h): BertSelfOutput / BertOutput in train mode
 # (modeling_bert.py:289-293, :347-351); the keep mask is regenerated from (seed, element index) in the backward
 def _dropout_add_layernorm_setup(ctx, inputs, output):
-    ctx.save_for_backward(output[1], inputs[2], output[2], output[3])
+    ctx.save_for_backward(output[1], inputs[2], output[2], output[3], inputs[7])  # (+ the device seed, if any)
     ctx.has_b = inputs[3] is not None
     ctx.drop = (inputs[5], inputs[6])
     ctx.set_materialize_grads(False)
 
 
 def _dropout_add_layernorm_backward(ctx, dy, dh, _dm, _dr):
-    none = (None,) * 7
+    none = (None,) * 8
     if dy is None:
         if dh is None:
             return none
         raise TamdError("dropout_add_layernorm: only the pre-norm sum is differentiated; use ops.layernorm pieces")
-    h, w, mean, rstd = ctx.saved_tensors
-    dx, dxd, dw, db, _ = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, ctx.drop[0], ctx.drop[1], dh, ctx.has_b, False)
+    h, w, mean, rstd, seed_dev = ctx.saved_tensors
+    dx, dxd, dw, db, _ = T.layernorm_dropout_bwd(dy, h, w, mean, rstd, ctx.drop[0], ctx.drop[1], dh, ctx.has_b, False, seed_dev)
     return (dxd, dx, dw, (db if ctx.has_b else None)) + none[4:]
 
 
-register("dropout_add_layernorm", lambda x, residual, w, b, eps, dropout_p, seed: (
+register("dropout_add_layernorm", lambda x, residual, w, b, eps, dropout_p, seed, seed_dev=None: (
     torch.empty_like(x), torch.empty_like(x), _f32(x, _rows(x)), _f32(x, _rows(x))),
     _dropout_add_layernorm_backward, _dropout_add_layernorm_setup)
 
@@ -611,25 +612,25 @@ register("rope", lambda x, cos, sin, nheads, head_dim, conj=False: torch.empty_l
 # softmax(scale QK^T + mask) V on [B,S,H,D] views.  Reference: eager_attention_forward,
 # models/llama/modeling_llama.py:191-213 and siblings.
 def _attention_setup(ctx, inputs, output):
-    q, k, v, key_valid, scale, causal, dropout_p, seed, q_start, _train = inputs
-    ctx.save_for_backward(q, k, v, output[0], output[1], key_valid, q_start)
+    q, k, v, key_valid, scale, causal, dropout_p, seed, q_start, _train, seed_dev = inputs
+    ctx.save_for_backward(q, k, v, output[0], output[1], key_valid, q_start, seed_dev)
     ctx.meta = (scale, causal, dropout_p, seed)
     ctx.set_materialize_grads(False)
 
 
 def _attention_backward(ctx, do, _dlse):
-    none = (None,) * 10
+    none = (None,) * 11
     if do is None:
         return none
-    q, k, v, o, lse, key_valid, q_start = ctx.saved_tensors
+    q, k, v, o, lse, key_valid, q_start, seed_dev = ctx.saved_tensors
     if lse.numel() == 0:
         raise TamdError("attention was run with train=False but is being differentiated")
     scale, causal, dropout_p, seed = ctx.meta
-    dq, dk, dv = T.attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid, dropout_p, seed, q_start)
+    dq, dk, dv = T.attn_bwd(q, k, v, o, lse, do, scale, causal, key_valid, dropout_p, seed, q_start, None, None, seed_dev)
     return (dq, dk, dv) + none[3:]
 
 
-register("attention", lambda q, k, v, key_valid, scale, causal, dropout_p, seed, q_start, train: (
+register("attention", lambda q, k, v, key_valid, scale, causal, dropout_p, seed, q_start, train, seed_dev=None: (
     q.new_empty(q.shape), _f32(q, q.shape[0], q.shape[2], q.shape[1]) if train else _nothing(q)),
     _attention_backward, _attention_setup)
 
@@ -812,11 +813,13 @@ def layernorm(x, w, b, eps, residual=None):
 
 
 def dropout_add_layernorm(x, residual, w, b, eps, dropout_p, seed=None):
-    """LayerNorm(dropout(x, p) + residual) -> y, the dropout inside the norm kernel (seed from torch's CPU generator
-    unless given: `torch.manual_seed` repeats it, activation checkpointing regenerates it)."""
+    """LayerNorm(dropout(x, p) + residual) -> y, the dropout inside the norm kernel (seed from torch's generators unless
+    given -- `dropout_seeds`: `torch.manual_seed` repeats it, activation checkpointing regenerates it, a captured step draws
+    a fresh one per replay)."""
+    seed_dev = None
     if seed is None:
-        seed = dropout_seed()
-    return T.dropout_add_layernorm(x, residual, w, b, float(eps), float(dropout_p), int(seed))[0]
+        (seed,), seed_dev = dropout_seeds(1, x.device)
+    return T.dropout_add_layernorm(x, residual, w, b, float(eps), float(dropout_p), int(seed), seed_dev)[0]
 
 
 def hidden_dropout_keep_mask(seed: int, rows: int, cols: int, p: float) -> torch.Tensor:
@@ -869,6 +872,24 @@ def dropout_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
+def dropout_seed_tensor(n: int, device) -> torch.Tensor:
+    """`n` 62-bit seeds as an int64 DEVICE tensor, drawn by torch's own RNG kernel on the current stream: no host round trip,
+    and -- the point -- safe under HIP-graph capture: the generator's philox offset is part of the captured graph's state and
+    advances on every replay, so every replay of a captured training step draws fresh masks (a host-drawn seed would be baked
+    into the graph).  `torch.manual_seed` / `torch.cuda.manual_seed` repeat it; activation checkpointing restores the device
+    RNG state before recomputing."""
+    return torch.empty(n, dtype=torch.int64, device=device).random_(0, 2 ** 62)
+
+
+def dropout_seeds(n: int, device):
+    """-> (host seeds [n ints], device seed tensor or None) for `n` dropout sites of one op.  Eagerly the seeds are host
+    integers (no extra launch); while the current stream is being captured into a graph they live on the device."""
+    dev = torch.device(device)
+    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+        return [0] * n, dropout_seed_tensor(n, dev)
+    return [dropout_seed() for _ in range(n)], None
+
+
 def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int, p: float) -> torch.Tensor:
     """The attention kernels' keep mask [B,H,Sq,Sk] (bool), rebuilt on the host (csrc/dropout.h: the seed is mixed once by
     splitmix64; one 64-bit mix of 24-bit multiplies decides a 2 x 2 block -- query pair x key pair -- of the probability
@@ -909,11 +930,11 @@ def dropout_keep_mask(seed: int, batch: int, heads: int, seq_q: int, seq_k: int,
     return torch.from_numpy((field >= thr16).reshape(batch, heads, seq_q, seq_k))
 
 
-def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None, q_start=None):
-    if dropout_p > 0.0 and seed is None:
-        seed = dropout_seed()
+def attention(q, k, v, scale, causal, key_valid=None, dropout_p=0.0, seed=None, q_start=None, seed_dev=None):
+    if dropout_p > 0.0 and seed is None and seed_dev is None:
+        (seed,), seed_dev = dropout_seeds(1, q.device)
     return T.attention(q, k, v, key_valid, float(scale), bool(causal), float(dropout_p), int(seed or 0), q_start,
-                       _wants_grad(q, k, v))[0]
+                       _wants_grad(q, k, v), seed_dev)[0]
 
 
 def packed_q_start(seq_ids: torch.Tensor) -> torch.Tensor:
