@@ -294,8 +294,9 @@ def main():
     ap.add_argument("--config", default="llama3-8b", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hip-graph", action="store_true",
-                    help="forward-only configurations (llava): capture one step in a HIP graph after the warm-up and time "
-                         "replays -- the host side (10-20 us per op, ~3300 launches) is what bounds that regime")
+                    help="capture one step (forward, or forward + backward with graph-safe dropout seeds) in a HIP graph after "
+                         "the warm-up and time replays -- for configurations whose host side (hundreds to thousands of "
+                         "10-50 us launches) bounds the step")
     ap.add_argument("--fused-lm-head-loss", action="store_true")
     ap.add_argument("--gemm-timer", choices=("auto", "on", "off"), default="auto",
                     help="HIP-event pair around every GEMM launch of the timed region (the `roofline` object).  auto = on for "
@@ -432,8 +433,12 @@ def main():
     barrier()
     run = step
     if args.hip_graph:
-        if backward or world > 1:
-            raise SystemExit("--hip-graph: single-GPU forward-only configurations")
+        # one step as ONE HIP graph.  Forward-only configurations: the host side is what bounds them.  Training steps
+        # (round 4): dropout seeds are device words drawn by torch's graph-safe RNG kernel while capturing
+        # (transformers_amd.ops.dropout_seeds), so every replay draws fresh masks; gradients are left to autograd's first-write
+        # path (zero_grad(set_to_none=True) inside the captured step), i.e. a replay overwrites them.
+        if world > 1:
+            raise SystemExit("--hip-graph: single-GPU runs (DDP's bucket hooks are host code)")
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # (capture wants the allocator warmed on a side stream)
