@@ -146,8 +146,15 @@ def bert_layer(h_in, key_valid, wqkv, bqkv, members, wo, bo, ln1_w, ln1_b, wi, b
     train = ops._wants_grad(h_in, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w, ln2_b)
     seed_attn = seed1 = seed2 = 0
     seeds_dev = None
-    if p_attn > 0.0 or p_hidden > 0.0:  # (eager: three host seeds; while a graph is being captured: three device words)
-        (seed_attn, seed1, seed2), seeds_dev = ops.dropout_seeds(3, h_in.device)
+    if p_attn > 0.0 or p_hidden > 0.0:
+        # eager: one host seed per ACTIVE site, drawn in the order attention, hidden 1, hidden 2; while a graph is being
+        # captured: three device words (site = index)
+        n = (1 if p_attn > 0.0 else 0) + (2 if p_hidden > 0.0 else 0)
+        host, seeds_dev = ops.dropout_seeds(3 if ops.capturing(h_in.device) else n, h_in.device)
+        if seeds_dev is None:
+            it = iter(host)
+            seed_attn = next(it) if p_attn > 0.0 else 0
+            seed1, seed2 = (next(it), next(it)) if p_hidden > 0.0 else (0, 0)
     return T.bert_layer(h_in, key_valid, wqkv, bqkv, wq, wk, wv, bq, bk, bv, wo, bo, ln1_w, ln1_b, wi, bi, wo2, bo2, ln2_w,
                         ln2_b, float(eps), int(heads), int(d), float(scale), int(act), float(p_attn), float(p_hidden),
                         int(seed_attn), int(seed1), int(seed2), train, seeds_dev)[0]

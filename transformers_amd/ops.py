@@ -881,12 +881,17 @@ def dropout_seed_tensor(n: int, device) -> torch.Tensor:
     return torch.empty(n, dtype=torch.int64, device=device).random_(0, 2 ** 62)
 
 
+def capturing(device) -> bool:
+    """Is the current stream of `device` being captured into a HIP graph?"""
+    dev = torch.device(device)
+    return dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
 def dropout_seeds(n: int, device):
     """-> (host seeds [n ints], device seed tensor or None) for `n` dropout sites of one op.  Eagerly the seeds are host
     integers (no extra launch); while the current stream is being captured into a graph they live on the device."""
-    dev = torch.device(device)
-    if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
-        return [0] * n, dropout_seed_tensor(n, dev)
+    if capturing(device):
+        return [0] * n, dropout_seed_tensor(n, torch.device(device))
     return [dropout_seed() for _ in range(n)], None
 
 
