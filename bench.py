@@ -308,6 +308,9 @@ def main():
                     help="between steps: none = zero_grad(set_to_none=True) (Trainer's default; ours without DDP), zero = "
                          "zero in place (gradients stay views of the DDP buckets; ours under DDP), keep = no zero_grad")
     ap.add_argument("--bucket-mb", type=int, default=int(os.environ.get("TAMD_DDP_BUCKET_MB", "256")))
+    ap.add_argument("--no-ddp-zero-copy", action="store_true",
+                    help="under DDP: leave the gradient hand-over to torch (copy into the bucket views) instead of writing the "
+                         "weight-gradient GEMMs straight into them (transformers_amd/ddp.py)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -404,6 +407,13 @@ def main():
 
         net = DDP(model, device_ids=[local_rank], bucket_cap_mb=args.bucket_mb, gradient_as_bucket_view=True,
                   broadcast_buffers=False, find_unused_parameters=False, static_graph=True)
+        if not args.no_ddp_zero_copy:
+            # the layer ops write dW straight into DDP's bucket views and hand DDP aliases of them; the bucket is averaged
+            # in place by RCCL (ReduceOp.AVG): no copy into the buckets, no scaling pass (transformers_amd/ddp.py)
+            from transformers_amd import ddp as tamd_ddp
+
+            tamd_ddp.reset()
+            tamd_ddp.enable_zero_copy(net)
 
     def step():
         if not backward:
@@ -416,7 +426,8 @@ def main():
         # hand DDP fresh tensors that it copies into the buckets and re-points, so they are zeroed in place instead --
         # measured on MI355X at world size 1 (profiles/r03c_ddp_grads_ab.jsonl): 1299.8 ms per step dropped, 1288.9 zeroed
         # in place, 1285.8 never zeroed (non-DDP step on the same box: 1273.4).  `--ddp-grads none|zero|keep` overrides.
-        mode = args.ddp_grads or ("zero" if ddp else "none")
+        # (with the zero-copy hand-over the gradients must be None when the backward starts: the Trainer's default)
+        mode = args.ddp_grads or ("zero" if (ddp and args.no_ddp_zero_copy) else "none")
         if mode == "none":
             model.zero_grad(set_to_none=True)
         elif mode == "zero":
@@ -522,6 +533,10 @@ def main():
                                        if m.__dict__.get("_tamd_stack", (None, 1))[1] == 0),
             "roofline": roofline,
         }
+        if ddp:
+            from transformers_amd import ddp as tamd_ddp
+
+            line["ddp_zero_copy"] = dict(tamd_ddp.STATS, enabled=not args.no_ddp_zero_copy)
         if roofline is not None and world == 1 and args.config == "llama3-8b":
             try:
                 roofline["clock_probe"] = clock_probe(dev)

@@ -249,6 +249,16 @@ int tamd_gemm_ws(const void* A, const void* B, void* C, const void* bias, const 
                  int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act, int dtype,
                  void* workspace, size_t workspace_bytes, tamd_stream_t stream);
 
+/* ABI 8.  The weight gradient dW[M, N] = dY[K, M]^T . X[K, N] (both operands k-major: TAMD_GEMM_A_KM | TAMD_GEMM_B_KN) of a
+ * FUSED projection -- weight rows [q | k | v] (modeling_llama.py:254-256) or [gate | up] (:174-176) -- with the rows of each
+ * member stored into that member's own buffer: nseg <= 3 segments, C_segs[i] = [seg_rows[i], ldc], every segment but the last
+ * a multiple of 256 rows.  The members' gradients are separate tensors (under DistributedDataParallel: non-adjacent views of
+ * the all-reduce buckets, trainer.py:712-737); this writes them without a copy.  K % 64 == 0; epilogue TAMD_EPI_NONE or
+ * TAMD_EPI_ACCUM; workspace as tamd_gemm_ws (tamd_gemm_workspace_bytes(M, N, K, flags 3, epilogue), may be NULL). */
+int tamd_gemm_seg(const void* A, const void* B, void* const* C_segs, const int64_t* seg_rows, int nseg, int64_t N, int64_t K,
+                  int64_t lda, int64_t ldb, int64_t ldc, int epilogue, int dtype, void* workspace, size_t workspace_bytes,
+                  tamd_stream_t stream);
+
 /* ABI 8.  BertIntermediate / CLIPMLP.fc1 in train mode (models/bert/modeling_bert.py:334-337, models/clip/modeling_clip.py:
  * 346-350): the activation AND the rounded pre-activation its backward needs, from ONE GEMM:
  *   PRE[M,N] = round(A . B^T + bias)      Y[M,N] = round(act(PRE))

@@ -26,6 +26,11 @@ def _build_model(kind="llama"):
     from transformers import LlamaConfig, LlamaForCausalLM
 
     torch.manual_seed(0)
+    if kind == "llama-tiles":  # q / k / v / gate / up of 256 rows each: the segmented dW GEMM stores whole tiles (tamd_gemm_seg)
+        cfg = LlamaConfig(vocab_size=256, hidden_size=256, intermediate_size=256, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=4, head_dim=64, max_position_embeddings=128,
+                          rms_norm_eps=1e-5, attn_implementation="eager")
+        return LlamaForCausalLM(cfg).bfloat16().train(), cfg
     if kind == "bert":  # the fused BertLayer op, the padded-vocabulary MLM head and loss (dropout off: the check below
         from transformers import BertConfig, BertForMaskedLM  # recomputes the per-rank gradients in this process)
 
@@ -41,12 +46,45 @@ def _build_model(kind="llama"):
 
 def _batch(cfg, rank, kind):
     g = torch.Generator().manual_seed(100 + rank)
-    ids = torch.randint(0, cfg.vocab_size, (2, 48), generator=g)
+    ids = torch.randint(0, cfg.vocab_size, (2, 64 if kind == "llama-tiles" else 48), generator=g)
     if kind != "bert":
         return dict(input_ids=ids, labels=ids, use_cache=False)
     labels = ids.clone()
     labels[torch.rand(ids.shape, generator=g) > 0.3] = -100  # MLM: most positions carry no label
     return dict(input_ids=ids, labels=labels)
+
+
+def _worker_zero_copy(rank, world, port, out_dir, kind):
+    """Three steps of a Llama model under DDP with transformers_amd.ddp.enable_zero_copy: step 1 fills the registry (and DDP
+    rebuilds its buckets after it), step 2 still copies (stale views), step 3 writes the dW GEMMs into the buckets."""
+    for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import transformers_amd
+    from emu_backend import emu_backend
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from transformers_amd import ddp as tddp
+
+    with emu_backend():
+        model, cfg = _build_model(kind)
+        transformers_amd.accelerate(model)
+        net = DDP(model, bucket_cap_mb=1, gradient_as_bucket_view=True, broadcast_buffers=False,
+                  find_unused_parameters=False, static_graph=True)
+        tddp.reset()
+        tddp.enable_zero_copy(net)
+        per_step = []
+        for step in range(3):
+            model.zero_grad(set_to_none=True)  # (the Trainer's default between steps)
+            out = net(**_batch(cfg, rank, kind))
+            out.loss.backward()
+            per_step.append(dict(tddp.STATS))
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+        aliased = all(tddp._VIEWS[id(p)][1].data_ptr() == p.grad.data_ptr() for p in model.parameters() if id(p) in tddp._VIEWS)
+    torch.save({"grads": grads, "stats": per_step, "aliased": aliased, "loss": out.loss.item()}, f"{out_dir}/rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, out_dir, kind="llama"):
@@ -88,6 +126,40 @@ def test_ddp_world2_gloo(tmp_path, kind):
         assert torch.equal(r[0]["weights"][n], r[1]["weights"][n]), n
         assert torch.equal(r[0]["grads"][n], r[1]["grads"][n]), n
     # (2) reduced gradient == mean of single-process gradients on the two data shards
+    for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
+        sys.path.insert(0, str(p))
+    import transformers_amd
+    from emu_backend import emu_backend
+
+    per_rank = []
+    with emu_backend():
+        for rank in range(world):
+            model, cfg = _build_model(kind)
+            transformers_amd.accelerate(model)
+            model(**_batch(cfg, rank, kind)).loss.backward()
+            per_rank.append({n: p.grad.detach().float() for n, p in model.named_parameters()})
+    for n, gd in r[0]["grads"].items():
+        want = (per_rank[0][n] + per_rank[1][n]) / 2
+        err = (gd - want).norm() / want.norm().clamp_min(1e-12)
+        assert err < 1e-2, (n, err.item())  # bf16 bucket arithmetic
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind", ["llama-tiles", "llama"])  # whole-tile segments (tamd_gemm_seg); ragged ones (one product + slices)
+def test_ddp_zero_copy_gradients_world2_gloo(tmp_path, kind):
+    """transformers_amd/ddp.py (trainer.py:712-737): with the communication hook registered, the layer op's
+    backward writes its weight gradients straight into DDP's bucket views from the third step on (tamd_gemm_seg for the fused
+    q|k|v and gate|up products) and hands DDP aliases of them -- the reduced gradients are still the mean of the per-rank
+    gradients, identical on both ranks, and `.grad` IS the bucket view."""
+    world = 2
+    mp.spawn(_worker_zero_copy, args=(world, _free_port(), str(tmp_path), kind), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
+    for n in r[0]["grads"]:
+        assert torch.equal(r[0]["grads"][n], r[1]["grads"][n]), n
+    assert r[0]["aliased"] and r[1]["aliased"]
+    st = r[0]["stats"]
+    assert st[0]["zero_copy_layers"] == 0                      # step 1: nothing registered yet
+    assert st[2]["zero_copy_layers"] - st[1]["zero_copy_layers"] == 2, st  # step 3: both decoder layers wrote into the buckets
     for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
         sys.path.insert(0, str(p))
     import transformers_amd

@@ -1126,3 +1126,19 @@ def test_dropout_seed_from_device_memory_is_the_same_mask(env):
     b1 = ops.raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, 0.1, seed)
     b2 = ops.raw_layernorm_dropout_bwd(dy, h, w, mean, rstd, 0.1, 0, seed_dev=sd)
     assert all(torch.equal(a, c) for a, c in zip(b1, b2))
+
+
+def test_gemm_segmented_weight_gradient(env):
+    """tamd_gemm_seg (ABI 8): dW = dY^T . X of a fused q|k|v / gate|up projection with each member's rows stored into its own
+    buffer -- the bits of the one-buffer product, with and without split-K."""
+    torch.manual_seed(93)
+    dev = env.device
+    cases = ([(6144, 4096, 4096, (4096, 1024, 1024)), (1536, 768, 16384, (768, 768))] if env.big else
+             [(768, 128, 320, (512, 256)), (1032, 136, 4096, (512, 256, 264))])
+    for (m, n, k, rows) in cases:
+        dy = torch.randn(k, m).bfloat16().to(dev)
+        x = torch.randn(k, n).bfloat16().to(dev)
+        whole = ops.raw_gemm(dy, x, a_km=True, b_kn=True)          # default dispatch (split-K where the policy picks it)
+        segs = [torch.full((r, n), 7.0, dtype=torch.bfloat16, device=dev) for r in rows]
+        torch.ops.tamd.gemm_dw_segments(dy, x, segs)
+        assert torch.equal(torch.cat(segs, 0), whole), (m, n, k, rows)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "tamd_gemm_workspace_bytes": (c_size_t, [I64, I64, I64, c_int, c_int]),
     "tamd_gemm_ws": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P, c_size_t,
                              P]),
+    "tamd_gemm_seg": (c_int, [P, P, P, P, c_int, I64, I64, I64, I64, I64, c_int, c_int, P, c_size_t, P]),
     "tamd_gemm_bias_act_pre": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, P]),
     "tamd_gemm_colscale": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, I64, c_float, c_int, P]),
     "tamd_gemm_swiglu": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),

@@ -108,7 +108,20 @@ struct GemmArgs {
   // columns of a q|k|v projection leave carrying the attention kernels' scale*log2(e) (tamd_attn_params.q_prescaled)
   int64_t scale_cols;
   float col_scale;
+  // segmented output (tamd_gemm_seg; dW layout, plain / accumulate): rows [0, seg_row1) of C live at C, [seg_row1, seg_row2) at
+  // C_seg1, [seg_row2, M) at C_seg2 (each with leading dimension ldc; seg_row* multiples of 256, 0 = no such segment) -- the
+  // gradient of a fused q|k|v / gate|up weight written straight into the member parameters' separate gradient buffers
+  void* C_seg1;
+  void* C_seg2;
+  int64_t seg_row1, seg_row2;
 };
+// the output base (as if row 0 were the matrix's first row) of the tile whose first row is m0
+template <typename T>
+__device__ __forceinline__ void* gemm_seg_base(const GemmArgs& g, int64_t m0) {
+  if (g.seg_row2 > 0 && m0 >= g.seg_row2) return reinterpret_cast<T*>(g.C_seg2) - g.seg_row2 * g.ldc;
+  if (g.seg_row1 > 0 && m0 >= g.seg_row1) return reinterpret_cast<T*>(g.C_seg1) - g.seg_row1 * g.ldc;
+  return g.C;
+}
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
 constexpr int kEpiRope = 103;
@@ -842,8 +855,14 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), m0 + wm * 128,
                             (n0 >> 1) + wn * 64, elane);
   } else {
-    gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
-        g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+    if (A_KM && B_KN && (EPI == TAMD_EPI_NONE || EPI == TAMD_EPI_ACCUM) && g.seg_row1 > 0) {  // (wave-uniform; dW only)
+      GemmArgs gs = g;
+      gs.C = gemm_seg_base<T>(g, m0);
+      gemm_epilogue16<T, EPI, ACT>(gs, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+    } else {
+      gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
+          g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+    }
   }
   TAMD_TIMELINE_END
 }
@@ -1141,7 +1160,8 @@ __global__ __launch_bounds__(kTwThreads, 2) void gemm_tw_kernel(GemmArgs g) {
 // accumulated onto it: 41 us against hipBLASLt's 19 for CLIP fc2, profiles/r04b_gemm_tw_ab.jsonl).
 template <typename T, int MODE>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, const T* __restrict__ bias,
-                                     const T* __restrict__ R, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int splits) {
+                                     const T* __restrict__ R, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int splits,
+                                     T* C_seg1 = nullptr, T* C_seg2 = nullptr, int64_t seg_row1 = 0, int64_t seg_row2 = 0) {
   typedef typename elem<T>::raw raw;
   const int64_t nvec = M * (N / 4);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nvec; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -1153,6 +1173,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict
       for (int e = 0; e < 4; ++e) a[e] += u32_as_f32(v[e]);
     }
     T* out = C + m * ldc + n;
+    if (seg_row2 > 0 && m >= seg_row2)  // (segmented output: tamd_gemm_seg)
+      out = C_seg2 + (m - seg_row2) * ldc + n;
+    else if (seg_row1 > 0 && m >= seg_row1)
+      out = C_seg1 + (m - seg_row1) * ldc + n;
     if ((MODE == TAMD_EPI_BIAS || MODE == TAMD_EPI_RESIDUAL) && bias != nullptr) {
       const u32x2 bq = ld8(bias + n);
       a[0] += elem<T>::to_f32((raw)(bq[0] & 0xffffu));
@@ -1269,7 +1293,8 @@ static int gemm_fl_splitk_launch2(const GemmArgs& g, int epilogue, hipStream_t s
   if (blocks > 4096) blocks = 4096;
 #define TAMD_RK(MODE_)                                                                                                   \
   hipLaunchKernelGGL((splitk_reduce_kernel<T, MODE_>), dim3((unsigned)blocks), dim3(256), 0, s, g.ws, (T*)g.C,          \
-                     (const T*)g.bias, (const T*)g.R, g.M, g.N, g.ldc, g.ldr, g.splits)
+                     (const T*)g.bias, (const T*)g.R, g.M, g.N, g.ldc, g.ldr, g.splits, (T*)g.C_seg1, (T*)g.C_seg2,     \
+                     g.seg_row1, g.seg_row2)
   switch (epilogue) {
     case TAMD_EPI_ACCUM: TAMD_RK(TAMD_EPI_ACCUM); break;
     case TAMD_EPI_BIAS: TAMD_RK(TAMD_EPI_BIAS); break;
@@ -1378,6 +1403,8 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->cos_batch = 1;
   g->scale_cols = 0;
   g->col_scale = 1.f;
+  g->C_seg1 = g->C_seg2 = nullptr;
+  g->seg_row1 = g->seg_row2 = 0;
   return TAMD_OK;
 }
 
@@ -1510,6 +1537,38 @@ extern "C" int tamd_gemm_ws(const void* A, const void* B, void* C, const void* b
   GemmArgs g;
   gemm_fill_args(&g, A, B, C, bias, R, M, N, K, lda, ldb, ldc, ldr);
   return gemm_run(g, flags, epilogue, act, dtype, workspace, workspace_bytes, stream);
+}
+
+// dW = dY^T . X of a FUSED projection (weight rows = [q | k | v] or [gate | up]) with every member's rows stored into its own
+// buffer: the members' gradients are separate tensors (DDP's bucket views; `.grad` of separate parameters), not slices of
+// one.  Both operands k-major; plain or accumulating epilogue; segments are whole 256-row tiles.
+extern "C" int tamd_gemm_seg(const void* A, const void* B, void* const* C_segs, const int64_t* seg_rows, int nseg, int64_t N,
+                             int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int epilogue, int dtype, void* workspace,
+                             size_t workspace_bytes, tamd_stream_t stream) {
+  if (!C_segs || !seg_rows) return TAMD_E_NULL;
+  if (nseg < 1 || nseg > 3 || (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM)) return TAMD_E_ARG;
+  int64_t M = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!C_segs[i]) return TAMD_E_NULL;
+    if (seg_rows[i] <= 0 || (i + 1 < nseg && seg_rows[i] % kBM != 0)) return TAMD_E_SHAPE;  // (the last may be ragged)
+    if (!aligned16(C_segs[i])) return TAMD_E_ALIGN;
+    M += seg_rows[i];
+  }
+  const int flags = TAMD_GEMM_A_KM | TAMD_GEMM_B_KN;
+  const int st = gemm_check(A, B, C_segs[0], nullptr, nullptr, M, N, K, lda, ldb, ldc, 0, flags, epilogue);
+  if (st != TAMD_OK) return st;
+  if (K % kXK != 0) return TAMD_E_SHAPE;  // (the full-line kernel and its split-K: the ping-pong kernel has no segments)
+  GemmArgs g;
+  gemm_fill_args(&g, A, B, C_segs[0], nullptr, nullptr, M, N, K, lda, ldb, ldc, 0);
+  if (nseg > 1) {
+    g.C_seg1 = C_segs[1];
+    g.seg_row1 = seg_rows[0];
+  }
+  if (nseg > 2) {
+    g.C_seg2 = C_segs[2];
+    g.seg_row2 = seg_rows[0] + seg_rows[1];
+  }
+  return gemm_run(g, flags | (workspace ? 0 : TAMD_GEMM_SCHED_FL), epilogue, TAMD_ACT_NONE, dtype, workspace, workspace_bytes, stream);
 }
 
 // BertIntermediate / CLIPMLP.fc1 / GPT2MLP.c_fc in train mode (models/bert/modeling_bert.py:334-337): the activation AND the

@@ -43,7 +43,7 @@ using OptTensor = std::optional<at::Tensor>;
   X(tamd_bert_embeddings_fwd) X(tamd_swiglu_fwd) X(tamd_swiglu_bwd) X(tamd_bias_act_fwd) X(tamd_bias_act_bwd)         \
   X(tamd_add) X(tamd_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
   X(tamd_cross_entropy_fwd) X(tamd_cross_entropy_bwd) X(tamd_gemm) X(tamd_gemm_workspace_bytes) X(tamd_gemm_ws)       \
-  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
+  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
   X(tamd_attn_decode_workspace_bytes) X(tamd_attn_decode)
 
 struct Api {
@@ -562,6 +562,48 @@ std::tuple<Tensor, Tensor> linear_act_pre(const Tensor& x2, const Tensor& w, con
   return {k_bias_act_fwd(pre, {}, act), pre};
 }
 
+// dW[M, N] = dy[K, M]^T . x[K, N] with the M rows stored into `segs` (each [rows_i, N] contiguous: tamd_gemm_seg) -- the weight
+// gradient of a fused q|k|v / gate|up projection written straight into the members' own gradient buffers
+void gemm_dw_segments(const Tensor& dy, const Tensor& x, const std::vector<Tensor>& segs) {
+  std::vector<const Tensor*> all = {&dy, &x};
+  for (const Tensor& t : segs) all.push_back(&t);
+  Launch L({&dy, &x, &segs[0]});
+  TORCH_CHECK(dy.dim() == 2 && x.dim() == 2 && dy.stride(1) == 1 && x.stride(1) == 1 && dy.size(0) == x.size(0),
+              "tamd: gemm_dw_segments takes dy [K, M] and x [K, N]");
+  const int64_t k = dy.size(0), m = dy.size(1), n = x.size(1);
+  void* ptrs[3];
+  int64_t rows[3];
+  int64_t total = 0;
+  TORCH_CHECK(segs.size() >= 1 && segs.size() <= 3, "tamd: 1..3 output segments");
+  for (size_t i = 0; i < segs.size(); ++i) {
+    const Tensor& t = segs[i];
+    TORCH_CHECK(t.dim() == 2 && t.size(1) == n && t.is_contiguous() && t.scalar_type() == dy.scalar_type() &&
+                    t.device() == dy.device(),
+                "tamd: an output segment must be a contiguous [rows, ", n, "] tensor of the operands' dtype and device");
+    ptrs[i] = t.mutable_data_ptr();
+    rows[i] = t.size(0);
+    total += rows[i];
+  }
+  TORCH_CHECK(total == m, "tamd: the segments hold ", total, " rows, the product has ", m);
+  bool tile_aligned = k % 64 == 0;
+  for (size_t i = 0; i + 1 < segs.size(); ++i) tile_aligned = tile_aligned && rows[i] % 256 == 0;
+  if (!tile_aligned) {  // segments that cut through a 256-row tile (small test models): one product, then the slices
+    Tensor whole = gemm_plain(dy, x, true, true);
+    int64_t off = 0;
+    for (size_t i = 0; i < segs.size(); ++i) {
+      const_cast<Tensor&>(segs[i]).copy_(whole.narrow(0, off, rows[i]));
+      off += rows[i];
+    }
+    return;
+  }
+  const size_t ws_bytes = api().tamd_gemm_workspace_bytes(m, n, k, 3, TAMD_EPI_NONE);
+  Tensor ws = ws_bytes ? at::empty({(int64_t)ws_bytes}, dy.options().dtype(at::kByte)) : Tensor();
+  GemmTimerScope timer(2.0 * (double)m * (double)n * (double)k, 2.0 * ((double)m * k + (double)n * k + (double)m * n), L.stream);
+  check(api().tamd_gemm_seg(ptr(dy), ptr(x), ptrs, rows, (int)segs.size(), n, k, dy.stride(0), x.stride(0), n, TAMD_EPI_NONE,
+                            code_of(dy), mptr(ws), ws_bytes, L.stream),
+        "tamd_gemm_seg");
+}
+
 bool half_type(const Tensor& t) { return t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf; }
 
 // shapes the fused gate|up GEMM + SiLU*up epilogue takes (csrc/gemm.hip tamd_gemm_swiglu)
@@ -786,6 +828,7 @@ std::tuple<Tensor, Tensor> op_bias_act_bwd(const Tensor& x, const OptTensor& bia
   auto [dx, dc] = k_bias_act_bwd(x, bias, dy, act, need_colsum);
   return {dx, dc.defined() ? dc : nothing(x)};
 }
+void op_gemm_dw_segments(const Tensor& dy, const Tensor& x, at::TensorList segs) { gemm_dw_segments(dy, x, segs.vec()); }
 std::tuple<Tensor, Tensor> op_gemm_bias_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
   return k_gemm_bias_act_pre(x2, w, bias, act);
 }
@@ -1108,7 +1151,11 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
     const OptTensor& q_start, const Tensor& w_ln1, const Tensor& wqkv, const Tensor& wo, const Tensor& w_ln2,
     const Tensor& wgu, const Tensor& wd, const Tensor& rstd1, const Tensor& xn, const Tensor& qkv, const Tensor& o,
     const Tensor& lse, const Tensor& h_mid, const Tensor& rstd2, const Tensor& xn2, const Tensor& gu, const Tensor& act_saved,
-    int64_t hq, int64_t hkv, int64_t d, double scale, bool causal) {
+    int64_t hq, int64_t hkv, int64_t d, double scale, bool causal, const OptTensor& dst_q, const OptTensor& dst_k,
+    const OptTensor& dst_v, const OptTensor& dst_o, const OptTensor& dst_g, const OptTensor& dst_u, const OptTensor& dst_d) {
+  // dst_*: the weight gradients' destinations (transformers_amd/ddp.py: DDP's bucket views) -- all seven or none.  With them
+  // the dW GEMMs store there and the corresponding outputs come back empty.
+  const bool to_dst = dst_q && dst_k && dst_v && dst_o && dst_g && dst_u && dst_d;
   const int64_t b = h_in.size(0), s = h_in.size(1), hd = h_in.size(2), t = b * s;
   Tensor x = contig(h_in).view({t, hd});
   Tensor dh = contig(d_hout).view({t, hd});
@@ -1122,16 +1169,25 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
     std::tie(d_gu, act) = k_swiglu_bwd(gu, d_act, true);
   }
   d_act = Tensor();
-  Tensor dwd = gemm_plain(dh, act, true, true);  // [hd, I]
+  Tensor dwd = to_dst ? (gemm_plain(dh, act, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_d), nothing(h_in))
+                      : gemm_plain(dh, act, true, true);  // [hd, I]
   act = Tensor();
   Tensor d_xn2 = gemm_plain(d_gu, wgu, false, true);  // [T, hd]
-  Tensor dwgu = gemm_plain(d_gu, xn2, true, true);    // [2I, hd]
+  Tensor dwgu;                                        // [2I, hd]
+  if (to_dst) {
+    gemm_dw_segments(d_gu, xn2, {*dst_g, *dst_u});
+    dwgu = nothing(h_in);
+  } else {
+    dwgu = gemm_plain(d_gu, xn2, true, true);
+  }
   d_gu = Tensor();
   auto [d_hmid, dw_ln2] = k_rmsnorm_bwd(d_xn2, h_mid, w_ln2, rstd2, dh);
   d_xn2 = Tensor();
   // ---- attention
   Tensor d_o = gemm_plain(d_hmid, wo, false, true);  // [T, Hq*D]
-  Tensor dwo = gemm_plain(d_hmid, o.view({t, hq * d}), true, true);
+  Tensor dwo = to_dst ? (gemm_plain(d_hmid, o.view({t, hq * d}), true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_o),
+                         nothing(h_in))
+                      : gemm_plain(d_hmid, o.view({t, hq * d}), true, true);
   Tensor d_qkv = at::empty_like(qkv);
   Qkv f = split_qkv(qkv, b, s, hq, hkv, d), g = split_qkv(d_qkv, b, s, hq, hkv, d);
   const bool fused_rope = kFuseRopeBwd && attn_bwd_rope_supported(f.q, f.k, cos, d);  // the transposed rotary inside the kernels
@@ -1140,7 +1196,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   d_o = Tensor();
   if (!fused_rope) k_rope_(d_qkv, cos, sin, s, hq + hkv, d, true);
   Tensor d_xn = gemm_plain(d_qkv, wqkv, false, true);
-  Tensor dwqkv = gemm_plain(d_qkv, xn, true, true);  // [(Hq+2Hkv)D, hd]
+  Tensor dwqkv;  // [(Hq+2Hkv)D, hd]
+  if (to_dst) {
+    gemm_dw_segments(d_qkv, xn, {*dst_q, *dst_k, *dst_v});
+    dwqkv = nothing(h_in);
+  } else {
+    dwqkv = gemm_plain(d_qkv, xn, true, true);
+  }
   auto [d_hin, dw_ln1] = k_rmsnorm_bwd(d_xn, x, w_ln1, rstd1, d_hmid);
   return {d_hin.view({b, s, hd}), dw_ln1, dwqkv, dwo, dw_ln2, dwgu, dwd};
 }
@@ -1279,6 +1341,7 @@ TORCH_LIBRARY(tamd, m) {
         "Tensor? residual=None, int epilogue=0, int act=0, int sched=0) -> ()");
   m.def("gemm_swiglu(Tensor x2, Tensor wgu, bool need_gu=True) -> (Tensor, Tensor)");
   m.def("gemm_bias_act_pre(Tensor x2, Tensor w, Tensor bias, int act) -> (Tensor, Tensor)");
+  m.def("gemm_dw_segments(Tensor dy, Tensor x, Tensor(a!)[] segs) -> ()");
   m.def("gemm_colscale(Tensor x2, Tensor w, Tensor? bias, int scale_cols, float col_scale) -> Tensor");
   m.def("gemm_rope(Tensor x2, Tensor wqkv, Tensor cos, Tensor sin, int seq, int rope_heads, int head_dim) -> Tensor");
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None, bool need_lse=True, "
@@ -1321,7 +1384,9 @@ TORCH_LIBRARY(tamd, m) {
   m.def("llama_layer_bwd(Tensor d_hout, Tensor h_in, Tensor cos, Tensor sin, Tensor? key_valid, Tensor? q_start, "
         "Tensor w_ln1, Tensor wqkv, Tensor wo, Tensor w_ln2, Tensor wgu, Tensor wd, Tensor rstd1, Tensor xn, Tensor qkv, "
         "Tensor o, Tensor lse, Tensor h_mid, Tensor rstd2, Tensor xn2, Tensor gu, Tensor act_saved, int hq, int hkv, int d, "
-        "float scale, bool causal) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+        "float scale, bool causal, Tensor(a!)? dst_q=None, Tensor(b!)? dst_k=None, Tensor(c!)? dst_v=None, "
+        "Tensor(d!)? dst_o=None, Tensor(e!)? dst_g=None, Tensor(f!)? dst_u=None, Tensor(g!)? dst_d=None) -> "
+        "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("bert_layer(Tensor h_in, Tensor? key_valid, Tensor wqkv, Tensor bqkv, Tensor wq, Tensor wk, Tensor wv, Tensor bq, "
         "Tensor bk, Tensor bv, Tensor wo, Tensor bo, Tensor ln1_w, Tensor ln1_b, Tensor wi, Tensor bi, Tensor wo2, "
         "Tensor bo2, Tensor ln2_w, Tensor ln2_b, float eps, int heads, int d, float scale, int act, float p_attn, "
@@ -1352,6 +1417,7 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("bias_act_fwd", &k_bias_act_fwd);                           \
   m.impl("bias_act_bwd", &op_bias_act_bwd);                          \
   m.impl("gemm_bias_act_pre", &op_gemm_bias_act_pre);                \
+  m.impl("gemm_dw_segments", &op_gemm_dw_segments);                  \
   m.impl("gemm_colscale", &op_gemm_colscale);                        \
   m.impl("add", &k_add);                                             \
   m.impl("colsum", &k_colsum);                                       \

@@ -14,7 +14,7 @@ import os
 
 import torch
 
-from . import ops
+from . import ddp, ops
 from .ops import register
 
 T = torch.ops.tamd
@@ -36,10 +36,11 @@ def _llama_layer_fake(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wq, wk, w
 
 
 def _llama_layer_bwd_fake(d_hout, h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv,
-                          o, lse, h_mid, rstd2, xn2, gu, act_saved, hq, hkv, d, scale, causal):
+                          o, lse, h_mid, rstd2, xn2, gu, act_saved, hq, hkv, d, scale, causal, dst_q=None, dst_k=None,
+                          dst_v=None, dst_o=None, dst_g=None, dst_u=None, dst_d=None):
+    e = (lambda w: h_in.new_empty(0)) if dst_q is not None else torch.empty_like  # (with destinations: written there)
     return (torch.empty_like(h_in, memory_format=torch.contiguous_format), torch.empty_like(w_ln1),
-            torch.empty_like(wqkv), torch.empty_like(wo), torch.empty_like(w_ln2), torch.empty_like(wgu),
-            torch.empty_like(wd))
+            e(wqkv), e(wo), torch.empty_like(w_ln2), e(wgu), e(wd))
 
 
 def _llama_layer_setup(ctx, inputs, output):
@@ -49,6 +50,7 @@ def _llama_layer_setup(ctx, inputs, output):
     ctx.save_for_backward(h_in, cos, sin, key_valid, q_start, w_ln1, wqkv, wo, w_ln2, wgu, wd, rstd1, xn, qkv, o, lse,
                           h_mid, rstd2, xn2, gu, act)
     ctx.meta = (hq, hkv, d, scale, causal, train)
+    ctx.weights = (_wq, _wk, _wv, wo, _wg, _wu, wd)  # the parameters themselves: ddp.destinations looks their bucket views up
     ctx.set_materialize_grads(False)
 
 
@@ -59,6 +61,12 @@ def _llama_layer_backward(ctx, d_hout, *_aux):
     hq, hkv, d, scale, causal, train = ctx.meta
     if not train:
         raise ops.TamdError("llama_layer was run with train=False but is being differentiated")
+    # under DistributedDataParallel with ddp.enable_zero_copy: the dW GEMMs write straight into the all-reduce buckets
+    dst = ddp.destinations(ctx.weights) if ddp._VIEWS else None
+    if dst is not None:
+        d_hin, dw_ln1, _, _, dw_ln2, _, _ = T.llama_layer_bwd(d_hout, *ctx.saved_tensors, hq, hkv, d, scale, causal, *dst)
+        gq, gk, gv, go, gg, gu_, gd = (t.detach() for t in dst)  # fresh aliases: AccumulateGrad adopts them without a copy
+        return (d_hin, None, None, None, None, dw_ln1, None, gq, gk, gv, go, dw_ln2, None, gg, gu_, gd) + none[16:]
     d_hin, dw_ln1, dwqkv, dwo, dw_ln2, dwgu, dwd = T.llama_layer_bwd(d_hout, *ctx.saved_tensors, hq, hkv, d, scale,
                                                                       causal)
     nq, nk = hq * d, hkv * d
