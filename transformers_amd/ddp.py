@@ -23,6 +23,7 @@ these takes the ordinary path.  `tests/test_ddp_gloo.py` checks reduced = mean o
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional, Sequence
 
@@ -32,6 +33,7 @@ import torch.distributed as dist
 # id(parameter) -> (weak reference to the parameter, its gradient view inside the current bucket)
 _VIEWS: dict = {}
 STATS = {"zero_copy_layers": 0, "ordinary_layers": 0}
+_WORLD1_COLLECTIVE = os.environ.get("TAMD_DDP_WORLD1_COLLECTIVE", "0") == "1"  # A/B switch of the world-size-1 shortcut below
 
 
 class _HookState:
@@ -53,6 +55,12 @@ def _allreduce_hook(state: _HookState, bucket):
     buf = bucket.buffer()
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
+    if world == 1 and not _WORLD1_COLLECTIVE:
+        # nothing to exchange.  (RCCL would still run its AVG kernel over the whole bucket -- unlike an in-place SUM it is not
+        # a no-op for one rank -- beside the backward: +50 ms on the Llama-3-8B step, profiles/r04f_ddp_ab.jsonl.)
+        fut = torch.futures.Future()
+        fut.set_result(buf)
+        return fut
     if backend == "nccl":  # RCCL: the average is part of the collective
         fut = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=True).get_future()
         return fut.then(lambda f: f.value()[0])

@@ -134,7 +134,7 @@ class TamdCLIPVisionEmbeddings(ref.CLIPVisionEmbeddings):
         patches = pixel_values.new_zeros((b * gh * gw, wp.shape[1]), dtype=w.dtype)
         # [B, C, gh, p, gw, p] -> [B, gh, gw, C, p, p]: one copy (with the dtype cast of `pixel_values.to(target_dtype)`)
         patches[:, :k].view(b, gh, gw, c, p, p).copy_(pixel_values.view(b, c, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5))
-        patch_embeds = ops.raw_gemm(patches, wp).view(b, gh * gw, w.shape[0])  # = conv(...).flatten(2).transpose(1, 2)
+        patch_embeds = ops.linear(patches, wp).view(b, gh * gw, w.shape[0])  # = conv(...).flatten(2).transpose(1, 2)
         class_embeds = self.class_embedding.expand(b, 1, -1)
         embeddings = torch.cat([class_embeds, patch_embeds], dim=1)
         if interpolate_pos_encoding:
