@@ -259,6 +259,26 @@ int tamd_gemm_seg(const void* A, const void* B, void* const* C_segs, const int64
                   int64_t lda, int64_t ldb, int64_t ldc, int epilogue, int dtype, void* workspace, size_t workspace_bytes,
                   tamd_stream_t stream);
 
+/* ABI 8.  Up to 4 independent products of ONE layout in a single launch (+ one reduction launch when K is split):
+ *   C_p = A_p . B_p   (TAMD_EPI_NONE)    or    C_p += A_p . B_p   (TAMD_EPI_ACCUM),      K_p % 64 == 0
+ * `flags`: TAMD_GEMM_A_KM | TAMD_GEMM_B_KN (A_p = [K, M], B_p = [K, N]: the weight gradients dW = dY^T . X of the dense layers of
+ * one transformer layer's backward -- what autograd computes one `mm` at a time for BertSelfAttention.query/key/value,
+ * BertSelfOutput.dense, BertIntermediate.dense and BertOutput.dense, models/bert/modeling_bert.py:131-133, 288, 333, 347) or 0
+ * (row-major A [M, K] and B [N, K]).  Such gradients are 9 .. 36 output tiles each over 16384 tokens: alone each one has to split
+ * K 7 .. 16 ways to reach the GPU's 256 CUs; together two splits do.  Every product is split into equal K ranges of one common
+ * length chosen so that the whole group is one round of workgroups; the fp32 partial tiles go to `workspace`
+ * (tamd_gemm_group_workspace_bytes; smaller or NULL: no K split). */
+typedef struct tamd_gemm_problem {
+  const void* a;
+  const void* b;
+  void* c;
+  int64_t m, n, k;
+  int64_t lda, ldb, ldc;
+} tamd_gemm_problem;
+size_t tamd_gemm_group_workspace_bytes(const tamd_gemm_problem* problems, int count, int flags);
+int tamd_gemm_group(const tamd_gemm_problem* problems, int count, int flags, int epilogue, int dtype, void* workspace,
+                    size_t workspace_bytes, tamd_stream_t stream);
+
 /* ABI 8.  BertIntermediate / CLIPMLP.fc1 in train mode (models/bert/modeling_bert.py:334-337, models/clip/modeling_clip.py:
  * 346-350): the activation AND the rounded pre-activation its backward needs, from ONE GEMM:
  *   PRE[M,N] = round(A . B^T + bias)      Y[M,N] = round(act(PRE))

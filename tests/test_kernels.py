@@ -1128,6 +1128,69 @@ def test_dropout_seed_from_device_memory_is_the_same_mask(env):
     assert all(torch.equal(a, c) for a, c in zip(b1, b2))
 
 
+def test_gemm_group_weight_gradients(env):
+    """tamd_gemm_group (ABI 8): the weight gradients of one layer's dense layers in ONE launch.  Groups that fit one round
+    of workgroups are split along K with one common range length (fp32 partials + one grouped reduction): the single
+    product's result up to fp32 summation order; groups too large to split: its bits.  Plain and accumulating, through the
+    C ABI and through torch.ops.tamd.gemm_dw_group."""
+    import ctypes
+
+    from transformers_amd import _cabi
+
+    torch.manual_seed(97)
+    dev = env.device
+    lib = ops.backend().lib
+    if env.big:   # bert-base layer (9 + 36 + 36 + 27 tiles over 16384 tokens); a ragged pair; Llama-sized (no split: same bits)
+        groups = [[(768, 768, 16384), (3072, 768, 16384), (768, 3072, 16384), (2304, 768, 16384)],
+                  [(264, 520, 4096), (1000, 136, 8192)], [(4096, 4096, 2048), (1024, 4096, 2048)]]
+    else:
+        groups = [[(256, 128, 2048), (264, 136, 1088), (128, 520, 2048)], [(256, 256, 1024)], [(2560, 2560, 128), (256, 2816, 64)]]
+    for gi, group in enumerate(groups):
+        dys = [torch.randn(k, m).bfloat16().to(dev) for (m, n, k) in group]
+        xs = [(torch.randn(k, n) * 0.1).bfloat16().to(dev) for (m, n, k) in group]
+        single = [ops.raw_gemm(a, b, a_km=True, b_kn=True, sched="fl") for a, b in zip(dys, xs)]  # unsplit, one by one
+        outs = torch.ops.tamd.gemm_dw_group(dys, xs)
+        pr = (_cabi.GemmProblem * len(group))()
+        acc = [torch.randn(m, n).bfloat16().to(dev) for (m, n, k) in group]
+        acc0 = [a.clone() for a in acc]
+        for i, (m, n, k) in enumerate(group):
+            pr[i] = _cabi.GemmProblem(dys[i].data_ptr(), xs[i].data_ptr(), acc[i].data_ptr(), m, n, k, m, n, n)
+        need = lib.tamd_gemm_group_workspace_bytes(ctypes.byref(pr), len(group), 3)
+        tiles = sum(-(-m // 256) * -(-n // 256) for (m, n, k) in group)
+        assert (need > 0) == (tiles <= 256 and max(k for (_, _, k) in group) // 64 > 16), (group, need)
+        for i, (m, n, k) in enumerate(group):
+            ref = dys[i].float().t() @ xs[i].float()
+            assert rel_err(outs[i], ref) < 0.0034, (group, i)
+            if need == 0:
+                assert torch.equal(outs[i], single[i]), (group, i)
+            else:
+                assert rel_err(outs[i], single[i]) < 0.00015 and (outs[i] != single[i]).float().mean() < 0.2, (group, i)
+        # accumulate, through the C ABI, with and without the workspace (none: unsplit, the single accumulating product's bits)
+        for with_ws in (True, False):
+            for a, a0 in zip(acc, acc0):
+                a.copy_(a0)
+            ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+            sh = ops.backend().stream(ws)
+            st = lib.tamd_gemm_group(ctypes.byref(pr), len(group), 3, ops.EPI_ACCUM, _cabi.TAMD_BF16,
+                                     ws.data_ptr() if with_ws else None, need if with_ws else 0,
+                                     ctypes.c_void_p(sh) if sh else None)
+            assert st == 0, (group, st)
+            for i, (m, n, k) in enumerate(group):
+                want = acc0[i].clone()
+                ops.raw_gemm(dys[i], xs[i], a_km=True, b_kn=True, epilogue=ops.EPI_ACCUM, out=want, sched="fl")
+                if with_ws and need > 0:
+                    assert rel_err(acc[i], want) < 0.00015, (group, i)
+                else:
+                    assert torch.equal(acc[i], want), (group, i)
+    # argument checks: more than 4 products, mixed layouts, K % 64
+    pr = (_cabi.GemmProblem * 1)()
+    a = torch.randn(96, 64).bfloat16().to(dev)
+    pr[0] = _cabi.GemmProblem(a.data_ptr(), a.data_ptr(), a.data_ptr(), 64, 64, 96, 64, 64, 64)
+    assert lib.tamd_gemm_group(ctypes.byref(pr), 1, 3, ops.EPI_NONE, _cabi.TAMD_BF16, None, 0, None) != 0   # K % 64
+    assert lib.tamd_gemm_group(ctypes.byref(pr), 5, 3, ops.EPI_NONE, _cabi.TAMD_BF16, None, 0, None) != 0
+    assert lib.tamd_gemm_group(ctypes.byref(pr), 1, 1, ops.EPI_NONE, _cabi.TAMD_BF16, None, 0, None) != 0   # A_KM only
+
+
 def test_gemm_segmented_weight_gradient(env):
     """tamd_gemm_seg (ABI 8): dW = dY^T . X of a fused q|k|v / gate|up projection with each member's rows stored into its own
     buffer -- the bits of the one-buffer product, with and without split-K."""

@@ -34,6 +34,12 @@ class AttnParams(Structure):
     ]
 
 
+class GemmProblem(Structure):
+    """tamd_gemm_problem (include/tamd.h): one product of a grouped launch."""
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("c", c_void_p), ("m", c_int64), ("n", c_int64), ("k", c_int64),
+                ("lda", c_int64), ("ldb", c_int64), ("ldc", c_int64)]
+
+
 class AttnBwdParams(Structure):
     _fields_ = [("fwd", AttnParams), ("dout", P), ("dq", P), ("dk", P), ("dv", P), ("delta", P), ("rope_cos", P),
                 ("rope_sin", P), ("rope_cos_batch", I64)]
@@ -74,6 +80,8 @@ SIGNATURES = {
     "tamd_gemm_ws": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, c_int, P, c_size_t,
                              P]),
     "tamd_gemm_seg": (c_int, [P, P, P, P, c_int, I64, I64, I64, I64, I64, c_int, c_int, P, c_size_t, P]),
+    "tamd_gemm_group_workspace_bytes": (c_size_t, [P, c_int, c_int]),
+    "tamd_gemm_group": (c_int, [P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "tamd_gemm_bias_act_pre": (c_int, [P, P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, c_int, c_int, P]),
     "tamd_gemm_colscale": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, I64, c_float, c_int, P]),
     "tamd_gemm_swiglu": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),

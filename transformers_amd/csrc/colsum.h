@@ -11,11 +11,19 @@ constexpr int kNormMaxPartials = 512;  // partial rows a first stage may produce
 // sums P/64 rows with 16-byte loads, the row groups are combined through LDS in a fixed order (deterministic).
 // (The first version walked all P rows on one thread per column: 16 workgroups and a 512-deep serial chain, 120-140 us
 // per call -- a third of the bert-base step and 9 ms of the Llama-3-8B one, profiles/r02_bert_kernel_stats_before.csv.)
+// Up to 3 such reductions of one shape in ONE launch (blockIdx.y = plane): a LayerNorm backward produces dw, db and the
+// neighbouring dense layer's bias gradient at once, and three 5 us launches per call were 0.5 ms of a 20 ms bert-base step
+// (816 launches in 8 steps, profiles/r04c_bert_kernel_stats.csv).
 constexpr int kColsumCols = 16, kColsumGroups = 64;
+struct ColsumPlanes {
+  const float* part[3];
+  void* out[3];
+};
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ part, T* __restrict__ out, int P,
-                                                         int cols) {
+__global__ __launch_bounds__(256) void colsum_f32_kernel(ColsumPlanes pl, int P, int cols) {
   __shared__ float sm[kColsumGroups][kColsumCols + 1];
+  const float* __restrict__ part = pl.part[blockIdx.y];
+  T* __restrict__ out = reinterpret_cast<T*>(pl.out[blockIdx.y]);
   const int cq = threadIdx.x & 3, rg = threadIdx.x >> 2;
   const int col = blockIdx.x * kColsumCols + cq * 4;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -44,10 +52,25 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
   }
 }
 
+// planes with a null `out` are skipped
+template <typename T>
+static inline void colsum_partials_reduce3(const float* p0, void* o0, const float* p1, void* o1, const float* p2, void* o2,
+                                           int P, int cols, hipStream_t s) {
+  ColsumPlanes pl;
+  int n = 0;
+  const float* ps[3] = {p0, p1, p2};
+  void* os[3] = {o0, o1, o2};
+  for (int i = 0; i < 3; ++i) {
+    pl.part[i] = nullptr, pl.out[i] = nullptr;
+    if (os[i] != nullptr && ps[i] != nullptr) pl.part[n] = ps[i], pl.out[n] = os[i], ++n;
+  }
+  if (n == 0) return;
+  dim3 g2((unsigned)ceil_div(cols, kColsumCols), (unsigned)n), b2(256);
+  hipLaunchKernelGGL((colsum_f32_kernel<T>), g2, b2, 0, s, pl, P, cols);
+}
 template <typename T>
 static inline void colsum_partials_reduce(const float* part, void* out, int P, int cols, hipStream_t s) {
-  dim3 g2((unsigned)ceil_div(cols, kColsumCols)), b2(256);
-  hipLaunchKernelGGL((colsum_f32_kernel<T>), g2, b2, 0, s, part, (T*)out, P, cols);
+  colsum_partials_reduce3<T>(part, out, nullptr, nullptr, nullptr, nullptr, P, cols, s);
 }
 
 }  // namespace tamd

@@ -35,6 +35,7 @@
 //                   in a 4-stage ring: any K (ragged token counts in dW, odd hidden sizes)
 //   gemm_sm_kernel  128 x 128 tile, 4 waves x (64 x 64) on v_mfma_f32_32x32x16, two workgroups per CU: forward products whose
 //                   256 x 256 grid cannot spread over the GPU (a CLIP tower's 577 tokens)
+#include <limits.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -639,14 +640,15 @@ __device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
 // fabric traffic to the patch floor (11.2 GB), and bought nothing: 1492 vs 1498 TFLOP/s with aligned rounds, -22 % with the
 // hand-shakes.  The L2 misses of the long-K products are not what bounds them.  profiles/r03b_gemm_persist_ab.jsonl,
 // r03b_gemm_persist_pmc.txt; the code: profiles/r03b_gemm_persist.patch.)
-template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
-__global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
+// (the kernel body: `vbid` = the workgroup's index inside ITS product -- blockIdx.x for gemm_fl_kernel, the index behind the
+// product's first workgroup for gemm_fl_group_kernel)
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG>
+__device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) {
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
   const int wm = wave >> 1, wn = wave & 1;
   const int g4 = lane >> 4, l15 = lane & 15;
-  const int vbid = (int)blockIdx.x;
   TAMD_TIMELINE_BEGIN
   TAMD_CLOCK_BEGIN
   int tile_m, tile_n;
@@ -855,16 +857,43 @@ __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
     gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), m0 + wm * 128,
                             (n0 >> 1) + wn * 64, elane);
   } else {
-    if (A_KM && B_KN && (EPI == TAMD_EPI_NONE || EPI == TAMD_EPI_ACCUM) && g.seg_row1 > 0) {  // (wave-uniform; dW only)
-      GemmArgs gs = g;
+    constexpr int E2 = (EPI == kEpiSplitK || EPI == kEpiSwiGLU) ? TAMD_EPI_NONE : EPI;  // (kEpiRope: in the way out)
+    if (A_KM && B_KN && (EPI == TAMD_EPI_NONE || EPI == TAMD_EPI_ACCUM)) {  // dW: the tile's segment (wave-uniform selects;
+      GemmArgs gs = g;                                                        // ONE epilogue instance: a second one spills)
       gs.C = gemm_seg_base<T>(g, m0);
-      gemm_epilogue16<T, EPI, ACT>(gs, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+      gemm_epilogue16<T, E2, ACT>(gs, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
     } else {
-      gemm_epilogue16<T, (EPI == kEpiSplitK || EPI == kEpiSwiGLU ? TAMD_EPI_NONE : EPI), ACT>(  // (kEpiRope: in the way out)
-          g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+      gemm_epilogue16<T, E2, ACT>(g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
     }
   }
   TAMD_TIMELINE_END
+}
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
+__global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
+  gemm_fl_body<T, A_KM, B_KN, EPI, ACT, DBG>(g, (int)blockIdx.x);
+}
+
+// ============================================================================================ grouped launch
+// Several independent products of ONE layout in a single launch (tamd_gemm_group): the four weight gradients of a BERT layer
+// (dW = dY^T . X, outputs of 768 .. 3072 rows and columns over 16384 tokens) are 9 .. 36 tiles each -- launched one by one
+// every one of them splits K 7 .. 16 ways to reach the 256 CUs, 16 .. 37 stages per workgroup behind a prologue and in front
+// of a 256 KiB fp32 partial tile (256 MB of partials per layer, 335 us for 232 GFLOP: profiles/r04c_bert_kernel_stats.csv).
+// Together they are 108 tiles: two splits fill the GPU with 128-stage workgroups and a quarter of the partial traffic.
+constexpr int kGroupMax = 4;
+struct GemmGroupArgs {
+  GemmArgs p[kGroupMax];
+  int start[kGroupMax];   // first workgroup of problem i (unused problems: INT_MAX).  Direct launches pad every problem to a
+  int blocks[kGroupMax];  // multiple of 8 workgroups (blockIdx & 7 stays the XCD for gemm_tile_of_block); the rest exit
+};
+template <typename T, bool A_KM, bool B_KN, int EPI>
+__global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_group_kernel(GemmGroupArgs grp) {
+  const int bid = (int)blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < kGroupMax; ++j) i = (bid >= grp.start[j]) ? j : i;
+  const int local = bid - grp.start[i];
+  if (local >= grp.blocks[i]) return;
+  gemm_fl_body<T, A_KM, B_KN, EPI, TAMD_ACT_NONE, 0>(grp.p[i], local);  // (wave-uniform index into the kernel arguments)
 }
 
 // ============================================================================================ small tile
@@ -1158,40 +1187,72 @@ __global__ __launch_bounds__(kTwThreads, 2) void gemm_tw_kernel(GemmArgs g) {
 // bias / residual product on a grid that cannot fill the GPU (CLIP fc2: 12 tiles over K = 4096; o_proj / down_proj of a
 // short prompt) splits like a plain one (round 3 sent those to the 128 x 128 kernel, or copied the residual into C first and
 // accumulated onto it: 41 us against hipBLASLt's 19 for CLIP fc2, profiles/r04b_gemm_tw_ab.jsonl).
+// one 4-column vector (row m, columns n..n+3) of the reduction
+template <typename T, int MODE>
+__device__ __forceinline__ void splitk_reduce_vec(const float* __restrict__ ws, T* __restrict__ out, const T* __restrict__ bias,
+                                                  const T* __restrict__ res, int64_t M, int64_t N, int64_t m, int64_t n,
+                                                  int splits) {
+  typedef typename elem<T>::raw raw;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int sidx = 0; sidx < splits; ++sidx) {
+    const u32x4 v = ld16(ws + ((int64_t)sidx * M + m) * N + n);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += u32_as_f32(v[e]);
+  }
+  if ((MODE == TAMD_EPI_BIAS || MODE == TAMD_EPI_RESIDUAL) && bias != nullptr) {
+    const u32x2 bq = ld8(bias + n);
+    a[0] += elem<T>::to_f32((raw)(bq[0] & 0xffffu));
+    a[1] += elem<T>::to_f32((raw)(bq[0] >> 16));
+    a[2] += elem<T>::to_f32((raw)(bq[1] & 0xffffu));
+    a[3] += elem<T>::to_f32((raw)(bq[1] >> 16));
+  }
+  if (MODE == TAMD_EPI_ACCUM || MODE == TAMD_EPI_RESIDUAL) {
+    const u32x2 o = ld8(MODE == TAMD_EPI_ACCUM ? (const T*)out : res);
+    a[0] = round_through<T>(a[0]) + elem<T>::to_f32((raw)(o[0] & 0xffffu));
+    a[1] = round_through<T>(a[1]) + elem<T>::to_f32((raw)(o[0] >> 16));
+    a[2] = round_through<T>(a[2]) + elem<T>::to_f32((raw)(o[1] & 0xffffu));
+    a[3] = round_through<T>(a[3]) + elem<T>::to_f32((raw)(o[1] >> 16));
+  }
+  st8(out, u32x2{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3])});
+}
 template <typename T, int MODE>
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, T* __restrict__ C, const T* __restrict__ bias,
                                      const T* __restrict__ R, int64_t M, int64_t N, int64_t ldc, int64_t ldr, int splits,
                                      T* C_seg1 = nullptr, T* C_seg2 = nullptr, int64_t seg_row1 = 0, int64_t seg_row2 = 0) {
-  typedef typename elem<T>::raw raw;
   const int64_t nvec = M * (N / 4);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < nvec; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = idx / (N / 4), n = (idx % (N / 4)) * 4;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int sidx = 0; sidx < splits; ++sidx) {
-      const u32x4 v = ld16(ws + ((int64_t)sidx * M + m) * N + n);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a[e] += u32_as_f32(v[e]);
-    }
     T* out = C + m * ldc + n;
     if (seg_row2 > 0 && m >= seg_row2)  // (segmented output: tamd_gemm_seg)
       out = C_seg2 + (m - seg_row2) * ldc + n;
     else if (seg_row1 > 0 && m >= seg_row1)
       out = C_seg1 + (m - seg_row1) * ldc + n;
-    if ((MODE == TAMD_EPI_BIAS || MODE == TAMD_EPI_RESIDUAL) && bias != nullptr) {
-      const u32x2 bq = ld8(bias + n);
-      a[0] += elem<T>::to_f32((raw)(bq[0] & 0xffffu));
-      a[1] += elem<T>::to_f32((raw)(bq[0] >> 16));
-      a[2] += elem<T>::to_f32((raw)(bq[1] & 0xffffu));
-      a[3] += elem<T>::to_f32((raw)(bq[1] >> 16));
-    }
-    if (MODE == TAMD_EPI_ACCUM || MODE == TAMD_EPI_RESIDUAL) {
-      const u32x2 o = ld8(MODE == TAMD_EPI_ACCUM ? (const T*)out : R + m * ldr + n);
-      a[0] = round_through<T>(a[0]) + elem<T>::to_f32((raw)(o[0] & 0xffffu));
-      a[1] = round_through<T>(a[1]) + elem<T>::to_f32((raw)(o[0] >> 16));
-      a[2] = round_through<T>(a[2]) + elem<T>::to_f32((raw)(o[1] & 0xffffu));
-      a[3] = round_through<T>(a[3]) + elem<T>::to_f32((raw)(o[1] >> 16));
-    }
-    st8(out, u32x2{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3])});
+    splitk_reduce_vec<T, MODE>(ws, out, bias, R + m * ldr + n, M, N, m, n, splits);
+  }
+}
+// the reductions of a grouped launch (tamd_gemm_group) in one: plain or accumulating
+struct ReduceGroupArgs {
+  const float* ws[kGroupMax];
+  void* C[kGroupMax];
+  int64_t M[kGroupMax], N[kGroupMax], ldc[kGroupMax];
+  int splits[kGroupMax];
+  int start[kGroupMax];   // first block of problem i (unused: INT_MAX)
+  int blocks[kGroupMax];
+};
+template <typename T, int MODE>
+__global__ void splitk_reduce_group_kernel(ReduceGroupArgs r) {
+  const int bid = (int)blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < kGroupMax; ++j) i = (bid >= r.start[j]) ? j : i;
+  const int64_t M = r.M[i], N = r.N[i], ldc = r.ldc[i];
+  const float* ws = r.ws[i];
+  T* C = reinterpret_cast<T*>(r.C[i]);
+  const int splits = r.splits[i];
+  const int64_t nvec = M * (N / 4), stride = (int64_t)r.blocks[i] * blockDim.x;
+  for (int64_t idx = (int64_t)(bid - r.start[i]) * blockDim.x + threadIdx.x; idx < nvec; idx += stride) {
+    const int64_t m = idx / (N / 4), n = (idx % (N / 4)) * 4;
+    splitk_reduce_vec<T, MODE>(ws, C + m * ldc + n, nullptr, nullptr, M, N, m, n, splits);
   }
 }
 
@@ -1569,6 +1630,141 @@ extern "C" int tamd_gemm_seg(const void* A, const void* B, void* const* C_segs, 
     g.seg_row2 = seg_rows[0] + seg_rows[1];
   }
   return gemm_run(g, flags | (workspace ? 0 : TAMD_GEMM_SCHED_FL), epilogue, TAMD_ACT_NONE, dtype, workspace, workspace_bytes, stream);
+}
+
+// ---- grouped launch (kernels: gemm_fl_group_kernel, splitk_reduce_group_kernel)
+// The plan: one stage count L per workgroup for every product -- the smallest L (>= 16 stages) with
+// sum_p tiles_p * ceil(stages_p / L) <= 256 workgroups: one dispatch round, equal K ranges.  Products too many for one round
+// (more than 256 tiles) run unsplit.  `allow_split` false (no workspace): unsplit as well.
+struct GroupPlan {
+  int splits[kGroupMax], sps[kGroupMax];
+  size_t ws_floats[kGroupMax];  // partial planes of product p
+  bool any_split;
+};
+static int gemm_group_plan(const tamd_gemm_problem* pr, int count, int flags, bool allow_split, GroupPlan* plan) {
+  if (!pr) return TAMD_E_NULL;
+  if (count < 1 || count > kGroupMax) return TAMD_E_ARG;
+  int64_t nst[kGroupMax], tiles[kGroupMax], max_nst = 0, sum_tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    const tamd_gemm_problem& q = pr[i];
+    const int st = gemm_check(q.a, q.b, q.c, nullptr, nullptr, q.m, q.n, q.k, q.lda, q.ldb, q.ldc, 0, flags, TAMD_EPI_NONE);
+    if (st != TAMD_OK) return st;
+    if (q.k % kXK != 0) return TAMD_E_SHAPE;  // (the full-line kernel)
+    nst[i] = q.k / kXK;
+    tiles[i] = ceil_div(q.m, kBM) * ceil_div(q.n, kBN);
+    if (nst[i] > max_nst) max_nst = nst[i];
+    sum_tiles += tiles[i];
+  }
+  int64_t L = max_nst;
+  if (allow_split && sum_tiles <= 256) {
+    for (int64_t c = 16; c < max_nst; ++c) {
+      int64_t wgs = 0;
+      for (int i = 0; i < count; ++i) wgs += tiles[i] * ceil_div(nst[i], c);
+      if (wgs <= 256) {
+        L = c;
+        break;
+      }
+    }
+  }
+  plan->any_split = false;
+  for (int i = 0; i < count; ++i) {
+    const int64_t s0 = ceil_div(nst[i], L), sps = ceil_div(nst[i], s0);
+    plan->sps[i] = (int)sps;
+    plan->splits[i] = (int)ceil_div(nst[i], sps);  // no empty split
+    plan->any_split = plan->any_split || plan->splits[i] > 1;
+  }
+  for (int i = 0; i < count; ++i)
+    plan->ws_floats[i] = plan->any_split ? (size_t)plan->splits[i] * (size_t)pr[i].m * (size_t)pr[i].n : 0;
+  return TAMD_OK;
+}
+
+extern "C" size_t tamd_gemm_group_workspace_bytes(const tamd_gemm_problem* problems, int count, int flags) {
+  GroupPlan plan;
+  if (gemm_group_plan(problems, count, flags & 0xff, true, &plan) != TAMD_OK) return 0;
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) total += plan.ws_floats[i];
+  return total * sizeof(float);
+}
+
+template <typename T, bool A_KM, bool B_KN>
+static int gemm_group_launch(const tamd_gemm_problem* pr, int count, const GroupPlan& plan, int epilogue, float* ws,
+                             hipStream_t s) {
+  GemmGroupArgs grp;
+  ReduceGroupArgs red;
+  int next = 0, rnext = 0;
+  for (int i = 0; i < kGroupMax; ++i) {
+    grp.start[i] = red.start[i] = INT_MAX;
+    grp.blocks[i] = red.blocks[i] = 0;
+    if (i >= count) {
+      grp.p[i] = grp.p[0];
+      red.ws[i] = nullptr, red.C[i] = nullptr, red.M[i] = red.N[i] = red.ldc[i] = 0, red.splits[i] = 0;
+      continue;
+    }
+    const tamd_gemm_problem& q = pr[i];
+    GemmArgs& g = grp.p[i];
+    gemm_fill_args(&g, q.a, q.b, q.c, nullptr, nullptr, q.m, q.n, q.k, q.lda, q.ldb, q.ldc, 0);
+    grp.start[i] = next;
+    if (plan.any_split) {
+      g.ws = ws;
+      g.splits = plan.splits[i];
+      g.stages_per_split = plan.sps[i];
+      grp.blocks[i] = g.tiles_m * g.tiles_n * g.splits;
+      next += grp.blocks[i];
+      const int64_t nvec = q.m * (q.n / 4);
+      int64_t blocks = ceil_div(nvec, 256);
+      if (blocks > 1024) blocks = 1024;
+      red.ws[i] = ws, red.C[i] = q.c, red.M[i] = q.m, red.N[i] = q.n, red.ldc[i] = q.ldc, red.splits[i] = g.splits;
+      red.start[i] = rnext, red.blocks[i] = (int)blocks;
+      rnext += (int)blocks;
+      ws += plan.ws_floats[i];
+    } else {
+      grp.blocks[i] = g.tiles_m * g.tiles_n;
+      next += (grp.blocks[i] + 7) & ~7;  // (blockIdx & 7 stays the XCD of the product's own workgroup index)
+    }
+  }
+  dim3 grid((unsigned)next), block(kFlThreads);
+  if (plan.any_split) {
+    hipLaunchKernelGGL((gemm_fl_group_kernel<T, A_KM, B_KN, kEpiSplitK>), grid, block, (size_t)kXSmem, s, grp);
+    if (epilogue == TAMD_EPI_ACCUM)
+      hipLaunchKernelGGL((splitk_reduce_group_kernel<T, TAMD_EPI_ACCUM>), dim3((unsigned)rnext), dim3(256), 0, s, red);
+    else
+      hipLaunchKernelGGL((splitk_reduce_group_kernel<T, TAMD_EPI_NONE>), dim3((unsigned)rnext), dim3(256), 0, s, red);
+  } else if (epilogue == TAMD_EPI_ACCUM) {
+    hipLaunchKernelGGL((gemm_fl_group_kernel<T, A_KM, B_KN, TAMD_EPI_ACCUM>), grid, block, (size_t)kXSmem, s, grp);
+  } else {
+    hipLaunchKernelGGL((gemm_fl_group_kernel<T, A_KM, B_KN, TAMD_EPI_NONE>), grid, block, (size_t)kXSmem, s, grp);
+  }
+  return launch_status();
+}
+
+// Up to 4 independent products of one layout in ONE launch (+ one reduction launch when K is split):
+//   C_p = A_p . B_p (plain) or C_p += A_p . B_p (TAMD_EPI_ACCUM), K_p % 64 == 0.
+// Layouts: the weight-gradient one (TAMD_GEMM_A_KM | TAMD_GEMM_B_KN: the dW products of one layer's backward) and the
+// row-major forward one (0).  `workspace` of tamd_gemm_group_workspace_bytes (smaller / null: no K split).
+extern "C" int tamd_gemm_group(const tamd_gemm_problem* problems, int count, int flags, int epilogue, int dtype,
+                               void* workspace, size_t workspace_bytes, tamd_stream_t stream) {
+  flags &= 0xff;
+  if (epilogue != TAMD_EPI_NONE && epilogue != TAMD_EPI_ACCUM) return TAMD_E_ARG;
+  const bool akm = flags & TAMD_GEMM_A_KM, bkn = flags & TAMD_GEMM_B_KN;
+  if (akm != bkn) return TAMD_E_ARG;
+  GroupPlan plan;
+  int st = gemm_group_plan(problems, count, flags, workspace != nullptr && aligned16(workspace), &plan);
+  if (st != TAMD_OK) return st;
+  if (plan.any_split) {
+    size_t need = 0;
+    for (int i = 0; i < count; ++i) need += plan.ws_floats[i];
+    if (need * sizeof(float) > workspace_bytes) {
+      st = gemm_group_plan(problems, count, flags, false, &plan);
+      if (st != TAMD_OK) return st;
+    }
+  }
+  float* ws = reinterpret_cast<float*>(workspace);
+  if (akm) {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_group_launch<T, true, true>(problems, count, plan, epilogue, ws, TAMD_STREAM(stream))));
+  } else {
+    TAMD_DISPATCH_HALF(dtype, return (gemm_group_launch<T, false, false>(problems, count, plan, epilogue, ws, TAMD_STREAM(stream))));
+  }
+  return TAMD_E_DTYPE;
 }
 
 // BertIntermediate / CLIPMLP.fc1 / GPT2MLP.c_fc in train mode (models/bert/modeling_bert.py:334-337): the activation AND the

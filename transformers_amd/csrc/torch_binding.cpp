@@ -43,7 +43,7 @@ using OptTensor = std::optional<at::Tensor>;
   X(tamd_bert_embeddings_fwd) X(tamd_swiglu_fwd) X(tamd_swiglu_bwd) X(tamd_bias_act_fwd) X(tamd_bias_act_bwd)         \
   X(tamd_add) X(tamd_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
   X(tamd_cross_entropy_fwd) X(tamd_cross_entropy_bwd) X(tamd_gemm) X(tamd_gemm_workspace_bytes) X(tamd_gemm_ws)       \
-  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
+  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_gemm_group_workspace_bytes) X(tamd_gemm_group) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
   X(tamd_attn_decode_workspace_bytes) X(tamd_attn_decode)
 
 struct Api {
@@ -606,6 +606,47 @@ void gemm_dw_segments(const Tensor& dy, const Tensor& x, const std::vector<Tenso
 
 bool half_type(const Tensor& t) { return t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf; }
 
+// dW_i[M_i, N_i] = dy_i[K_i, M_i]^T . x_i[K_i, N_i] for up to 4 pairs in ONE launch (tamd_gemm_group): the weight gradients of
+// one BERT layer's four dense layers are 9 .. 36 output tiles each; together they fill the GPU with two K splits instead of
+// 7 .. 16 (csrc/gemm.hip "grouped launch").  Pairs the grouped kernel does not take (K % 64) fall back to one product each.
+std::vector<Tensor> gemm_dw_group(const std::vector<Tensor>& dys, const std::vector<Tensor>& xs) {
+  TORCH_CHECK(dys.size() == xs.size() && !dys.empty() && dys.size() <= 4, "tamd: gemm_dw_group takes 1..4 (dy, x) pairs");
+  std::vector<const Tensor*> all;
+  for (const Tensor& t : dys) all.push_back(&t);
+  for (const Tensor& t : xs) all.push_back(&t);
+  Launch L({&dys[0], &xs[0]});
+  std::vector<tamd_gemm_problem> pr(dys.size());
+  std::vector<Tensor> outs;
+  bool groupable = true;
+  double flops = 0, bytes = 0;
+  for (size_t i = 0; i < dys.size(); ++i) {
+    const Tensor &dy = dys[i], &x = xs[i];
+    TORCH_CHECK(dy.dim() == 2 && x.dim() == 2 && dy.stride(1) == 1 && x.stride(1) == 1 && dy.size(0) == x.size(0) &&
+                    dy.scalar_type() == dys[0].scalar_type() && x.scalar_type() == dys[0].scalar_type() &&
+                    dy.device() == dys[0].device() && x.device() == dys[0].device(),
+                "tamd: gemm_dw_group takes dy_i [K, M] and x_i [K, N] of one dtype on one device");
+    const int64_t k = dy.size(0), m = dy.size(1), n = x.size(1);
+    groupable = groupable && k % 64 == 0 && half_type(dy);
+    outs.push_back(at::empty({m, n}, dy.options()));
+    pr[i] = tamd_gemm_problem{ptr(dy), ptr(x), mptr(outs.back()), m, n, k, dy.stride(0), x.stride(0), n};
+    flops += 2.0 * (double)m * (double)n * (double)k;
+    bytes += 2.0 * ((double)m * k + (double)n * k + (double)m * n);
+  }
+  if (!groupable) {
+    for (size_t i = 0; i < dys.size(); ++i) outs[i] = gemm_plain(dys[i], xs[i], true, true);
+    return outs;
+  }
+  const int flags = TAMD_GEMM_A_KM | TAMD_GEMM_B_KN;
+  const size_t ws_bytes = api().tamd_gemm_group_workspace_bytes(pr.data(), (int)pr.size(), flags);
+  Tensor ws = ws_bytes ? at::empty({(int64_t)ws_bytes}, dys[0].options().dtype(at::kByte)) : Tensor();
+  GemmTimerScope timer(flops, bytes, L.stream);
+  check(api().tamd_gemm_group(pr.data(), (int)pr.size(), flags, TAMD_EPI_NONE, code_of(dys[0]), mptr(ws), ws_bytes, L.stream),
+        "tamd_gemm_group");
+  return outs;
+}
+
+
+
 // shapes the fused gate|up GEMM + SiLU*up epilogue takes (csrc/gemm.hip tamd_gemm_swiglu)
 bool gemm_swiglu_supported(const Tensor& x2, const Tensor& wgu) {
   const int64_t two_i = wgu.size(0), k = wgu.size(1);
@@ -829,6 +870,7 @@ std::tuple<Tensor, Tensor> op_bias_act_bwd(const Tensor& x, const OptTensor& bia
   return {dx, dc.defined() ? dc : nothing(x)};
 }
 void op_gemm_dw_segments(const Tensor& dy, const Tensor& x, at::TensorList segs) { gemm_dw_segments(dy, x, segs.vec()); }
+std::vector<Tensor> op_gemm_dw_group(at::TensorList dy, at::TensorList x) { return gemm_dw_group(dy.vec(), x.vec()); }
 std::tuple<Tensor, Tensor> op_gemm_bias_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
   return k_gemm_bias_act_pre(x2, w, bias, act);
 }
@@ -1090,6 +1132,9 @@ const bool kRopePrescale = env_flag("TAMD_ROPE_PRESCALE", true);
 constexpr double kLog2e = 1.44269504088896340736;
 // BertLayer: the q|k|v GEMM's epilogue delivers the pre-scaled queries (TAMD_BERT_PRESCALE=0: the kernels scale and re-round)
 const bool kBertPrescale = env_flag("TAMD_BERT_PRESCALE", true);
+// the layer's four weight gradients as ONE grouped launch at the end of its backward (gemm_dw_group) instead of four split-K
+// products where they arise: A/B switch
+const bool kBertGroupDw = env_flag("TAMD_BERT_GROUP_DW", true);
 
 struct Qkv {
   Tensor q, k, v;
@@ -1282,16 +1327,17 @@ BertLayerOut op_bert_layer_bwd(const Tensor& d_out, const Tensor& h_in, const Op
   };
   // ---- BertOutput / BertIntermediate
   auto [d_h1_res, d_b, dw_ln2, db_ln2, dbo2] = ln_bwd(dy, y2, ln2_w, mean2, rstd2, seed2, 2);
-  Tensor dwo2 = gemm_plain(d_b, inter, true, true);  // [hd, I]
+  // (the four weight gradients: together, at the end -- gemm_dw_group; TAMD_BERT_GROUP_DW=0: one product each, where they arise)
+  Tensor dwo2 = kBertGroupDw ? Tensor() : gemm_plain(d_b, inter, true, true);  // [hd, I]
   Tensor d_inter = gemm_plain(d_b, wo2, false, true);  // [T, I]
   auto [d_pre, dbi] = k_bias_act_bwd(pre, {}, d_inter, act, true);  // (+ its column sums: the intermediate bias gradient)
   d_inter = Tensor();
-  Tensor dwi = gemm_plain(d_pre, h1, true, true);  // [I, hd]
+  Tensor dwi = kBertGroupDw ? Tensor() : gemm_plain(d_pre, h1, true, true);  // [I, hd]
   Tensor d_h1 = gemm_plain(d_pre, wi, false, true, {}, d_h1_res, TAMD_EPI_RESIDUAL);  // + the residual path's gradient
-  d_pre = Tensor();
+  if (!kBertGroupDw) d_pre = Tensor();
   // ---- BertSelfOutput / BertSelfAttention
   auto [d_x_res, d_a, dw_ln1, db_ln1, dbo] = ln_bwd(d_h1, y1, ln1_w, mean1, rstd1, seed1, 1);
-  Tensor dwo = gemm_plain(d_a, o.view({t, hd}), true, true);
+  Tensor dwo = kBertGroupDw ? Tensor() : gemm_plain(d_a, o.view({t, hd}), true, true);
   Tensor d_o = gemm_plain(d_a, wo, false, true);
   Tensor d_qkv = at::empty_like(qkv);
   Qkv f = split_qkv(qkv, b, s, heads, heads, d), g = split_qkv(d_qkv, b, s, heads, heads, d);
@@ -1299,8 +1345,14 @@ BertLayerOut op_bert_layer_bwd(const Tensor& d_out, const Tensor& h_in, const Op
              Tensor(), Tensor(), kBertPrescale, seed_word(seeds_dev, 0));
   d_o = Tensor();
   Tensor dbqkv = k_colsum(d_qkv);
-  Tensor dwqkv = gemm_plain(d_qkv, x, true, true);  // [3 hd, hd]
   Tensor d_x = gemm_plain(d_qkv, wqkv, false, true, {}, d_x_res, TAMD_EPI_RESIDUAL);
+  Tensor dwqkv;  // [3 hd, hd]
+  if (kBertGroupDw) {
+    std::vector<Tensor> dws = gemm_dw_group({d_b, d_pre, d_a, d_qkv}, {inter, h1, o.view({t, hd}), x});
+    dwo2 = dws[0], dwi = dws[1], dwo = dws[2], dwqkv = dws[3];
+  } else {
+    dwqkv = gemm_plain(d_qkv, x, true, true);
+  }
   return {d_x.view({b, s, hd}), dwqkv, dbqkv, dwo, dbo, dw_ln1, db_ln1, dwi, dbi, dwo2, dbo2, dw_ln2, db_ln2};
 }
 
@@ -1342,6 +1394,7 @@ TORCH_LIBRARY(tamd, m) {
   m.def("gemm_swiglu(Tensor x2, Tensor wgu, bool need_gu=True) -> (Tensor, Tensor)");
   m.def("gemm_bias_act_pre(Tensor x2, Tensor w, Tensor bias, int act) -> (Tensor, Tensor)");
   m.def("gemm_dw_segments(Tensor dy, Tensor x, Tensor(a!)[] segs) -> ()");
+  m.def("gemm_dw_group(Tensor[] dy, Tensor[] x) -> Tensor[]");
   m.def("gemm_colscale(Tensor x2, Tensor w, Tensor? bias, int scale_cols, float col_scale) -> Tensor");
   m.def("gemm_rope(Tensor x2, Tensor wqkv, Tensor cos, Tensor sin, int seq, int rope_heads, int head_dim) -> Tensor");
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None, bool need_lse=True, "
@@ -1418,6 +1471,7 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("bias_act_bwd", &op_bias_act_bwd);                          \
   m.impl("gemm_bias_act_pre", &op_gemm_bias_act_pre);                \
   m.impl("gemm_dw_segments", &op_gemm_dw_segments);                  \
+  m.impl("gemm_dw_group", &op_gemm_dw_group);                        \
   m.impl("gemm_colscale", &op_gemm_colscale);                        \
   m.impl("add", &k_add);                                             \
   m.impl("colsum", &k_colsum);                                       \

@@ -377,6 +377,7 @@ register("gemm_bias_act_pre", lambda x2, w, bias, act: (x2.new_empty(x2.shape[0]
                                                         x2.new_empty(x2.shape[0], w.shape[0])))
 register("gemm_colscale", lambda x2, w, bias, scale_cols, col_scale: x2.new_empty(x2.shape[0], w.shape[0]))
 register("gemm_dw_segments", lambda dy, x, segs: None)
+register("gemm_dw_group", lambda dy, x: [a.new_empty(a.shape[1], b.shape[1]) for a, b in zip(dy, x)])
 register("add", lambda a, b: torch.empty_like(a))
 register("colsum", lambda x2d: x2d.new_empty(x2d.shape[1]))
 register("transpose", lambda x2d: x2d.new_empty(x2d.shape[1], x2d.shape[0]))
