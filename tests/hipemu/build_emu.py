@@ -13,7 +13,7 @@ CSRC = ROOT / "transformers_amd" / "csrc"
 OUT = HERE / "_build"
 LIB = OUT / "libtamd_emu.so"
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip", "probe.hip"]
+SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "gemv.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip", "probe.hip"]
 FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-fPIC", "-DTAMD_DIAG", "-ffp-contract=off", "-pthread", "-Wno-unused-value",
          "-Wno-unknown-attributes", "-Wno-ignored-attributes", "-Wno-pass-failed",
          "-I", str(HERE), "-I", str(CSRC), "-I", str(ROOT / "include")]

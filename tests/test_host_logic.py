@@ -125,3 +125,30 @@ def test_varlen_kwargs_give_the_packed_bounds():
         varlen_q_start(None, {"cu_seq_lens_q": cu, "cu_seq_lens_k": cu}, 2, 12, 12, True)       # not one flattened row
     with pytest.raises(ops.TamdError):
         varlen_q_start(None, {"cu_seq_lens_q": cu, "cu_seq_lens_k": torch.tensor([0, 5, 6, 12])}, 1, 12, 12, True)
+
+
+def test_key_validity_mask_is_converted_once_per_forward():
+    """Every layer of a forward hands the attention function the same mask tensor: `split_mask` converts it to the kernels'
+    [B, kv_len] bool form once and the other layers get that tensor back; another mask, an in-place update of the same one,
+    another batch or key length are converted afresh (a stale hit would attend to padding)."""
+    from transformers_amd.attention import split_mask
+
+    am = torch.tensor([[1, 1, 1, 0], [1, 1, 1, 1]])
+    kv1, _ = split_mask(am, 2, 4)
+    kv2, _ = split_mask(am, 2, 4)
+    assert kv1 is kv2 and kv1.dtype == torch.bool and kv1.tolist() == [[True, True, True, False], [True, True, True, True]]
+    am[0, 3] = 1                                   # in place: the version moves
+    kv3, _ = split_mask(am, 2, 4)
+    assert kv3 is not kv1 and kv3.all()
+    other = am.clone()
+    other[1, 0] = 0
+    kv4, _ = split_mask(other, 2, 4)
+    assert kv4.tolist()[1][0] is False
+    kv5, _ = split_mask(am, 2, 3)                  # the last 3 key slots
+    assert kv5.shape == (2, 3)
+    kv6, _ = split_mask(TamdMask(am, None), 2, 4)  # the mask factory's wrapper around the same tensor
+    assert kv6.all() and kv6.shape == (2, 4)
+    add = torch.zeros(2, 1, 1, 4)
+    add[0, 0, 0, 0] = torch.finfo(torch.float32).min
+    kv7, _ = split_mask(add, 2, 4)                 # the reference's additive 4-D padding mask
+    assert kv7.tolist()[0] == [False, True, True, True] and split_mask(add, 2, 4)[0] is kv7

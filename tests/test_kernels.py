@@ -1128,6 +1128,43 @@ def test_dropout_seed_from_device_memory_is_the_same_mask(env):
     assert all(torch.equal(a, c) for a, c in zip(b1, b2))
 
 
+def test_gemv_decode_projections(env):
+    """M <= 8 rows against a row-major weight (the projections of a cached decode step: modeling_llama.py:254-256, 280, 174-176,
+    480 with one new token per sequence) run on the weight-streaming kernel of csrc/gemv.hip: fp32 reference on the same
+    bf16-rounded operands, plain / bias / residual (+ bias) epilogues with the GEMM kernels' roundings, ragged N and K, strided
+    inputs (a [B, 1, H] slice of a longer buffer); a schedule hint keeps the product on the tile kernels, M = 9 is theirs anyway."""
+    torch.manual_seed(101)
+    dev = env.device
+    shapes = [(4096, 4096), (6144, 4096), (1032, 520), (28672, 4096)] if env.big else [(264, 520), (72, 4104), (16, 64)]
+    for (n, k) in shapes:
+        w = (torch.randn(n, k) * 0.05).bfloat16().to(dev)
+        bias = torch.randn(n).bfloat16().to(dev)
+        for m in (1, 2, 3, 5, 8):
+            xbuf = torch.randn(m, 2 * k).bfloat16().to(dev)
+            x = xbuf[:, :k]  # row stride 2k
+            res = torch.randn(m, n).bfloat16().to(dev)
+            ref = x.float() @ w.float().t()
+            got = ops.raw_gemm(x, w)
+            assert got.shape == (m, n) and rel_err(got, ref) < 0.0034, (m, n, k)
+            tiles = ops.raw_gemm(x, w, sched="fl" if k % 64 == 0 else "pp")
+            assert rel_err(got, tiles) < 0.004, (m, n, k)
+            got = ops.raw_gemm(x, w, bias=bias, epilogue=ops.EPI_BIAS)
+            assert rel_err(got, ref + bias.float()) < 0.0034, (m, n, k)
+            for b in (None, bias):
+                got = ops.raw_gemm(x, w, bias=b, residual=res, epilogue=ops.EPI_RESIDUAL)
+                want = (ref + (b.float() if b is not None else 0)).bfloat16().float() + res.float()
+                assert rel_err(got, want) < 0.0034, (m, n, k, b is not None)
+        x9 = torch.randn(9, k).bfloat16().to(dev)
+        assert rel_err(ops.raw_gemm(x9, w), x9.float() @ w.float().t()) < 0.0034
+    x = torch.randn(2, 256).half().to(dev)
+    w = (torch.randn(264, 256) * 0.05).half().to(dev)
+    assert rel_err(ops.raw_gemm(x, w), x.float() @ w.float().t()) < 0.0006   # fp16
+    # the layer-level entry: ops.linear on a [B, 1, H] decode input
+    h = torch.randn(3, 1, 520).bfloat16().to(dev)
+    w = (torch.randn(264, 520) * 0.05).bfloat16().to(dev)
+    assert rel_err(ops.linear(h, w), h.float() @ w.float().t()) < 0.0034
+
+
 def test_gemm_group_weight_gradients(env):
     """tamd_gemm_group (ABI 8): the weight gradients of one layer's dense layers in ONE launch.  Groups that fit one round
     of workgroups are split along K with one common range length (fp32 partials + one grouped reduction): the single

@@ -102,18 +102,30 @@ def test_llama_module_level_path_matches_fused_layer(env):
 
 
 def test_generate_with_cache_uses_reference_modules(env):
-    """KV-cache decode goes through the reference attention module + our registered attention function."""
+    """A forward with a KV cache (round 4): our layer around the reference's own cache object -- fused q|k|v product, rotary
+    kernel, `Cache.update`, the registered attention function, residual adds in the o_proj / down_proj epilogues -- for the
+    prefill and for single-token decode steps (M = batch rows: the weight-streaming kernel of csrc/gemv.hip); nothing falls
+    back.  Under autograd the cached forward is the reference module's (counted as `kv_cache`)."""
     torch.manual_seed(2)
     cfg = tiny_llama(False)
     ref = LlamaForCausalLM(cfg).bfloat16().eval()
     fast = copy.deepcopy(ref).to(env.device)
     transformers_amd.accelerate(fast)
-    ids = torch.randint(0, cfg.vocab_size, (1, 12))
+    ids = torch.randint(0, cfg.vocab_size, (2, 12))
+    transformers_amd.fallback_calls(reset=True)
     with torch.no_grad():
-        want = ref(input_ids=ids, use_cache=True)
-        got = fast(input_ids=ids.to(env.device), use_cache=True)
-    assert rel_err(got.logits, want.logits) < 0.014
-    assert got.past_key_values is not None
+        want = ref(input_ids=ids[:, :10], use_cache=True)
+        got = fast(input_ids=ids[:, :10].to(env.device), use_cache=True)
+        assert rel_err(got.logits, want.logits) < 0.014
+        assert got.past_key_values is not None
+        for t in (10, 11):  # two decode steps on the caches the prefills returned
+            want = ref(input_ids=ids[:, t:t + 1], past_key_values=want.past_key_values, use_cache=True)
+            got = fast(input_ids=ids[:, t:t + 1].to(env.device), past_key_values=got.past_key_values, use_cache=True)
+            assert got.logits.shape == (2, 1, cfg.vocab_size) and rel_err(got.logits, want.logits) < 0.02, t
+    assert transformers_amd.fallback_calls() == {}
+    fast.train()  # (autograd on: the cached forward is the reference module's)
+    got = fast(input_ids=ids[:, :10].to(env.device), use_cache=True)
+    assert any("kv_cache" in k for k in transformers_amd.fallback_calls()), transformers_amd.fallback_calls()
 
 
 @pytest.mark.parametrize("padding_side", [None, "left"])

@@ -2,8 +2,9 @@
   kernels   per shape: the split-KV schedule vs the training kernel (tamd_attn_fwd on the same call) vs torch SDPA -- us per call
             and the K+V bytes of the cache / time (the HBM roofline of a decode step's attention: every cached key and value
             is read once)
-  generate  `model.generate` of a Llama-3-8B-shaped model (8 layers, random init) after a 4096-token prompt: new tokens / s
-            with attn_implementation="tamd" (decode kernel on, and -- in a child process -- TAMD_DECODE_KERNEL=0) and "sdpa"
+  generate  `model.generate` of a Llama-3-8B-shaped model (DECODE_BENCH_LAYERS layers, default 8, random init) after a 4096-token
+            prompt: new tokens / s with attn_implementation="tamd" (and, in child processes, with the M = batch projections kept
+            on the MFMA tiles, TAMD_GEMM=x, and with the training attention kernel, TAMD_DECODE_KERNEL=0) and "sdpa"
     python tools/decode_bench.py [kernels] [generate] > gpurun_out/<tag>_decode_bench.jsonl"""
 import ctypes
 import json
@@ -77,7 +78,8 @@ def kernels():
 def generate(arm):
     from transformers import LlamaConfig, LlamaForCausalLM
 
-    cfg = LlamaConfig(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=8, num_attention_heads=32,
+    layers = int(os.environ.get("DECODE_BENCH_LAYERS", "8"))
+    cfg = LlamaConfig(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=layers, num_attention_heads=32,
                       num_key_value_heads=8, max_position_embeddings=8192, attn_implementation="sdpa" if arm == "sdpa" else "eager")
     torch.manual_seed(0)
     old = torch.get_default_dtype()
@@ -101,7 +103,7 @@ def generate(arm):
             torch.cuda.synchronize()
             t2 = time.perf_counter()
         dec = (t2 - t1) - (t1 - t0)  # the decode steps alone (both runs include the same prefill)
-        print(json.dumps({"bench": "generate", "arm": arm, "batch": b, "prompt": 4096, "new_tokens": new, "layers": 8,
+        print(json.dumps({"bench": "generate", "arm": arm, "batch": b, "prompt": 4096, "new_tokens": new, "layers": layers,
                           "prefill_s": round(t1 - t0, 4), "decode_ms_per_token": round(dec / new * 1e3, 3),
                           "new_tokens_per_s": round(b * new / dec, 1),
                           "fallbacks": transformers_amd.fallback_calls() if arm != "sdpa" else None}), flush=True)
@@ -116,6 +118,8 @@ if __name__ == "__main__":
         if arm:
             generate(arm)
         else:
-            for arm, env in (("tamd", {}), ("tamd, TAMD_DECODE_KERNEL=0", {"TAMD_DECODE_KERNEL": "0"}), ("sdpa", {})):
+            # (TAMD_GEMM=x keeps the M = batch projections on the 256 x 256 MFMA tiles instead of csrc/gemv.hip)
+            for arm, env in (("tamd", {}), ("tamd, TAMD_GEMM=x (tile GEMMs)", {"TAMD_GEMM": "x"}),
+                             ("tamd, TAMD_DECODE_KERNEL=0", {"TAMD_DECODE_KERNEL": "0"}), ("sdpa", {})):
                 e = dict(os.environ, DECODE_BENCH_ARM=arm, **env)
                 subprocess.run([sys.executable, __file__, "generate"], env=e, timeout=600)

@@ -166,17 +166,41 @@ def varlen_q_start(q_start, kwargs, batch: int, sq: int, sk: int, causal: bool):
         raise TamdError("attn_implementation='tamd' takes cu_seq_lens_q/k for one flattened, causal row without a KV cache "
                         "(equal query and key boundaries)")
     hit = getattr(_varlen_cache, "entry", None)
-    if hit is not None and hit[2] == sq and _same_tensor(hit[0], cu_q) and (cu_k is None or _same_tensor(hit[1], cu_k)):
+    if (hit is not None and hit[2] == sq and _same_tensor(hit[0], cu_q) and (cu_k is None or _same_tensor(hit[1], cu_k))
+            and hit[4] == (cu_q._version, cu_k._version if cu_k is not None else -1)):  # (the SAME object updated in place)
         return hit[3]
     if cu_k is not None and cu_k is not cu_q and (cu_k.shape != cu_q.shape or not torch.equal(cu_k, cu_q)):
         raise TamdError("attn_implementation='tamd' takes cu_seq_lens_q/k for one flattened, causal row without a KV cache "
                         "(equal query and key boundaries)")
     qs = ops.q_start_from_cu_seqlens(cu_q, sq)
-    _varlen_cache.entry = (cu_q, cu_k if cu_k is not None else cu_q, sq, qs)
+    _varlen_cache.entry = (cu_q, cu_k if cu_k is not None else cu_q, sq, qs,
+                           (cu_q._version, cu_k._version if cu_k is not None else -1))
     return qs
 
 
+_kv_cache = threading.local()  # the last (mask tensor, batch, kv_len) -> key_valid of this thread
+
+
 def _key_valid_from_mask(attention_mask, batch: int, kv_len: int) -> Optional[torch.Tensor]:
+    """[B, kv_len] bool, contiguous.  Every layer of a forward receives the same mask tensor: it is converted ONCE per forward
+    (two small launches per layer otherwise -- 64 per generated token of a 32-layer model, where a decode step is bound by
+    launches).  The entry keeps the mask tensor alive, so `_same_tensor` cannot be fooled by a recycled allocation, and an
+    in-place update of the mask changes its version."""
+    src = attention_mask.key_valid if isinstance(attention_mask, TamdMask) else attention_mask
+    hit = getattr(_kv_cache, "entry", None)
+    if (hit is not None and hit[1] == batch and hit[2] == kv_len and torch.is_tensor(src) and _same_tensor(hit[0], src)
+            and hit[4] == src._version):
+        if isinstance(attention_mask, TamdMask) and attention_mask.q_start is not None:
+            raise TamdError("packed sequences reached a fused block that does not implement them (supported: the "
+                            "Llama path and every model that goes through the registered attention function)")
+        return hit[3]
+    out = _key_valid_from_mask_uncached(attention_mask, batch, kv_len)
+    if torch.is_tensor(src) and out is not None:
+        _kv_cache.entry = (src, batch, kv_len, out, src._version)
+    return out
+
+
+def _key_valid_from_mask_uncached(attention_mask, batch: int, kv_len: int) -> Optional[torch.Tensor]:
     if isinstance(attention_mask, TamdMask):  # a fused module path that only knows padding masks
         if attention_mask.q_start is not None:
             raise TamdError("packed sequences reached a fused block that does not implement them (supported: the "

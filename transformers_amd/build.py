@@ -21,7 +21,7 @@ INCLUDE = HERE.parent / "include"
 LIB = HERE / "libtamd.so"
 DIAG_LIB = HERE / "libtamd_diag.so"  # diagnostics only (include/tamd_diag.h): tools/ and tests/test_gpu_probe.py
 OBJ_DIR = HERE / "_build"
-SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip"]
+SOURCES = ["api.hip", "norm.hip", "elementwise.hip", "gemm.hip", "gemv.hip", "attention.hip", "attention_bwd_dkdv.hip", "optim.hip"]
 DIAG_SOURCES = SOURCES + ["probe.hip"]  # + every source recompiled with -DTAMD_DIAG (ablation instantiations, traces)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",

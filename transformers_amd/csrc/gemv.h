@@ -1,0 +1,20 @@
+// gemv.h -- the skinny product of a cached decode step: Y[M, N] = X[M, K] . W[N, K]^T with M <= kGemvMaxRows (gemv.hip).
+#pragma once
+#include "common.h"
+
+namespace tamd {
+
+constexpr int kGemvMaxRows = 8;
+
+struct GemvArgs {
+  const void* X;
+  const void* W;
+  void* Y;
+  const void* bias;
+  const void* R;
+  int64_t M, N, K, ldx, ldw, ldy, ldr;
+};
+// epilogue: TAMD_EPI_NONE / TAMD_EPI_BIAS / TAMD_EPI_RESIDUAL (bias optional) with the GEMM kernels' roundings
+int gemv_run(const GemvArgs& g, int epilogue, int dtype, hipStream_t stream);
+
+}  // namespace tamd

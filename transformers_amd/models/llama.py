@@ -74,10 +74,36 @@ class TamdLlamaAttention(ref.LlamaAttention):
                 and self.head_dim in (64, 128) and hidden_states.dtype in (torch.bfloat16, torch.float16)
                 and self.config._attn_implementation == "tamd")
 
+    def _cached_ok(self, hidden_states) -> bool:
+        """A forward with a KV cache (prefill into it, or a decode step) on the kernels: inference only."""
+        return (self._fast_ok(hidden_states, None) and self.o_proj.bias is None
+                and not (torch.is_grad_enabled() and (hidden_states.requires_grad or self.q_proj.weight.requires_grad)))
+
+    def cached_forward(self, hidden_states, position_embeddings, attention_mask, past_key_values, residual=None, **kwargs):
+        """LlamaAttention.forward with `past_key_values` (modeling_llama.py:254-281): ONE fused q|k|v product (the
+        weight-streaming kernel of csrc/gemv.hip at one token per sequence), the rotary kernel, the reference's own
+        `Cache.update` (cache_utils.py: the cache stays the reference's object), the registered attention function (split-KV
+        decode kernel for seq_q <= 16) and o_proj -- with `residual` added in its epilogue when the caller is our layer."""
+        from ..attention import tamd_attention_forward
+
+        b, s, _ = hidden_states.shape
+        hq, hkv, d = self.config.num_attention_heads, self.config.num_key_value_heads, self.head_dim
+        cos, sin = position_embeddings
+        qkv = self._fused().linear(hidden_states)                       # [B, S, (Hq+2Hkv)*D]
+        qkv = ops.rope(qkv, cos, sin, hq + hkv, d)
+        q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)        # the reference's [B, H, S, D] views
+        k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
+        v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
+        k, v = past_key_values.update(k, v, self.layer_idx)
+        o, _ = tamd_attention_forward(self, q, k, v, attention_mask, dropout=0.0, scaling=self.scaling, **kwargs)
+        return ops.linear(o.reshape(b, s, hq * d), self.o_proj.weight, residual=residual)
+
     def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        if past_key_values is not None and self._cached_ok(hidden_states):
+            return self.cached_forward(hidden_states, position_embeddings, attention_mask, past_key_values, **kwargs), None
         if not self._fast_ok(hidden_states, past_key_values):
-            # cached decode: the reference module (projections through the TamdLinear children, cache update) around the
-            # registered attention function -- by design, counted under its own reason
+            # (a cache under autograd, biases, other head sizes: the reference module -- projections through the TamdLinear
+            # children, cache update -- around the registered attention function, counted under its own reason)
             note_fallback(self, hidden_states, "kv_cache" if past_key_values is not None else "unsupported")
             return super().forward(hidden_states, position_embeddings=position_embeddings,
                                    attention_mask=attention_mask, past_key_values=past_key_values, **kwargs)
@@ -114,8 +140,28 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
                 and attn.o_proj.bias is None
                 and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm))
 
+    def _cached_ok(self, hidden_states) -> bool:
+        attn, mlp = self.self_attn, self.mlp
+        return (isinstance(attn, TamdLlamaAttention) and isinstance(mlp, TamdLlamaMLP) and attn._cached_ok(hidden_states)
+                and mlp.config.hidden_act in ("silu", "swish") and mlp.gate_proj.bias is None and mlp.down_proj.bias is None
+                and mlp.gate_proj.weight.dtype == hidden_states.dtype
+                and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm))
+
+    def cached_forward(self, hidden_states, attention_mask, past_key_values, position_embeddings, **kwargs):
+        """The layer with a KV cache (modeling_llama.py:303-324), prefill or decode: both residual adds ride in the epilogues
+        of o_proj / down_proj; 11 launches per decode step and layer (the reference path: ~25)."""
+        attn, mlp = self.self_attn, self.mlp
+        x = ops.rmsnorm(hidden_states, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
+        h = attn.cached_forward(x, position_embeddings, attention_mask, past_key_values, residual=hidden_states, **kwargs)
+        x = ops.rmsnorm(h, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
+        act = ops.swiglu(mlp._fused().linear(x))
+        return ops.linear(act, mlp.down_proj.weight, residual=h)
+
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                 position_embeddings=None, **kwargs):
+        if past_key_values is not None and self._cached_ok(hidden_states):
+            return self.cached_forward(hidden_states, attention_mask, past_key_values, position_embeddings,
+                                       position_ids=position_ids, **kwargs)
         if not self._fused_ok(hidden_states, past_key_values):
             # (the children are replacement classes: this level only loses the epilogue fusions)
             note_fallback(self, hidden_states, "kv_cache" if past_key_values is not None else "layer_unfused")

@@ -222,6 +222,8 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int, flags: int = 0) 
     two in step."""
     if k % 64 or n % 4 or epilogue not in (EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_ACCUM):
         return 0
+    if (flags & 3) == 0 and m <= 8 and epilogue <= EPI_RESIDUAL:  # the streaming kernel of csrc/gemv.hip
+        return 0
     tiles, nst = -(-m // 256) * -(-n // 256), k // 64
     if nst < 32:
         return 0
