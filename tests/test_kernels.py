@@ -1159,6 +1159,16 @@ def test_gemv_decode_projections(env):
     x = torch.randn(2, 256).half().to(dev)
     w = (torch.randn(264, 256) * 0.05).half().to(dev)
     assert rel_err(ops.raw_gemm(x, w), x.float() @ w.float().t()) < 0.0006   # fp16
+    # LlamaMLP's inner product at M = batch (tamd_gemm_swiglu -> gemv_swiglu_kernel): the bits of product + swiglu kernel
+    for (m, inter, k) in ([(1, 14336, 4096), (8, 11008, 4096)] if env.big else [(1, 264, 128), (3, 72, 192), (8, 16, 64)]):
+        x = torch.randn(m, k).bfloat16().to(dev)
+        wgu = (torch.randn(2 * inter, k) * 0.05).bfloat16().to(dev)
+        assert ops.gemm_swiglu_supported(x, wgu)
+        gu, act = ops.raw_gemm_swiglu(x, wgu, need_gu=True)
+        plain = ops.raw_gemm(x, wgu, sched="fl")                 # the tile kernel's gate | up
+        assert rel_err(gu, plain) < 0.004
+        assert torch.equal(act, ops.raw_swiglu_fwd(gu)), (m, inter, k)   # same expression on the same rounded gate | up
+        assert torch.equal(ops.raw_gemm_swiglu(x, wgu, need_gu=False)[1], act)
     # the layer-level entry: ops.linear on a [B, 1, H] decode input
     h = torch.randn(3, 1, 520).bfloat16().to(dev)
     w = (torch.randn(264, 520) * 0.05).bfloat16().to(dev)

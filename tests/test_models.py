@@ -827,6 +827,19 @@ def test_llava_forward_parity(env):
         assert torch.equal(merged[0][mask[0]], feats.reshape(-1, feats.shape[-1]).to(emb.dtype))
     e_fast, e_ref = rel_err(c, a32), rel_err(a, a32)
     assert e_fast <= 1.15 * e_ref + 1e-3, (e_fast, e_ref)
+    # with a KV cache (what `generate` does): the multimodal prefill fills the cache, then teacher-forced decode steps -- the
+    # language model's cached layer path (fused q|k|v, rotary kernel, Cache.update, M = batch products), nothing falls back
+    nxt = torch.randint(0, 1000, (1, 2))
+    with torch.no_grad():
+        transformers_amd.fallback_calls(reset=True)
+        r = ref32(input_ids=ids, pixel_values=px, use_cache=True)
+        f = fast(input_ids=ids.to(dev), pixel_values=px.bfloat16().to(dev), use_cache=True)
+        assert rel_err(f.logits, r.logits) <= 1.15 * e_ref + 1e-3
+        for t in range(2):
+            r = ref32(input_ids=nxt[:, t:t + 1], past_key_values=r.past_key_values, use_cache=True)
+            f = fast(input_ids=nxt[:, t:t + 1].to(dev), past_key_values=f.past_key_values, use_cache=True)
+            assert f.logits.shape == r.logits.shape and rel_err(f.logits, r.logits) <= 1.3 * e_ref + 2e-3, t
+        assert transformers_amd.fallback_calls() == {}, transformers_amd.fallback_calls()
 
 
 def test_bert_decoder_cross_attention_matches_reference(env):

@@ -89,7 +89,7 @@ def generate(arm):
     torch.set_default_dtype(old)
     if arm != "sdpa":
         transformers_amd.accelerate(model)
-    for b in (1, 8):
+    for b in [int(v) for v in os.environ.get("DECODE_BENCH_BATCHES", "1,8").split(",")]:
         ids = torch.randint(0, 128000, (b, 4096), device=dev)
         new = 48
         with torch.no_grad():

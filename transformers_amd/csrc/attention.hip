@@ -77,7 +77,7 @@ int attn_decode_launch(const AttnArgs& a, bool causal, hipStream_t s) {
   else
     hipLaunchKernelGGL((attn_fwd_kernel<T, D, false, true, false, true>), grid, block, smem, s, a);
   const int rows = a.batch * a.seq_q * a.heads_q;
-  hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((attn_combine_kernel<T, D>), dim3((unsigned)rows), dim3(256), 0, s, a);  // one workgroup per row
   return launch_status();
 }
 

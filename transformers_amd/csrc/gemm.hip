@@ -1820,6 +1820,10 @@ extern "C" int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* 
   if ((K % kXK) || (I % 8) || (ldx % 8) || (ldw % 8) || (ldact % 8) || (GU && (ldgu % 8))) return TAMD_E_SHAPE;
   if (!aligned16(X) || !aligned16(Wgu) || !aligned16(ACT) || (GU && !aligned16(GU))) return TAMD_E_ALIGN;
   if ((int64_t)2 * I * ldw * 2 >= ((int64_t)1 << 31)) return TAMD_E_SHAPE;  // 32-bit buffer offsets over the fused weight
+  if (M <= kGemvMaxRows) {  // a decode step: the weight-streaming kernel (gemv.hip), same bits
+    const GemvArgs v{X, Wgu, ACT, nullptr, GU, M, I, K, ldx, ldw, ldact, ldgu};
+    return gemv_swiglu_run(v, dtype, TAMD_STREAM(stream));
+  }
   GemmArgs g;
   gemm_fill_args(&g, X, Wgu, GU, nullptr, nullptr, M, 2 * I, K, ldx, ldw, ldgu, 0);
   g.tiles_n = (int)ceil_div(I, kBN / 2);  // 128 features (gate + up columns) per 256-wide tile

@@ -99,6 +99,92 @@ static int gemv_launch(const GemvArgs& g, int epilogue, hipStream_t s) {
   return gemv_launch_rows<T, 8>(g, epilogue, s);
 }
 
+// gate|up product + SiLU(gate) * up: a wave owns R FEATURES, i.e. weight rows i (gate) and I + i (up); the expression is
+// swiglu_fwd_kernel's (elementwise.hip) on the rounded gate / up, so the result is the two-launch path's bit for bit
+template <typename T, int MB, int R>
+__global__ __launch_bounds__(256) void gemv_swiglu_kernel(GemvArgs g) {
+  typedef typename elem<T>::raw raw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t inter = g.N;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+  if (i0 >= inter) return;
+  const T* __restrict__ W = reinterpret_cast<const T*>(g.W);
+  const T* __restrict__ X = reinterpret_cast<const T*>(g.X);
+  const T* wrow[2 * R];
+  const T* xrow[MB];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t i = i0 + r < inter ? i0 + r : inter - 1;
+    wrow[r] = W + i * g.ldw;
+    wrow[R + r] = W + (inter + i) * g.ldw;
+  }
+#pragma unroll
+  for (int m = 0; m < MB; ++m) xrow[m] = X + (m < g.M ? m : g.M - 1) * g.ldx;
+  float acc[MB][2 * R];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int r = 0; r < 2 * R; ++r) acc[m][r] = 0.f;
+#pragma unroll 2
+  for (int64_t k = (int64_t)lane * 8; k < g.K; k += 512) {
+    u32x4 wq[2 * R];
+#pragma unroll
+    for (int r = 0; r < 2 * R; ++r) wq[r] = ld16(wrow[r] + k);
+    float xv[MB][8];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) unpack16<T>(ld16(xrow[m] + k), xv[m]);
+#pragma unroll
+    for (int r = 0; r < 2 * R; ++r) {
+      float wv[8];
+      unpack16<T>(wq[r], wv);
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[m][r] = fmaf(wv[e], xv[m][e], acc[m][r]);
+    }
+  }
+  float gate = 0.f, up = 0.f;
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float tg = wave_sum(acc[m][r]), tu = wave_sum(acc[m][R + r]);
+      if (lane == m * R + r) gate = tg, up = tu;
+    }
+  const int m = lane / R, r = lane % R;
+  const int64_t i = i0 + r;
+  if (lane < MB * R && m < g.M && i < inter) {
+    const float gr = round_through<T>(gate), ur = round_through<T>(up);
+    const float sg = 1.f / (1.f + __expf(-gr));  // = silu_f of elementwise.hip
+    reinterpret_cast<raw*>(g.Y)[m * g.ldy + i] = elem<T>::from_f32(round_through<T>(gr * sg) * ur);
+    if (g.R != nullptr) {
+      raw* gu = reinterpret_cast<raw*>(const_cast<void*>(g.R));
+      gu[m * g.ldr + i] = elem<T>::from_f32(gr);
+      gu[m * g.ldr + inter + i] = elem<T>::from_f32(ur);
+    }
+  }
+}
+
+template <typename T, int MB>
+static int gemv_swiglu_launch_rows(const GemvArgs& g, hipStream_t s) {
+  constexpr int R = 2;  // (2 features = 4 weight rows per wave)
+  dim3 grid((unsigned)ceil_div(g.N, 4 * R)), block(256);
+  hipLaunchKernelGGL((gemv_swiglu_kernel<T, MB, R>), grid, block, 0, s, g);
+  return launch_status();
+}
+template <typename T>
+static int gemv_swiglu_launch(const GemvArgs& g, hipStream_t s) {
+  if (g.M <= 1) return gemv_swiglu_launch_rows<T, 1>(g, s);
+  if (g.M <= 2) return gemv_swiglu_launch_rows<T, 2>(g, s);
+  if (g.M <= 4) return gemv_swiglu_launch_rows<T, 4>(g, s);
+  return gemv_swiglu_launch_rows<T, 8>(g, s);
+}
+int gemv_swiglu_run(const GemvArgs& g, int dtype, hipStream_t stream) {
+  if (g.M < 1 || g.M > kGemvMaxRows || (g.K % 8) != 0) return TAMD_E_SHAPE;
+  TAMD_DISPATCH_HALF(dtype, return (gemv_swiglu_launch<T>(g, stream)));
+  return TAMD_E_DTYPE;
+}
+
 int gemv_run(const GemvArgs& g, int epilogue, int dtype, hipStream_t stream) {
   if (g.M < 1 || g.M > kGemvMaxRows || (g.K % 8) != 0) return TAMD_E_SHAPE;
   TAMD_DISPATCH_HALF(dtype, return (gemv_launch<T>(g, epilogue, stream)));

@@ -656,7 +656,8 @@ bool gemm_swiglu_supported(const Tensor& x2, const Tensor& wgu) {
          // small grids: the plain GEMM (128 x 128 tile or split-K by the library's policy) + the swiglu kernel.  "Small" as
          // for a k-major product (flags 3): the forward-layout exception of the policy -- short K goes to the 128 x 128
          // tile instead of split-K -- is about WHICH plain kernel runs, not about whether the grid fills the GPU
-         api().tamd_gemm_workspace_bytes(x2.size(0), two_i, k, 3, TAMD_EPI_NONE) == 0;
+         (x2.size(0) <= 8 ||  // (a decode step: the streaming kernel of csrc/gemv.hip behind the same entry point)
+          api().tamd_gemm_workspace_bytes(x2.size(0), two_i, k, 3, TAMD_EPI_NONE) == 0);
 }
 
 // x2 [T, K], wgu [2I, K] = [gate_proj.weight ; up_proj.weight]  ->  (gu [T, 2I] or undefined, act [T, I])
@@ -751,6 +752,9 @@ Tensor checked_key_valid(const OptTensor& key_valid, const Tensor& q, const Tens
   if (!key_valid) return Tensor();
   TORCH_CHECK(key_valid->dim() == 2 && key_valid->size(0) == q.size(0) && key_valid->size(1) == k.size(1),
               "tamd: key_valid must be [batch, seq_k] = [", q.size(0), ", ", k.size(1), "], got ", key_valid->sizes());
+  // (a bool mask IS one byte per key, 0 / 1: reinterpreted, not converted -- the conversion was a launch per attention call,
+  // one per layer and decode step: profiles/r04p_decode_kernel_stats.csv)
+  if (key_valid->scalar_type() == at::kBool) return contig(*key_valid).view(at::kByte);
   return contig(key_valid->to(at::kByte));
 }
 // packed sequences: int32 [2, B, S] = (first token of each query's sequence, last token of each key's sequence)

@@ -89,8 +89,8 @@ class TamdLlamaAttention(ref.LlamaAttention):
         b, s, _ = hidden_states.shape
         hq, hkv, d = self.config.num_attention_heads, self.config.num_key_value_heads, self.head_dim
         cos, sin = position_embeddings
-        qkv = self._fused().linear(hidden_states)                       # [B, S, (Hq+2Hkv)*D]
-        qkv = ops.rope(qkv, cos, sin, hq + hkv, d)
+        qkv = self._fused().linear(hidden_states)                       # [B, S, (Hq+2Hkv)*D], nobody else's: rotated in place
+        ops.raw_rope_(qkv.view(b * s, qkv.shape[-1]), cos, sin, s, hq + hkv, d)
         q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)        # the reference's [B, H, S, D] views
         k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
@@ -149,12 +149,17 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
 
     def cached_forward(self, hidden_states, attention_mask, past_key_values, position_embeddings, **kwargs):
         """The layer with a KV cache (modeling_llama.py:303-324), prefill or decode: both residual adds ride in the epilogues
-        of o_proj / down_proj; 11 launches per decode step and layer (the reference path: ~25)."""
+        of o_proj / down_proj, SiLU(gate) * up inside the gate|up product; 10 launches per decode step and layer (the reference path: ~25)."""
         attn, mlp = self.self_attn, self.mlp
         x = ops.rmsnorm(hidden_states, self.input_layernorm.weight, self.input_layernorm.variance_epsilon)
         h = attn.cached_forward(x, position_embeddings, attention_mask, past_key_values, residual=hidden_states, **kwargs)
         x = ops.rmsnorm(h, self.post_attention_layernorm.weight, self.post_attention_layernorm.variance_epsilon)
-        act = ops.swiglu(mlp._fused().linear(x))
+        wgu = mlp._fused().weight()
+        x2 = x.view(-1, x.shape[-1])
+        if ops.gemm_swiglu_supported(x2, wgu):  # SiLU(gate) * up inside the product (the streaming kernel at M = batch)
+            act = ops.raw_gemm_swiglu(x2, wgu, need_gu=False)[1].view(*x.shape[:-1], -1)
+        else:
+            act = ops.swiglu(mlp._fused().linear(x))
         return ops.linear(act, mlp.down_proj.weight, residual=h)
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,

@@ -286,7 +286,8 @@ def gemm_swiglu_supported(x2, wgu) -> bool:
     return (x2.dtype in (torch.bfloat16, torch.float16) and wgu.dtype == x2.dtype and k % 64 == 0 and two_i % 16 == 0
             and x2.stride(1) == 1 and wgu.stride(1) == 1 and x2.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0
             and two_i * wgu.stride(0) * 2 < 2 ** 31
-            and gemm_workspace_bytes(x2.shape[0], two_i, k, EPI_NONE, 3) == 0)  # (small grids: plain GEMM + swiglu kernel)
+            and (x2.shape[0] <= 8  # (a decode step: csrc/gemv.hip behind the same entry point)
+                 or gemm_workspace_bytes(x2.shape[0], two_i, k, EPI_NONE, 3) == 0))  # (small grids: plain GEMM + swiglu kernel)
 
 
 def raw_gemm_swiglu(x2, wgu, need_gu=True):
