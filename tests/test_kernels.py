@@ -1129,17 +1129,18 @@ def test_dropout_seed_from_device_memory_is_the_same_mask(env):
 
 
 def test_gemv_decode_projections(env):
-    """M <= 8 rows against a row-major weight (the projections of a cached decode step: modeling_llama.py:254-256, 280, 174-176,
+    """M <= 16 rows against a row-major weight (the projections of a cached decode step: modeling_llama.py:254-256, 280, 174-176,
     480 with one new token per sequence) run on the weight-streaming kernel of csrc/gemv.hip: fp32 reference on the same
     bf16-rounded operands, plain / bias / residual (+ bias) epilogues with the GEMM kernels' roundings, ragged N and K, strided
-    inputs (a [B, 1, H] slice of a longer buffer); a schedule hint keeps the product on the tile kernels, M = 9 is theirs anyway."""
+    inputs (a [B, 1, H] slice of a longer buffer); a schedule hint keeps the product on the tile kernels, M = 17 is theirs anyway."""
     torch.manual_seed(101)
     dev = env.device
-    shapes = [(4096, 4096), (6144, 4096), (1032, 520), (28672, 4096)] if env.big else [(264, 520), (72, 4104), (16, 64)]
+    shapes = ([(4096, 4096), (6144, 4096), (1032, 520), (28672, 4096), (32776, 64)] if env.big else
+              [(264, 520), (72, 4104), (16, 64), (16392, 64), (32776, 64)])  # (the last two: 2 / 4 row blocks per workgroup)
     for (n, k) in shapes:
         w = (torch.randn(n, k) * 0.05).bfloat16().to(dev)
         bias = torch.randn(n).bfloat16().to(dev)
-        for m in (1, 2, 3, 5, 8):
+        for m in (1, 2, 3, 4, 5, 8, 13, 16):  # 1 .. 4: the VALU kernel, 5 .. 16: the MFMA one
             xbuf = torch.randn(m, 2 * k).bfloat16().to(dev)
             x = xbuf[:, :k]  # row stride 2k
             res = torch.randn(m, n).bfloat16().to(dev)
@@ -1154,13 +1155,14 @@ def test_gemv_decode_projections(env):
                 got = ops.raw_gemm(x, w, bias=b, residual=res, epilogue=ops.EPI_RESIDUAL)
                 want = (ref + (b.float() if b is not None else 0)).bfloat16().float() + res.float()
                 assert rel_err(got, want) < 0.0034, (m, n, k, b is not None)
-        x9 = torch.randn(9, k).bfloat16().to(dev)
-        assert rel_err(ops.raw_gemm(x9, w), x9.float() @ w.float().t()) < 0.0034
+        x17 = torch.randn(17, k).bfloat16().to(dev)
+        assert rel_err(ops.raw_gemm(x17, w), x17.float() @ w.float().t()) < 0.0034
     x = torch.randn(2, 256).half().to(dev)
     w = (torch.randn(264, 256) * 0.05).half().to(dev)
     assert rel_err(ops.raw_gemm(x, w), x.float() @ w.float().t()) < 0.0006   # fp16
     # LlamaMLP's inner product at M = batch (tamd_gemm_swiglu -> gemv_swiglu_kernel): the bits of product + swiglu kernel
-    for (m, inter, k) in ([(1, 14336, 4096), (8, 11008, 4096)] if env.big else [(1, 264, 128), (3, 72, 192), (8, 16, 64)]):
+    for (m, inter, k) in ([(1, 14336, 4096), (8, 11008, 4096), (16, 14336, 4096)] if env.big else
+                          [(1, 264, 128), (3, 72, 192), (8, 16, 64), (11, 72, 192), (16, 264, 128)]):
         x = torch.randn(m, k).bfloat16().to(dev)
         wgu = (torch.randn(2 * inter, k) * 0.05).bfloat16().to(dev)
         assert ops.gemm_swiglu_supported(x, wgu)

@@ -1,10 +1,11 @@
-// gemv.h -- the skinny product of a cached decode step: Y[M, N] = X[M, K] . W[N, K]^T with M <= kGemvMaxRows (gemv.hip).
+// gemv.h -- the skinny product of a cached decode step: Y[M, N] = X[M, K] . W[N, K]^T with M <= kGemvMaxRows = 16 (gemv.hip).
 #pragma once
 #include "common.h"
 
 namespace tamd {
 
-constexpr int kGemvMaxRows = 8;
+constexpr int kGemvMaxRows = 16;     // rows of X these kernels take
+constexpr int kGemvValuRows = 4;     // ... of which the VALU kernel takes up to this many, the MFMA kernel the rest
 
 struct GemvArgs {
   const void* X;

@@ -656,7 +656,7 @@ bool gemm_swiglu_supported(const Tensor& x2, const Tensor& wgu) {
          // small grids: the plain GEMM (128 x 128 tile or split-K by the library's policy) + the swiglu kernel.  "Small" as
          // for a k-major product (flags 3): the forward-layout exception of the policy -- short K goes to the 128 x 128
          // tile instead of split-K -- is about WHICH plain kernel runs, not about whether the grid fills the GPU
-         (x2.size(0) <= 8 ||  // (a decode step: the streaming kernel of csrc/gemv.hip behind the same entry point)
+         (x2.size(0) <= 16 ||  // (a decode step: the streaming kernel of csrc/gemv.hip behind the same entry point)
           api().tamd_gemm_workspace_bytes(x2.size(0), two_i, k, 3, TAMD_EPI_NONE) == 0);
 }
 

@@ -222,7 +222,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int, flags: int = 0) 
     two in step."""
     if k % 64 or n % 4 or epilogue not in (EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_ACCUM):
         return 0
-    if (flags & 3) == 0 and m <= 8 and epilogue <= EPI_RESIDUAL:  # the streaming kernel of csrc/gemv.hip
+    if (flags & 3) == 0 and m <= 16 and epilogue <= EPI_RESIDUAL:  # the streaming kernel of csrc/gemv.hip
         return 0
     tiles, nst = -(-m // 256) * -(-n // 256), k // 64
     if nst < 32:
@@ -286,7 +286,7 @@ def gemm_swiglu_supported(x2, wgu) -> bool:
     return (x2.dtype in (torch.bfloat16, torch.float16) and wgu.dtype == x2.dtype and k % 64 == 0 and two_i % 16 == 0
             and x2.stride(1) == 1 and wgu.stride(1) == 1 and x2.stride(0) % 8 == 0 and wgu.stride(0) % 8 == 0
             and two_i * wgu.stride(0) * 2 < 2 ** 31
-            and (x2.shape[0] <= 8  # (a decode step: csrc/gemv.hip behind the same entry point)
+            and (x2.shape[0] <= 16  # (a decode step: csrc/gemv.hip behind the same entry point)
                  or gemm_workspace_bytes(x2.shape[0], two_i, k, EPI_NONE, 3) == 0))  # (small grids: plain GEMM + swiglu kernel)
 
 
