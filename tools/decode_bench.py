@@ -93,17 +93,20 @@ def generate(arm):
         ids = torch.randint(0, 128000, (b, 4096), device=dev)
         new = 48
         with torch.no_grad():
-            model.generate(ids[:, :256], max_new_tokens=4, do_sample=False, pad_token_id=0)  # warm-up
+            gen = dict(do_sample=False, pad_token_id=0)
+            if os.environ.get("DECODE_BENCH_CACHE"):  # e.g. "static": a pre-allocated cache (no torch.cat per layer and step)
+                gen["cache_implementation"] = os.environ["DECODE_BENCH_CACHE"]
+            model.generate(ids[:, :256], max_new_tokens=4, **gen)  # warm-up
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            model.generate(ids, max_new_tokens=1, do_sample=False, pad_token_id=0)
+            model.generate(ids, max_new_tokens=1, **gen)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            model.generate(ids, max_new_tokens=new + 1, min_new_tokens=new + 1, do_sample=False, pad_token_id=0)
+            model.generate(ids, max_new_tokens=new + 1, min_new_tokens=new + 1, **gen)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
         dec = (t2 - t1) - (t1 - t0)  # the decode steps alone (both runs include the same prefill)
-        print(json.dumps({"bench": "generate", "arm": arm, "batch": b, "prompt": 4096, "new_tokens": new, "layers": layers,
+        print(json.dumps({"bench": "generate", "arm": arm, "batch": b, "prompt": 4096, "new_tokens": new, "layers": layers, "cache": os.environ.get("DECODE_BENCH_CACHE", "dynamic"),
                           "prefill_s": round(t1 - t0, 4), "decode_ms_per_token": round(dec / new * 1e3, 3),
                           "new_tokens_per_s": round(b * new / dec, 1),
                           "fallbacks": transformers_amd.fallback_calls() if arm != "sdpa" else None}), flush=True)

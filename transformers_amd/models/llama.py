@@ -90,7 +90,7 @@ class TamdLlamaAttention(ref.LlamaAttention):
         hq, hkv, d = self.config.num_attention_heads, self.config.num_key_value_heads, self.head_dim
         cos, sin = position_embeddings
         qkv = self._fused().linear(hidden_states)                       # [B, S, (Hq+2Hkv)*D], nobody else's: rotated in place
-        ops.raw_rope_(qkv.view(b * s, qkv.shape[-1]), cos, sin, s, hq + hkv, d)
+        ops.rope_inplace(qkv.view(b * s, qkv.shape[-1]), cos, sin, s, hq + hkv, d)
         q = qkv[..., : hq * d].view(b, s, hq, d).transpose(1, 2)        # the reference's [B, H, S, D] views
         k = qkv[..., hq * d: (hq + hkv) * d].view(b, s, hkv, d).transpose(1, 2)
         v = qkv[..., (hq + hkv) * d:].view(b, s, hkv, d).transpose(1, 2)
@@ -157,7 +157,7 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
         wgu = mlp._fused().weight()
         x2 = x.view(-1, x.shape[-1])
         if ops.gemm_swiglu_supported(x2, wgu):  # SiLU(gate) * up inside the product (the streaming kernel at M = batch)
-            act = ops.raw_gemm_swiglu(x2, wgu, need_gu=False)[1].view(*x.shape[:-1], -1)
+            act = ops.linear_swiglu(x2, wgu).view(*x.shape[:-1], -1)
         else:
             act = ops.swiglu(mlp._fused().linear(x))
         return ops.linear(act, mlp.down_proj.weight, residual=h)

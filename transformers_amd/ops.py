@@ -867,6 +867,19 @@ def swiglu(gu):
     return T.swiglu(gu)
 
 
+def rope_inplace(x2d, cos, sin, seq, nheads, head_dim):
+    """Inference only: the rotary embedding applied IN PLACE to the first `nheads` heads of every row of x2d [tokens, row]
+    (a fresh q|k|v product nobody else holds: the cached forward, models/llama.py)."""
+    T.rope_(x2d, cos, sin, int(seq), int(nheads), int(head_dim), False)
+    return x2d
+
+
+def linear_swiglu(x2, wgu):
+    """Inference only: SiLU(x2 . Wg^T) * (x2 . Wu^T) for wgu = [Wg ; Wu] from ONE product (`gemm_swiglu_supported` shapes: the
+    GEMM epilogue, or the weight-streaming kernel at M <= 16), gate | up themselves not kept."""
+    return T.gemm_swiglu(x2, wgu, False)[1]
+
+
 def bias_act(x, bias, act):
     return T.bias_act(x, bias, int(act))
 
