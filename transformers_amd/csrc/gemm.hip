@@ -1499,7 +1499,9 @@ extern "C" int tamd_gemm_trace(const void* A, const void* B, void* C, int64_t M,
 static int gemm_choose_splits(int64_t M, int64_t N, int64_t K, int flags, int epilogue, int* stages_per_split) {
   *stages_per_split = 0;
   if (K % kXK != 0 || (N % 4) != 0 || epilogue == TAMD_EPI_BIAS_ACT || epilogue < TAMD_EPI_NONE || epilogue > TAMD_EPI_ACCUM) return 1;
-  if ((flags & (TAMD_GEMM_A_KM | TAMD_GEMM_B_KN)) == 0 && M <= kGemvMaxRows && epilogue <= TAMD_EPI_RESIDUAL) return 1;  // gemv.hip
+  if ((flags & (TAMD_GEMM_A_KM | TAMD_GEMM_B_KN)) == 0 && M <= kGemvMaxRows && epilogue <= TAMD_EPI_RESIDUAL &&
+      !(M > kGemvValuRows && N >= 65536))
+    return 1;  // gemv.hip
   const int64_t tiles = ceil_div(M, kBM) * ceil_div(N, kBN), nst = K / kXK;
   if (nst < 32) return 1;
   if ((flags & (TAMD_GEMM_A_KM | TAMD_GEMM_B_KN)) == 0 && tiles <= kSmMaxBigTiles && nst < 64) return 1;
@@ -1565,7 +1567,10 @@ static int gemm_run(GemmArgs& g, int flags, int epilogue, int act, int dtype, vo
   flags &= 0xff;
   // a cached decode step's projections (M = batch <= 8, row-major weight): streamed by the VALU kernel of gemv.hip -- bound by
   // HBM, where N / 256 MFMA tiles with one live row each are not.  A schedule hint keeps the product on the tile kernels.
-  if (sched == 0 && flags == 0 && M <= kGemvMaxRows &&
+  // (except the widest products at 5+ rows -- an lm_head of 128256 rows: 1 GB of weights is 501 tile columns, the 256 x 256
+  // kernel streams it at 5.4 TB/s, 188 us, where the MFMA streaming kernel re-reads X per workgroup: 207-225 us,
+  // profiles/r04s_gemv_bench.jsonl)
+  if (sched == 0 && flags == 0 && M <= kGemvMaxRows && !(M > kGemvValuRows && N >= 65536 && K % kXK == 0) &&
       (epilogue == TAMD_EPI_NONE || epilogue == TAMD_EPI_BIAS || epilogue == TAMD_EPI_RESIDUAL)) {
     const GemvArgs v{g.A, g.B, g.C, g.bias, g.R, M, N, K, g.lda, g.ldb, g.ldc, g.ldr};
     return gemv_run(v, epilogue, dtype, TAMD_STREAM(stream));

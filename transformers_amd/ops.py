@@ -222,7 +222,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int, flags: int = 0) 
     two in step."""
     if k % 64 or n % 4 or epilogue not in (EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_ACCUM):
         return 0
-    if (flags & 3) == 0 and m <= 16 and epilogue <= EPI_RESIDUAL:  # the streaming kernel of csrc/gemv.hip
+    if (flags & 3) == 0 and m <= 16 and epilogue <= EPI_RESIDUAL and not (m > 4 and n >= 65536):  # csrc/gemv.hip
         return 0
     tiles, nst = -(-m // 256) * -(-n // 256), k // 64
     if nst < 32:

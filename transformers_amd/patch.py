@@ -87,6 +87,14 @@ def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bo
     from . import graph_stack
 
     graph_stack.attach(model)  # forward-only calls of a whole decoder stack replay one HIP graph (graph_stack.py)
+    # `generate` with a pre-allocated cache wraps the forward in torch.compile on its own (generation/utils.py:2119-2160,
+    # 2862-2863).  Our layers are opaque custom ops around host-side dispatch: the tracer gains nothing and breaks the graph in
+    # every layer -- 30.8 ms per token against 5.5 without it at Llama-3-8B dimensions (profiles/r04t_decode_bench_32.jsonl).
+    # The reference's own switch turns it off; a caller's explicit GenerationConfig still wins.
+    gc = getattr(model, "generation_config", None)
+    if gc is not None and n > 0 and not getattr(gc, "disable_compile", False):
+        model.__dict__["_tamd_disable_compile_was"] = getattr(gc, "disable_compile", None)
+        gc.disable_compile = True
     if fuse_loss and getattr(model, "loss_type", None) == "ForCausalLM":
         from .ops import causal_lm_loss
 
@@ -118,6 +126,8 @@ def revert(model: nn.Module) -> nn.Module:
     if isinstance(getattr(model, "loss_function", None), _LossDispatch):
         model.loss_function = model.loss_function.reference
     model.__dict__.pop("forward", None)  # the instance-level fused forward, if installed
+    if "_tamd_disable_compile_was" in model.__dict__ and getattr(model, "generation_config", None) is not None:
+        model.generation_config.disable_compile = model.__dict__.pop("_tamd_disable_compile_was")
     from . import graph_stack
 
     graph_stack.detach(model)
