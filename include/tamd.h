@@ -235,7 +235,11 @@ enum tamd_gemm_epilogue {
  * and, through the layout flags, its two backward products dX = dY.W and dW = dY^T.X.
  * bf16/f16 only.  Requirements: N % 8 == 0, lda/ldb/ldc/ldr % 8 == 0; K % 8 == 0 unless both operands are
  * k-major (then K is a row count and unrestricted: dW over a ragged token count); M % 8 == 0 with TAMD_GEMM_A_KM.
- * bias: [N] or NULL; R: [M, ldr] or NULL (for TAMD_EPI_ACCUM, R is ignored and C is read). */
+ * bias: [N] or NULL; R: [M, ldr] or NULL (for TAMD_EPI_ACCUM, R is ignored and C is read).
+ * Round 4: row-major products with M <= 16 and a plain / bias / residual epilogue -- the projections of a cached decode step,
+ * one new token per sequence (modeling_llama.py:254-256, 280, 174-176 with hidden_states [batch, 1, hidden]) -- are bound by
+ * the weight bytes, not by the matrix pipe: without a schedule hint they run on the weight-streaming kernels of csrc/gemv.hip
+ * (same roundings; fp32 summation order differs from the MFMA tiles'), except the widest ones (N >= 65536) at 5+ rows. */
 int tamd_gemm(const void* A, const void* B, void* C, const void* bias, const void* R, int64_t M, int64_t N,
               int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int flags, int epilogue, int act,
               int dtype, tamd_stream_t stream);
