@@ -3,6 +3,7 @@ dimensions, weights cycled through > 1 GB so that they come from HBM as in the m
 ours, for the 256 x 256 tile kernels (schedule hint) and for torch (hipBLASLt / rocBLAS).
    python tools/gemv_bench.py > gpurun_out/<tag>_gemv_bench.jsonl"""
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -32,7 +33,7 @@ CASES = [("q|k|v", 6144, 4096, "none"), ("o_proj + residual", 4096, 4096, "res")
 for name, n, k, epi in CASES:
     copies = max(2, int(1.2e9 // (n * k * 2)) + 1)
     ws = [(torch.randn(n, k, device=dev) * 0.02).bfloat16() for _ in range(copies)]
-    for m in (1, 2, 4, 8, 16):
+    for m in [int(v) for v in os.environ.get("GEMV_BENCH_ROWS", "1,2,4,8,16").split(",")]:
         x = torch.randn(m, k, device=dev).bfloat16()
         res = torch.randn(m, n, device=dev).bfloat16()
         if epi == "swiglu":
