@@ -1231,6 +1231,28 @@ def test_gemm_group_weight_gradients(env):
                     assert rel_err(acc[i], want) < 0.00015, (group, i)
                 else:
                     assert torch.equal(acc[i], want), (group, i)
+    # the row-major layout (flags 0: C_p = A_p [M, K] . B_p [N, K]^T), split (one 2-tile + one 1-tile product over 32 stages) and
+    # unsplit: the single products' bits when nothing is split
+    for shapes in ([(264, 136, 2048), (128, 72, 2048)], [(264, 136, 128)]):
+        a_s = [torch.randn(m, k).bfloat16().to(dev) for (m, n, k) in shapes]
+        b_s = [(torch.randn(n, k) * 0.1).bfloat16().to(dev) for (m, n, k) in shapes]
+        c_s = [torch.full((m, n), 3.0, dtype=torch.bfloat16, device=dev) for (m, n, k) in shapes]
+        pr = (_cabi.GemmProblem * len(shapes))()
+        for i, (m, n, k) in enumerate(shapes):
+            pr[i] = _cabi.GemmProblem(a_s[i].data_ptr(), b_s[i].data_ptr(), c_s[i].data_ptr(), m, n, k, k, k, n)
+        need = lib.tamd_gemm_group_workspace_bytes(ctypes.byref(pr), len(shapes), 0)
+        ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+        sh = ops.backend().stream(ws)
+        st = lib.tamd_gemm_group(ctypes.byref(pr), len(shapes), 0, ops.EPI_NONE, _cabi.TAMD_BF16, ws.data_ptr(), need,
+                                 ctypes.c_void_p(sh) if sh else None)
+        assert st == 0, (shapes, st)
+        for i, (m, n, k) in enumerate(shapes):
+            single = ops.raw_gemm(a_s[i], b_s[i], sched="fl")
+            assert rel_err(c_s[i], a_s[i].float() @ b_s[i].float().t()) < 0.0034, (shapes, i)
+            if need == 0:
+                assert torch.equal(c_s[i], single), (shapes, i)
+            else:
+                assert rel_err(c_s[i], single) < 0.00015, (shapes, i)
     # argument checks: more than 4 products, mixed layouts, K % 64
     pr = (_cabi.GemmProblem * 1)()
     a = torch.randn(96, 64).bfloat16().to(dev)
