@@ -10,8 +10,5 @@ timeout 300 python -m pytest tests/test_kernels.py -q -m gpu -x -k "gemv" > $out
 timeout 400 python tools/gemv_bench.py > $out/${tag}_gemv_bench.jsonl 2> $out/${tag}_gemv_bench.err; cut -c1-260 $out/${tag}_gemv_bench.jsonl; tail -2 $out/${tag}_gemv_bench.err
 DECODE_BENCH_BATCHES=1,8,16 DECODE_BENCH_ARM=tamd timeout 400 python tools/decode_bench.py generate >> $out/${tag}_decode_bench_32.jsonl 2>> $out/${tag}_decode_bench.err
 cut -c1-300 $out/${tag}_decode_bench_32.jsonl
-TAMD_GEMV_VALU_ROWS=0 timeout 400 python tools/gemv_bench.py > $out/${tag}_gemv_bench_mfma_only.jsonl 2>> $out/${tag}_gemv_bench.err; python - <<'PY'
-import json,sys,os
-out=os.environ.get('OUTDIR','gpurun_out')
-PY
+TAMD_GEMV_VALU_ROWS=0 timeout 400 python tools/gemv_bench.py > $out/${tag}_gemv_bench_mfma_only.jsonl 2>> $out/${tag}_gemv_bench.err
 grep -h '"M": [124],' $out/${tag}_gemv_bench_mfma_only.jsonl | cut -c1-200

@@ -565,8 +565,6 @@ std::tuple<Tensor, Tensor> linear_act_pre(const Tensor& x2, const Tensor& w, con
 // dW[M, N] = dy[K, M]^T . x[K, N] with the M rows stored into `segs` (each [rows_i, N] contiguous: tamd_gemm_seg) -- the weight
 // gradient of a fused q|k|v / gate|up projection written straight into the members' own gradient buffers
 void gemm_dw_segments(const Tensor& dy, const Tensor& x, const std::vector<Tensor>& segs) {
-  std::vector<const Tensor*> all = {&dy, &x};
-  for (const Tensor& t : segs) all.push_back(&t);
   Launch L({&dy, &x, &segs[0]});
   TORCH_CHECK(dy.dim() == 2 && x.dim() == 2 && dy.stride(1) == 1 && x.stride(1) == 1 && dy.size(0) == x.size(0),
               "tamd: gemm_dw_segments takes dy [K, M] and x [K, N]");
@@ -611,9 +609,6 @@ bool half_type(const Tensor& t) { return t.scalar_type() == at::kBFloat16 || t.s
 // 7 .. 16 (csrc/gemm.hip "grouped launch").  Pairs the grouped kernel does not take (K % 64) fall back to one product each.
 std::vector<Tensor> gemm_dw_group(const std::vector<Tensor>& dys, const std::vector<Tensor>& xs) {
   TORCH_CHECK(dys.size() == xs.size() && !dys.empty() && dys.size() <= 4, "tamd: gemm_dw_group takes 1..4 (dy, x) pairs");
-  std::vector<const Tensor*> all;
-  for (const Tensor& t : dys) all.push_back(&t);
-  for (const Tensor& t : xs) all.push_back(&t);
   Launch L({&dys[0], &xs[0]});
   std::vector<tamd_gemm_problem> pr(dys.size());
   std::vector<Tensor> outs;

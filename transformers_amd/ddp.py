@@ -45,6 +45,9 @@ class _HookState:
 def _note_views(bucket) -> None:
     for p, g in zip(bucket.parameters(), bucket.gradients()):
         _VIEWS[id(p)] = (weakref.ref(p), g)
+    if len(_VIEWS) > 65536:  # (models built and dropped in a loop: entries of dead parameters pin their old buckets)
+        for k in [k for k, (r, _) in _VIEWS.items() if r() is None]:
+            del _VIEWS[k]
 
 
 def _allreduce_hook(state: _HookState, bucket):
