@@ -402,6 +402,7 @@ def main():
     if use_timer:
         timer.install()
     net = model
+    zero_copy_error = None
     if ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
 
@@ -413,7 +414,11 @@ def main():
             from transformers_amd import ddp as tamd_ddp
 
             tamd_ddp.reset()
-            tamd_ddp.enable_zero_copy(net)
+            try:
+                tamd_ddp.enable_zero_copy(net)
+            except Exception as e:  # (the measurement goes on with torch's copies; the line says so)
+                args.no_ddp_zero_copy = True
+                zero_copy_error = repr(e)
 
     def step():
         if not backward:
@@ -537,6 +542,8 @@ def main():
             from transformers_amd import ddp as tamd_ddp
 
             line["ddp_zero_copy"] = dict(tamd_ddp.STATS, enabled=not args.no_ddp_zero_copy)
+            if zero_copy_error:
+                line["ddp_zero_copy"]["error"] = zero_copy_error
         if roofline is not None and world == 1 and args.config == "llama3-8b":
             try:
                 roofline["clock_probe"] = clock_probe(dev)
