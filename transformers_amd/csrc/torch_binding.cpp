@@ -1134,6 +1134,7 @@ const bool kBertPrescale = env_flag("TAMD_BERT_PRESCALE", true);
 // the layer's four weight gradients as ONE grouped launch at the end of its backward (gemm_dw_group) instead of four split-K
 // products where they arise: A/B switch
 const bool kBertGroupDw = env_flag("TAMD_BERT_GROUP_DW", true);
+const bool kLlamaGroupDw = env_flag("TAMD_LLAMA_GROUP_DW", false);  // llama_layer_bwd: A/B switch (see there)
 
 struct Qkv {
   Tensor q, k, v;
@@ -1200,6 +1201,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   // dst_*: the weight gradients' destinations (transformers_amd/ddp.py: DDP's bucket views) -- all seven or none.  With them
   // the dW GEMMs store there and the corresponding outputs come back empty.
   const bool to_dst = dst_q && dst_k && dst_v && dst_o && dst_g && dst_u && dst_d;
+  // the four weight gradients as ONE grouped launch at the end (gemm_dw_group): at 32768 tokens they are 384 + 256 + 1792 + 896
+  // = 3328 tiles = exactly 13 rounds of the 256 CUs -- one by one q|k|v (1.5 rounds) and down_proj (3.5) go through split-K
+  // (fp32 partials + a reduction launch each) to fill their last round.  (Not with DDP destinations: those are seven buffers.)
+  const bool group_dw = kLlamaGroupDw && !to_dst;
   const int64_t b = h_in.size(0), s = h_in.size(1), hd = h_in.size(2), t = b * s;
   Tensor x = contig(h_in).view({t, hd});
   Tensor dh = contig(d_hout).view({t, hd});
@@ -1213,25 +1218,30 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
     std::tie(d_gu, act) = k_swiglu_bwd(gu, d_act, true);
   }
   d_act = Tensor();
-  Tensor dwd = to_dst ? (gemm_plain(dh, act, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_d), nothing(h_in))
-                      : gemm_plain(dh, act, true, true);  // [hd, I]
-  act = Tensor();
+  Tensor dwd;  // [hd, I]
+  if (!group_dw) {
+    dwd = to_dst ? (gemm_plain(dh, act, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_d), nothing(h_in))
+                 : gemm_plain(dh, act, true, true);
+    act = Tensor();
+  }
   Tensor d_xn2 = gemm_plain(d_gu, wgu, false, true);  // [T, hd]
   Tensor dwgu;                                        // [2I, hd]
   if (to_dst) {
     gemm_dw_segments(d_gu, xn2, {*dst_g, *dst_u});
     dwgu = nothing(h_in);
-  } else {
+  } else if (!group_dw) {
     dwgu = gemm_plain(d_gu, xn2, true, true);
   }
-  d_gu = Tensor();
+  if (!group_dw) d_gu = Tensor();
   auto [d_hmid, dw_ln2] = k_rmsnorm_bwd(d_xn2, h_mid, w_ln2, rstd2, dh);
   d_xn2 = Tensor();
   // ---- attention
   Tensor d_o = gemm_plain(d_hmid, wo, false, true);  // [T, Hq*D]
-  Tensor dwo = to_dst ? (gemm_plain(d_hmid, o.view({t, hq * d}), true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_o),
-                         nothing(h_in))
-                      : gemm_plain(d_hmid, o.view({t, hq * d}), true, true);
+  Tensor dwo;
+  if (!group_dw)
+    dwo = to_dst ? (gemm_plain(d_hmid, o.view({t, hq * d}), true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_o),
+                    nothing(h_in))
+                 : gemm_plain(d_hmid, o.view({t, hq * d}), true, true);
   Tensor d_qkv = at::empty_like(qkv);
   Qkv f = split_qkv(qkv, b, s, hq, hkv, d), g = split_qkv(d_qkv, b, s, hq, hkv, d);
   const bool fused_rope = kFuseRopeBwd && attn_bwd_rope_supported(f.q, f.k, cos, d);  // the transposed rotary inside the kernels
@@ -1244,10 +1254,14 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   if (to_dst) {
     gemm_dw_segments(d_qkv, xn, {*dst_q, *dst_k, *dst_v});
     dwqkv = nothing(h_in);
-  } else {
+  } else if (!group_dw) {
     dwqkv = gemm_plain(d_qkv, xn, true, true);
   }
   auto [d_hin, dw_ln1] = k_rmsnorm_bwd(d_xn, x, w_ln1, rstd1, d_hmid);
+  if (group_dw) {
+    std::vector<Tensor> dws = gemm_dw_group({dh, d_gu, d_hmid, d_qkv}, {act, xn2, o.view({t, hq * d}), xn});
+    dwd = dws[0], dwgu = dws[1], dwo = dws[2], dwqkv = dws[3];
+  }
   return {d_hin.view({b, s, hd}), dw_ln1, dwqkv, dwo, dw_ln2, dwgu, dwd};
 }
 
