@@ -65,7 +65,7 @@ CONFIGS = {
 }
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-GEMM_TRAFFIC_FILES = ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
+GEMM_TRAFFIC_FILES = ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
 
 
 def llama_flops_per_token(m, seq, backward=True) -> float:
@@ -180,6 +180,57 @@ def clock_probe(dev, m=32768, n=28672, k=4096):
         ops._set_backend(prev)
 
 
+def layer_forward_probe(model, dev, batch, seq, iters=10, warm=3):
+    """The north star's own figure (BASELINE.json): ONE `LlamaDecoderLayer.forward`
+    (modeling_llama.py:295-324 -- RMSNorm, fused q|k|v projection, rotary embedding, causal GQA attention, o_proj + residual,
+    RMSNorm, gate|up + SiLU*up, down_proj + residual) of the benchmarked model at (batch, seq, hidden) as a fraction of the
+    dense bf16 MFMA peak.  Layer 0 of the model `main()` has just timed, its weights, the same op (`torch.ops.tamd.llama_layer`);
+    HIP events on the launch stream around `iters` forwards, after the timed region and outside it.  `ms` is the forward
+    alone (no_grad: the gate|up pre-activations are not written), `ms_training_forward` the forward of a training step
+    (everything the backward needs is saved)."""
+    import torch
+
+    layer = model.model.layers[0]
+    mcfg = model.config
+    h, i = mcfg.hidden_size, mcfg.intermediate_size
+    d = h // mcfg.num_attention_heads
+    nq, nkv = mcfg.num_attention_heads * d, mcfg.num_key_value_heads * d
+    flop = batch * seq * (2 * h * (nq + 2 * nkv) + 2 * nq * h + 3 * 2 * h * i + 4 * nq * seq / 2)
+    x = torch.randn(batch, seq, h, device=dev).to(next(layer.parameters()).dtype)
+    pos = torch.arange(seq, device=dev)[None]
+    with torch.no_grad():
+        pe = model.model.rotary_emb(x, pos)
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def fwd():
+        with torch.no_grad():
+            return layer(x, position_embeddings=pe)
+
+    xg = x.clone().requires_grad_(True)
+
+    def fwd_train():
+        return layer(xg, position_embeddings=pe)
+
+    ms = timed(fwd)
+    ms_t = timed(fwd_train)
+    return {"what": f"one LlamaDecoderLayer.forward at ({batch}, {seq}, {h}): {flop / 1e12:.3f} TFLOP algorithmic "
+                    "(causal attention at half), layer 0 of the timed model, HIP events after the timed region",
+            "ms": ms, "tflops": flop / ms / 1e9, "frac_of_2500": flop / ms / 1e9 / PEAK_BF16_TFLOPS,
+            "ms_training_forward": ms_t, "frac_of_2500_training_forward": flop / ms_t / 1e9 / PEAK_BF16_TFLOPS,
+            "iters": iters}
+
+
 def cpu_baseline(model_cfg, seq, layers, threads=None, iters=3):
     """Reference eager path on the host cores: ONE decoder layer at (1, seq, hidden), bf16, fwd+bwd, averaged."""
     import torch
@@ -267,6 +318,96 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def ddp_report(args, net, model, fwd, dev, world, ddp_ms):
+    """What an N-GPU line says about the data-parallel step beyond its throughput.  Runs AFTER the timed region,
+    the same code on every rank (its two collectives are symmetric); every leg is fenced so that a failure becomes an `error`
+    entry instead of taking the measured number down.
+      gradient_bytes / buckets_per_step -- what DDP all-reduces per step, in how many buckets;
+      compute_only_ms       -- `--steps`-independent: 3 untimed steps under `net.no_sync()` (same model, same batch, no all-reduce);
+      exposed_allreduce_ms  -- ms_per_step - compute_only_ms (max over ranks): the part of the collective the backward did not hide;
+      busbw_GBps            -- 2 (N-1)/N x gradient_bytes / exposed_allreduce_ms: the ring all-reduce's bus bandwidth IF the exposed
+                               time were the whole collective (a lower bound of the real one: most of it overlaps);
+      verify (--verify-ddp) -- reduced gradients, zero-copy hand-over vs torch's copies, on one fixed batch."""
+    import torch
+    import torch.distributed as dist
+
+    from transformers_amd import ddp as tamd_ddp
+
+    out = {}
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)  # (the world-2 gloo test runs this on the CPU model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    gbytes = sum(p.numel() * p.element_size() for p in params)
+    out["gradient_bytes"] = gbytes
+    out["buckets_per_step"] = None
+    if tamd_ddp.STATS.get("buckets_reduced"):
+        out["buckets_per_step"] = tamd_ddp.STATS["buckets_reduced"] / max(args.steps + args.warmup, 1)
+
+    def one_step(sync=True):
+        ctx = net.no_sync() if not sync else torch.enable_grad()
+        with ctx:
+            o = fwd(net)
+            o.loss.backward()
+
+    if args.verify_ddp:
+        try:
+            if args.no_ddp_zero_copy:
+                raise RuntimeError("--verify-ddp compares against the zero-copy hand-over: drop --no-ddp-zero-copy")
+            before = dict(tamd_ddp.STATS)
+            model.zero_grad(set_to_none=True)
+            one_step()
+            sync()
+            zc_layers = tamd_ddp.STATS["zero_copy_layers"] - before["zero_copy_layers"]
+            # (per-parameter norms and a low-memory copy: the gradients are 16 GB for the 8B model, kept once)
+            kept = [p.grad.detach().clone() for p in params]
+            model.zero_grad(set_to_none=True)
+            was = tamd_ddp.set_enabled(False)
+            try:
+                one_step()
+                sync()
+            finally:
+                tamd_ddp.set_enabled(was)
+            worst = torch.zeros(2, device=dev, dtype=torch.float64)
+            for p, g0 in zip(params, kept):
+                g1 = p.grad.detach()
+                den = g1.double().norm()
+                err = (g0.double() - g1.double()).norm() / den.clamp_min(1e-30)
+                worst[0] = torch.maximum(worst[0], err)
+                worst[1] = torch.maximum(worst[1], (g0 != g1).any().double())
+            del kept
+            if world > 1:
+                dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            out["verify"] = dict(max_rel_err=worst[0].item(), bit_identical=worst[1].item() == 0.0, parameters=len(params),
+                                 zero_copy_layers_in_checked_step=zc_layers, ranks=world,
+                                 what="reduced gradients of one step with the dW GEMMs writing into the bucket views vs one "
+                                      "step with torch's copies into the buckets, same batch; worst parameter, worst rank")
+            model.zero_grad(set_to_none=True)
+        except Exception as e:  # (symmetric on every rank: same code, same state)
+            out["verify"] = {"error": repr(e)}
+    if not args.no_ddp_breakdown:
+        try:
+            model.zero_grad(set_to_none=True)
+            n = 3
+            one_step(sync=False)  # (untimed: the first no_sync step re-points nothing, but warms the path)
+            model.zero_grad(set_to_none=True)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                one_step(sync=False)
+                model.zero_grad(set_to_none=True)
+            sync()
+            cms = (time.perf_counter() - t0) / n * 1e3
+            t = torch.tensor([cms], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cms = t.item()
+            exposed = max(ddp_ms - cms, 0.0)
+            out.update(compute_only_ms=cms, exposed_allreduce_ms=exposed,
+                       busbw_GBps=(2.0 * (world - 1) / world * gbytes / (exposed * 1e-3) / 1e9) if (world > 1 and exposed > 0) else None)
+        except Exception as e:
+            out["breakdown_error"] = repr(e)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def build_llama(c, dev, args):
     import torch
@@ -311,6 +452,13 @@ def main():
     ap.add_argument("--no-ddp-zero-copy", action="store_true",
                     help="under DDP: leave the gradient hand-over to torch (copy into the bucket views) instead of writing the "
                          "weight-gradient GEMMs straight into them (transformers_amd/ddp.py)")
+    ap.add_argument("--verify-ddp", action="store_true",
+                    help="under DDP: two extra untimed steps on one fixed batch after the timed region -- the reduced gradients "
+                         "of a step with the zero-copy hand-over against a step with torch's own copies into the buckets, "
+                         "norm-relative per parameter, worst over parameters and ranks -> `ddp_verify` in the line")
+    ap.add_argument("--no-ddp-breakdown", action="store_true",
+                    help="under DDP: skip the untimed no_sync() steps after the timed region that price the exposed all-reduce "
+                         "(`ddp.exposed_allreduce_ms`, `ddp.busbw_GBps`)")
     args = ap.parse_args()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
@@ -493,10 +641,13 @@ def main():
         torch.cuda.synchronize()
         timer.enabled = False
         graph_stack.set_enabled(was)
+    dt_min = dt_max = dt
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, -dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
+        dt, dt_min = t[0].item(), -t[1].item()
+        dt_max = dt
+    ddp_extra = ddp_report(args, net, model, fwd, dev, world, dt / args.steps * 1e3) if (ddp and backward) else None
     tokens = batch * seq * world * args.steps
     value = tokens / dt
     if rank == 0:
@@ -544,9 +695,23 @@ def main():
             line["ddp_zero_copy"] = dict(tamd_ddp.STATS, enabled=not args.no_ddp_zero_copy)
             if zero_copy_error:
                 line["ddp_zero_copy"]["error"] = zero_copy_error
+            line["ddp"] = dict(ms_per_step_min_rank=dt_min / args.steps * 1e3, ms_per_step_max_rank=dt_max / args.steps * 1e3,
+                               bucket_mb=args.bucket_mb, **(ddp_extra or {}))
+            if ddp_extra and "verify" in ddp_extra:
+                line["ddp_verify"] = line["ddp"].pop("verify")
+        if kind == "llama" and world == 1 and not args.hip_graph:
+            # the north star's own number: one decoder layer's forward as a fraction of the MFMA peak (outside the timed region)
+            try:
+                fb = dict(transformers_amd.fallback_calls())
+                line["layer_forward"] = layer_forward_probe(model, dev, batch, seq)
+                line["layer_forward"]["fallback_calls"] = sum(transformers_amd.fallback_calls().values()) - sum(fb.values())
+            except Exception as e:  # diagnostics must never take the headline number down
+                line["layer_forward"] = {"error": repr(e)}
         if roofline is not None and world == 1 and args.config == "llama3-8b":
             try:
                 roofline["clock_probe"] = clock_probe(dev)
+                if "ms" in line.get("layer_forward", {}):
+                    line["layer_forward"]["clock_GHz"] = roofline["clock_probe"]["clock_GHz"]
             except Exception as e:  # diagnostics only
                 roofline["clock_probe"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and args.config in ("llama3-8b", "bert-base"):

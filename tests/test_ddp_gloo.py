@@ -82,7 +82,16 @@ def _worker_zero_copy(rank, world, port, out_dir, kind):
             per_step.append(dict(tddp.STATS))
         grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
         aliased = all(tddp._VIEWS[id(p)][1].data_ptr() == p.grad.data_ptr() for p in model.parameters() if id(p) in tddp._VIEWS)
-    torch.save({"grads": grads, "stats": per_step, "aliased": aliased, "loss": out.loss.item()}, f"{out_dir}/rank{rank}.pt")
+        # what `bench.py --gpus N --verify-ddp` runs after its timed region (the same function, on every rank): the reduced
+        # gradients of a zero-copy step against a step with torch's copies, then the no_sync() steps that price the all-reduce
+        import argparse
+
+        import bench
+
+        a = argparse.Namespace(verify_ddp=True, no_ddp_breakdown=False, no_ddp_zero_copy=False, steps=3, warmup=0)
+        report = bench.ddp_report(a, net, model, lambda n: n(**_batch(cfg, rank, kind)), torch.device("cpu"), world, 1e9)
+    torch.save({"grads": grads, "stats": per_step, "aliased": aliased, "loss": out.loss.item(), "report": report},
+               f"{out_dir}/rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -160,6 +169,13 @@ def test_ddp_zero_copy_gradients_world2_gloo(tmp_path, kind):
     st = r[0]["stats"]
     assert st[0]["zero_copy_layers"] == 0                      # step 1: nothing registered yet
     assert st[2]["zero_copy_layers"] - st[1]["zero_copy_layers"] == 2, st  # step 3: both decoder layers wrote into the buckets
+    for i in range(world):  # bench.ddp_report: the two hand-overs reduce to the same gradients; the breakdown legs ran
+        rep = r[i]["report"]
+        assert "error" not in rep["verify"] and "breakdown_error" not in rep, rep
+        assert rep["verify"]["zero_copy_layers_in_checked_step"] == 2 and rep["verify"]["ranks"] == world
+        assert rep["verify"]["bit_identical"] and rep["verify"]["max_rel_err"] == 0.0, rep["verify"]
+        assert rep["compute_only_ms"] > 0 and rep["busbw_GBps"] is not None and rep["buckets_per_step"] >= 1
+    assert r[0]["report"]["verify"] == r[1]["report"]["verify"]
     for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
         sys.path.insert(0, str(p))
     import transformers_amd

@@ -1643,7 +1643,9 @@ extern "C" int tamd_gemm_seg(const void* A, const void* B, void* const* C_segs, 
     g.C_seg2 = C_segs[2];
     g.seg_row2 = seg_rows[0] + seg_rows[1];
   }
-  return gemm_run(g, flags | (workspace ? 0 : TAMD_GEMM_SCHED_FL), epilogue, TAMD_ACT_NONE, dtype, workspace, workspace_bytes, stream);
+  // only gemm_fl_kernel and its split-K honour the segments: always pin the schedule (a TAMD_GEMM=pp in the environment must not
+  // send a segmented product to the ping-pong kernel, which would store past the first segment); split-K stays possible
+  return gemm_run(g, flags | TAMD_GEMM_SCHED_FL, epilogue, TAMD_ACT_NONE, dtype, workspace, workspace_bytes, stream);
 }
 
 // ---- grouped launch (kernels: gemm_fl_group_kernel, splitk_reduce_group_kernel)

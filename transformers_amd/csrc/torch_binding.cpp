@@ -484,7 +484,17 @@ Tensor k_gemm(const Tensor& a, const Tensor& b, bool a_km, bool b_kn, const OptT
   const int64_t k_a = a_km ? a.size(0) : a.size(1), m = a_km ? a.size(1) : a.size(0);
   const int64_t k_b = b_kn ? b.size(0) : b.size(1), n = b_kn ? b.size(1) : b.size(0);
   TORCH_CHECK(k_a == k_b, "tamd: gemm K mismatch: ", a.sizes(), " x ", b.sizes(), " (a_km=", a_km, ", b_kn=", b_kn, ")");
-  if (!out.defined()) out = at::empty({m, n}, a.options());
+  if (!out.defined()) {
+    out = at::empty({m, n}, a.options());
+  } else {  // a caller's destination (a DDP bucket view, a `.grad` buffer): the kernel stores 16 bytes per lane into it
+    TORCH_CHECK(out.dim() == 2 && out.size(0) == m && out.size(1) == n, "tamd: gemm out has shape ", out.sizes(), ", expected [", m,
+                ", ", n, "]");
+    TORCH_CHECK(out.scalar_type() == a.scalar_type() && out.device() == a.device(), "tamd: gemm out must have the operands' dtype "
+                "and device");
+    TORCH_CHECK(out.stride(1) == 1 && out.stride(0) % 8 == 0 && (reinterpret_cast<uintptr_t>(out.const_data_ptr()) % 16) == 0,
+                "tamd: gemm out must be a row-major view with a 16-byte aligned base and a row stride that is a multiple of 8 "
+                "elements");
+  }
   const int flags = (a_km ? TAMD_GEMM_A_KM : 0) | (b_kn ? TAMD_GEMM_B_KN : 0) | (int)(sched << 8);
   Tensor residual = residual_ ? *residual_ : Tensor();
   size_t ws_bytes = 0;

@@ -32,7 +32,9 @@ import torch.distributed as dist
 
 # id(parameter) -> (weak reference to the parameter, its gradient view inside the current bucket)
 _VIEWS: dict = {}
-STATS = {"zero_copy_layers": 0, "ordinary_layers": 0}
+STATS = {"zero_copy_layers": 0, "ordinary_layers": 0, "buckets_reduced": 0, "collective": None}
+_ENABLED = True  # set_enabled(False): every layer takes the ordinary hand-over (torch copies into the buckets) -- the A/B arm of
+#                  `bench.py --verify-ddp`; the hook keeps averaging the buckets in place either way
 _WORLD1_COLLECTIVE = os.environ.get("TAMD_DDP_WORLD1_COLLECTIVE", "0") == "1"  # A/B switch of the world-size-1 shortcut below
 
 
@@ -40,6 +42,13 @@ class _HookState:
     def __init__(self, process_group=None):
         self.group = process_group
         self.buckets_seen = 0
+
+
+def set_enabled(on: bool) -> bool:
+    """Switch the zero-copy hand-over on / off (the communication hook stays registered).  Returns the previous setting."""
+    global _ENABLED
+    was, _ENABLED = _ENABLED, bool(on)
+    return was
 
 
 def _note_views(bucket) -> None:
@@ -54,6 +63,7 @@ def _allreduce_hook(state: _HookState, bucket):
     """DDP communication hook: remember where each parameter's gradient lives, then average the bucket in place."""
     _note_views(bucket)
     state.buckets_seen += 1
+    STATS["buckets_reduced"] += 1
     group = state.group if state.group is not None else dist.group.WORLD
     buf = bucket.buffer()
     world = dist.get_world_size(group)
@@ -61,12 +71,15 @@ def _allreduce_hook(state: _HookState, bucket):
     if world == 1 and not _WORLD1_COLLECTIVE:
         # nothing to exchange.  (RCCL would still run its AVG kernel over the whole bucket -- unlike an in-place SUM it is not
         # a no-op for one rank -- beside the backward: +50 ms on the Llama-3-8B step, profiles/r04f_ddp_ab.jsonl.)
+        STATS["collective"] = "none (one rank)"
         fut = torch.futures.Future()
         fut.set_result(buf)
         return fut
     if backend == "nccl":  # RCCL: the average is part of the collective
+        STATS["collective"] = "all_reduce AVG in place (RCCL)"
         fut = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=True).get_future()
         return fut.then(lambda f: f.value()[0])
+    STATS["collective"] = f"div + all_reduce SUM ({backend})"
     buf.div_(world)  # (gloo, the CPU test backend, has no AVG)
     fut = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True).get_future()
     return fut.then(lambda f: f.value()[0])
@@ -83,13 +96,18 @@ def enable_zero_copy(ddp_model, process_group=None) -> _HookState:
 
 def reset() -> None:
     _VIEWS.clear()
-    STATS["zero_copy_layers"] = STATS["ordinary_layers"] = 0
+    STATS["zero_copy_layers"] = STATS["ordinary_layers"] = STATS["buckets_reduced"] = 0
+    STATS["collective"] = None
 
 
 def destinations(params: Sequence[torch.nn.Parameter]) -> Optional[list]:
     """Bucket views to write the gradients of `params` into, or None when any of them has none / already holds a gradient /
-    does not match (moved, resized, another dtype)."""
-    if not _VIEWS:
+    does not match (moved, resized, another dtype) / is not 16-byte aligned (the GEMM way out stores 16 bytes per lane: a bf16
+    parameter whose element count is not a multiple of 8 earlier in the bucket misaligns every later view -- those layers
+    take the ordinary path)."""
+    if not _VIEWS or not _ENABLED:
+        if _VIEWS:
+            STATS["ordinary_layers"] += 1
         return None
     out = []
     for p in params:
@@ -98,7 +116,8 @@ def destinations(params: Sequence[torch.nn.Parameter]) -> Optional[list]:
             STATS["ordinary_layers"] += 1
             return None
         v = hit[1]
-        if v.shape != p.shape or v.dtype != p.dtype or v.device != p.device or not v.is_contiguous():
+        if (v.shape != p.shape or v.dtype != p.dtype or v.device != p.device or not v.is_contiguous()
+                or v.data_ptr() % 16 != 0):
             STATS["ordinary_layers"] += 1
             return None
         out.append(v)
