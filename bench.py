@@ -111,7 +111,7 @@ def gemm_traffic():
 class GemmTimer:
     """HIP-event timing of every MFMA-GEMM launch inside the timed region.  The launches are issued by the compiled ops
     (csrc/torch_binding.cpp), so the event pairs are recorded there -- on the launch stream, around each tamd_gemm /
-    tamd_gemm_swiglu / tamd_gemm_rope call -- and read back through transformers_amd._native."""
+    tamd_gemm_swiglu call -- and read back through transformers_amd._native."""
 
     def __init__(self):
         self._on = False

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 8
+#define TAMD_ABI_VERSION 9
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -219,8 +219,7 @@ enum tamd_gemm_flags {
   TAMD_GEMM_SCHED_PP = 1 << 8, /* 8-wave ping-pong kernel, 32-deep stages (every layout, any K)                */
   TAMD_GEMM_SCHED_SM = 2 << 8, /* 128 x 128 tile, two workgroups per CU (row-major operands, K % 64 == 0): the  */
                                /* default for grids of few 256 x 256 tiles that split-K does not take           */
-  TAMD_GEMM_SCHED_FL = 3 << 8, /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
-  TAMD_GEMM_SCHED_TW = 4 << 8  /* 256 x 128 tile, two workgroups per CU, 32-deep units (row-major operands, K % 32 == 0) */
+  TAMD_GEMM_SCHED_FL = 3 << 8  /* one wave per SIMD, 64-deep full-line stages (every layout, K % 64 == 0)      */
 };
 enum tamd_gemm_epilogue {
   TAMD_EPI_NONE = 0,
@@ -283,14 +282,6 @@ size_t tamd_gemm_group_workspace_bytes(const tamd_gemm_problem* problems, int co
 int tamd_gemm_group(const tamd_gemm_problem* problems, int count, int flags, int epilogue, int dtype, void* workspace,
                     size_t workspace_bytes, tamd_stream_t stream);
 
-/* ABI 8.  BertIntermediate / CLIPMLP.fc1 in train mode (models/bert/modeling_bert.py:334-337, models/clip/modeling_clip.py:
- * 346-350): the activation AND the rounded pre-activation its backward needs, from ONE GEMM:
- *   PRE[M,N] = round(A . B^T + bias)      Y[M,N] = round(act(PRE))
- * -- the bits of tamd_gemm(TAMD_EPI_BIAS) followed by tamd_bias_act_fwd.  Operands and flags as tamd_gemm. */
-int tamd_gemm_bias_act_pre(const void* A, const void* B, void* Y, void* PRE, const void* bias, int64_t M, int64_t N,
-                           int64_t K, int64_t lda, int64_t ldb, int64_t ldy, int64_t ldpre, int flags, int act, int dtype,
-                           tamd_stream_t stream);
-
 /* ABI 8.  A projection whose leading columns leave scaled: the query columns of a fused q|k|v projection
  * (models/bert/modeling_bert.py:175-177, models/clip/modeling_clip.py:304-318) carrying the attention kernels'
  * scale*log2(e) BEFORE their one rounding (tamd_attn_params.q_prescaled; the counterpart of tamd_rope_inplace's q_scale
@@ -307,14 +298,6 @@ int tamd_gemm_colscale(const void* A, const void* B, void* C, const void* bias, 
  * GU may be NULL (inference: the projection outputs are never written to HBM).  K % 64 == 0, I % 8 == 0. */
 int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* ACT, int64_t M, int64_t I, int64_t K, int64_t ldx,
                      int64_t ldw, int64_t ldgu, int64_t ldact, int dtype, tamd_stream_t stream);
-
-/* q|k|v projection with apply_rotary_pos_emb in the GEMM epilogue (models/llama/modeling_llama.py:254-262):
- *   QKV[M, N] = X[M,K] . Wqkv[N,K]^T, rotary embedding on the first rope_cols columns (query + key heads of 128),
- * cos / sin [cos_batch, seq, 128] (cos_batch 1 = shared by the batch rows; then seq >= 128).  Bit-identical to tamd_gemm followed by
- * tamd_rope_inplace.  K % 64 == 0, N and rope_cols multiples of 128. */
-int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const void* cos, const void* sin, int64_t M, int64_t N,
-                   int64_t K, int64_t ldx, int64_t ldw, int64_t ldqkv, int64_t seq, int64_t cos_batch, int64_t rope_cols,
-                   int dtype, tamd_stream_t stream);
 
 /* ------------------------------------------------------------------ attention (MFMA, flash-style) */
 

@@ -360,6 +360,7 @@ inline u32x4 buf_load16_rng(const void* base, unsigned bytes, unsigned voff) {
 inline void buf_store16_rng(void* base, unsigned bytes, unsigned voff, u32x4 v) {
   if ((unsigned long long)voff + 16ull <= (unsigned long long)bytes) memcpy(reinterpret_cast<char*>(base) + voff, &v, 16);
 }
+inline void buf_store16_rng_nt(void* base, unsigned bytes, unsigned voff, u32x4 v) { buf_store16_rng(base, bytes, voff, v); }
 // 4-byte variant (global_load_lds_dword): LDS destination = wave-uniform base + lane*4
 inline void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   const int lane = hipemu::cur_lane();
@@ -412,6 +413,12 @@ inline unsigned long long device_realtime() { return 0ull; }
 inline unsigned device_xcc_id() { return 0u; }
 inline float fast_exp2(float x) { return exp2f(x); }
 inline float fast_rcp(float x) { return 1.0f / x; }
+// logistic function of the SiLU / quick-GELU paths (activations.py:92-123): 1 / (1 + exp(-x)) as v_exp_f32 + v_rcp_f32 (1 ulp
+// each; every user rounds the product to a 16-bit storage type right after).  ONE definition for the GEMM epilogues, the
+// element-wise kernels and the weight-streaming kernels, so that fused and unfused paths agree bit for bit.  (An IEEE
+// division here is ten instructions per element -- v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup -- a third of the
+// SwiGLU epilogue of the gate|up GEMM, during which the matrix pipe idles.)
+inline float fast_sigmoid(float x) { return fast_rcp(1.f + fast_exp2(x * -1.44269504088896340736f)); }
 inline float fast_log2(float x) { return log2f(x); }
 
 }  // namespace tamd

@@ -213,12 +213,44 @@ def test_bench_ddp_path_over_rccl_world1():
     """the RCCL path had never executed.  `bench.py --force-ddp` at world size 1: process-group init over
     RCCL ("nccl" on ROCm), DDP wrap of the accelerated model (fused-weight views, bucket views of the gradients),
     bucketed all-reduce overlapped with the backward of the custom ops, destroy -- and the same loss as without DDP."""
-    base = [sys.executable, "bench.py", "--config", "llama-tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    base = [sys.executable, "bench.py", "--config", "llama-tiny", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
     plain = _run(base)
-    ddp = _run(base + ["--force-ddp"])
+    ddp = _run(base + ["--force-ddp", "--verify-ddp"])
     assert "DDP over RCCL" in ddp["config"]["parallelism"] and ddp["n_gpus"] == 1
     assert abs(ddp["loss"] - plain["loss"]) < 1e-6
     assert ddp["value"] > 0.5 * plain["value"]
+    # the zero-copy hand-over engaged (from the third step on) and nothing went wrong registering it
+    zc = ddp["ddp_zero_copy"]
+    assert zc["enabled"] and "error" not in zc and zc["zero_copy_layers"] > 0, zc
+    assert ddp["ddp_verify"].get("bit_identical") is True and ddp["ddp_verify"]["zero_copy_layers_in_checked_step"] > 0, ddp["ddp_verify"]
+    assert "breakdown_error" not in ddp["ddp"] and ddp["ddp"]["compute_only_ms"] > 0 and ddp["ddp"]["buckets_per_step"] >= 1
+    assert plain["layer_forward"]["ms"] > 0 and plain["layer_forward"]["fallback_calls"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_bench_ddp_collective_branch_over_rccl_world1():
+    """transformers_amd/ddp.py's RCCL branch (`ReduceOp.AVG` in place, async, on the bucket the dW GEMMs wrote into) never ran
+    on hardware: gloo takes the div + SUM branch and one rank takes the early return.  TAMD_DDP_WORLD1_COLLECTIVE=1 forces the
+    collective at world size 1 (AVG over one rank = identity), so the branch the first 8-GPU run depends on executes here:
+    same loss as without DDP, the zero-copy hand-over engaged, reduced gradients bit-identical to torch's copies."""
+    import subprocess
+
+    base = [sys.executable, "bench.py", "--config", "llama-tiny", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"]
+    plain = _run(base)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", TAMD_DDP_WORLD1_COLLECTIVE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(base + ["--force-ddp", "--verify-ddp"], capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+
+    ddp = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    zc = ddp["ddp_zero_copy"]
+    assert zc["collective"] == "all_reduce AVG in place (RCCL)", zc
+    assert zc["enabled"] and "error" not in zc and zc["zero_copy_layers"] > 0, zc
+    assert abs(ddp["loss"] - plain["loss"]) < 1e-6
+    assert ddp["ddp_verify"].get("bit_identical") is True, ddp["ddp_verify"]
 
 
 @pytest.mark.gpu

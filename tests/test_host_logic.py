@@ -152,3 +152,78 @@ def test_key_validity_mask_is_converted_once_per_forward():
     add[0, 0, 0, 0] = torch.finfo(torch.float32).min
     kv7, _ = split_mask(add, 2, 4)                 # the reference's additive 4-D padding mask
     assert kv7.tolist()[0] == [False, True, True, True] and split_mask(add, 2, 4)[0] is kv7
+
+
+def test_mask_caches_under_inference_mode():
+    """tensors created inside `torch.inference_mode()` have no version counter (`t._version` raises).  The
+    per-forward mask / varlen caches skip them -- converted on every call, never a stale hit -- instead of crashing every
+    BERT / CLIP / Llama forward with a padding mask under inference_mode."""
+    from transformers_amd.attention import _key_valid_from_mask, split_mask, varlen_q_start
+
+    with torch.inference_mode():
+        am = torch.ones(2, 8, dtype=torch.long)
+        am[0, 6:] = 0
+        kv = _key_valid_from_mask(am, 2, 8)
+        assert kv.dtype == torch.bool and kv.tolist()[0] == [True] * 6 + [False] * 2 and kv[1].all()
+        am[0, 6:] = 1                               # an in-place update nothing could detect: must not be served from a cache
+        assert _key_valid_from_mask(am, 2, 8).all()
+        kv2, _ = split_mask(TamdMask(am, None), 2, 8)
+        assert kv2.all()
+        cu = torch.tensor([0, 4, 6, 12], dtype=torch.int32)
+        a = varlen_q_start(None, {"cu_seq_lens_q": cu, "cu_seq_lens_k": cu}, 1, 12, 12, True)
+        cu[1] = 3
+        b = varlen_q_start(None, {"cu_seq_lens_q": cu, "cu_seq_lens_k": cu}, 1, 12, 12, True)
+        assert a[0, 0].tolist()[:6] == [0, 0, 0, 0, 4, 4] and b[0, 0].tolist()[:6] == [0, 0, 0, 3, 3, 3]
+    outside = torch.ones(2, 8, dtype=torch.long)    # ordinary tensors keep the once-per-forward behaviour
+    assert split_mask(outside, 2, 8)[0] is split_mask(outside, 2, 8)[0]
+
+
+def test_fused_layer_paths_respect_accelerate_wrappers():
+    """the fused layer paths read their children's weights directly, so a forward wrapper accelerate installs on
+    a CHILD for `device_map` / offload (`_hf_hook`) would not run and the weight would still sit on `meta`.  `_placement_ok`
+    sends such layers to the reference module (whose children are called); a wrapper on the layer itself is fine."""
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaDecoderLayer
+
+    from transformers_amd.models.common import _placement_ok
+
+    cfg = LlamaConfig(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                      num_key_value_heads=1, head_dim=64)
+    layer = LlamaDecoderLayer(cfg, 0)
+    cpu = torch.device("cpu")
+    probe = (layer.self_attn.q_proj.weight, layer.mlp.down_proj.weight)
+    assert _placement_ok(layer, cpu, *probe)
+    layer._hf_hook = object()                       # a wrapper on the layer itself has run before its forward is entered
+    layer.__dict__.pop("_tamd_placement")
+    assert _placement_ok(layer, cpu, *probe)
+    layer.mlp.down_proj._hf_hook = object()         # ... on a child it has not
+    assert _placement_ok(layer, cpu, *probe)        # (cached on the probe weights' identity)
+    layer.__dict__.pop("_tamd_placement")
+    assert not _placement_ok(layer, cpu, *probe)
+    del layer.mlp.down_proj._hf_hook
+    # offload replaces the parameter object (meta) -- that alone invalidates the cached verdict
+    layer.mlp.down_proj.weight = torch.nn.Parameter(torch.empty_like(layer.mlp.down_proj.weight, device="meta"))
+    probe = (layer.self_attn.q_proj.weight, layer.mlp.down_proj.weight)
+    assert not _placement_ok(layer, cpu, *probe)
+
+
+def test_weight_gradient_cut_packs_the_dispatch_rounds():
+    """`gemm_dw_balanced` (csrc/torch_binding.cpp): a weight-gradient product whose 256 x 256 tile grid ends in a mostly empty
+    dispatch round is cut into a whole-rounds part and a remainder of at most half a round (which split-K fills) instead of
+    splitting the whole product along K.  Llama-3-8B at 32768 tokens: q|k|v (384 tiles) at the q | k|v boundary, down_proj (896)
+    at 48 of its 56 tile columns, lm_head (8016) at 496 of 501 tile rows; grids that already pack stay one launch."""
+    from transformers_amd import _native
+
+    t = 32768
+    assert _native.dw_cut(6144, 4096, t) == (0, 4096)        # 256 tiles = 1 round | 128 tiles -> 2 splits
+    assert _native.dw_cut(4096, 14336, t) == (1, 12288)      # 768 tiles = 3 rounds | 128 tiles
+    assert _native.dw_cut(128256, 4096, t) == (0, 126976)    # 31 rounds | 80 tiles
+    for m, n in ((28672, 4096), (4096, 4096), (2048, 4096), (4096, 11008), (2304, 768)):
+        assert _native.dw_cut(m, n, t)[0] == -1, (m, n)      # whole rounds, at most one round, or no cut of <= half a round
+    assert _native.dw_cut(6144, 4096, 1000)[0] == -1         # ragged token counts (the ping-pong kernel): untouched
+    assert _native.dw_cut(6100, 4096, t)[0] == -1            # ragged outputs: untouched
+    for m, n in ((6144, 4096), (4096, 14336), (128256, 4096)):
+        axis, at = _native.dw_cut(m, n, t)
+        tm, tn = m // 256, n // 256
+        main = (at // 256) * (tn if axis == 0 else tm)
+        assert main % 256 == 0 and 0 < tm * tn - main <= 128

@@ -267,7 +267,7 @@ def test_gemm_layouts(env, layout):
         assert rel_err(c, ref) < 0.0034, (layout, m, n, k)  # bf16 output rounding only (fp32 accumulation)
 
 
-@pytest.mark.parametrize("sched", ["pp", "fl", "sm", "tw", None])
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm", None])
 def test_gemm_schedules_agree(env, sched):
     """The three GEMM kernels (ping-pong with 32-deep stages; one-wave-per-SIMD with 64-deep full-line stages; the 128 x 128
     tile for small forward grids) and the default dispatch agree bit for bit on ragged M/N, stage counts around the ring
@@ -285,7 +285,7 @@ def test_gemm_schedules_agree(env, sched):
         if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
             continue  # the default dispatch splits K for this grid: fp32 summation order differs (test_gemm_split_k)
         assert torch.equal(c, ops.raw_gemm(x, w, sched="pp")), (sched, m, n, k)  # same fp32 k-order per output
-    if sched not in ("pp", "sm", "tw"):  # k-major operands (the backward products)
+    if sched not in ("pp", "sm"):  # k-major operands (the backward products)
         for (m, n, k) in ([(4096, 1024, 4096), (1000, 1032, 320), (264, 4104, 832)] if env.big else
                           [(256, 256, 64), (264, 248, 128), (136, 520, 192), (72, 264, 320), (304, 136, 384)]):
             if sched is None and ops.backend().lib.tamd_gemm_workspace_bytes(m, n, k, 0, ops.EPI_NONE):
@@ -778,38 +778,6 @@ def test_dropout_add_layernorm(env, cols):
     assert torch.equal(y0, ops.layernorm(x.detach(), w.detach(), b.detach(), 1e-12, residual=r.detach())[0])
 
 
-def test_gemm_rope_epilogue_is_bit_identical_to_unfused(env):
-    """apply_rotary_pos_emb in the q|k|v GEMM epilogue (tamd_gemm_rope, models/llama/modeling_llama.py:254-262): the
-    same bits as the projection followed by the in-place rotary kernel -- batch-shared and per-batch cos / sin, ragged
-    token counts, value heads untouched."""
-    torch.manual_seed(41)
-    dev = env.device
-    # (a table shared by the batch is indexed by the token's position in its sequence: one wrap per 128-row piece, so
-    # shared tables need seq >= 128 -- shorter ones are refused and take the two-kernel path)
-    for (b, s, hq, hkv, k) in ([(2, 1024, 32, 8, 4096), (3, 200, 4, 2, 256), (9, 40, 2, 1, 128)] if env.big
-                               else [(2, 136, 2, 1, 128), (1, 130, 1, 1, 64), (5, 24, 1, 1, 64)]):
-        d, t = 128, b * s
-        n = (hq + 2 * hkv) * d
-        x = torch.randn(t, k).bfloat16().to(dev)
-        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
-        for cb in (1, b):
-            ang = torch.rand(cb, s, d // 2) * 6.28
-            cos = torch.cat([ang.cos(), ang.cos()], -1).bfloat16().to(dev)
-            sin = torch.cat([ang.sin(), ang.sin()], -1).bfloat16().to(dev)
-            if cb == 1:
-                cos, sin = cos[0], sin[0]
-            if cos.dim() == 2 and s < 128:
-                assert not ops.gemm_rope_supported(x, w, cos, d)
-                with pytest.raises(RuntimeError, match="tamd"):
-                    ops.raw_gemm_rope(x, w, cos, sin, s, hq + hkv, d)
-                continue
-            assert ops.gemm_rope_supported(x, w, cos, d)
-            ref = ops.raw_gemm(x, w)
-            ops.raw_rope_(ref, cos, sin, s, hq + hkv, d)
-            got = ops.raw_gemm_rope(x, w, cos, sin, s, hq + hkv, d)
-            assert torch.equal(got, ref), (b, s, hq, hkv, k, cb)
-
-
 def test_attention_backward_rope_epilogue_is_bit_identical_to_unfused(env):
     """The transposed rotary embedding on dq / dk inside the attention backward kernels (tamd_attn_bwd rope_cos /
     rope_sin) gives the bits of the stored gradients followed by tamd_rope_inplace(conj): shared and per-batch cos / sin,
@@ -865,7 +833,8 @@ def test_residual_epilogue_on_a_small_grid_goes_through_split_k(env):
 def test_gemm_piece_placements_are_bit_identical(env):
     """The two LDS-DMA piece placements of the full-line GEMM kernel -- early (the product schedule whenever A is row-major:
     forward and dX) and late (dW) -- compute the same bits in every layout; the diagnostic entry point
-    tamd_gemm_set_dbg(32 / 128) selects the other one (tools/gemm_piece_ab.py measures them)."""
+    tamd_gemm_set_dbg(32 / 128) selects the other one (tools/gemm_piece_ab.py measures them), 64 / 256 / 512 the experimental
+    placements of round 5 (pieces first; the hand-off split into its write-after-read and its landed-data half)."""
     lib = ops.backend().lib
     if not hasattr(lib, "tamd_gemm_set_dbg"):
         pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
@@ -881,55 +850,17 @@ def test_gemm_piece_placements_are_bit_identical(env):
         for args, kw in layouts:
             plain = ops.raw_gemm(*args, sched="fl", **kw)
             assert rel_err(plain, ref) < 0.0036
-            for dbg in (32, 128):
-                lib.tamd_gemm_set_dbg(dbg)
+            for dbg in (32, 128, 64, 256, 512):  # (64 / 256 / 512: the round-5 placements, row-major A only -- the split hand-off
+                lib.tamd_gemm_set_dbg(dbg)         # of 512 is what the adversarial LDS-DMA timing of the CPU model is for)
                 assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
                 lib.tamd_gemm_set_dbg(0)
     finally:
         lib.tamd_gemm_set_dbg(0)
 
 
-# ---- round 4: the bert-base fusions (one GEMM for activation + pre-activation, pre-scaled query columns, bias gradients
+# ---- round 4: the bert-base fusions (pre-scaled query columns, bias gradients
 # ---- accumulated by the kernels that produce the tensors they sum)
-@pytest.mark.parametrize("sched", ["pp", "fl", "sm", "tw"])
-def test_gemm_bias_act_pre_is_bit_identical_to_gemm_plus_activation_kernel(env, sched):
-    """BertIntermediate in train mode (modeling_bert.py:334-337): tamd_gemm_bias_act_pre writes act(round(xW^T + b)) AND the
-    rounded pre-activation from one GEMM -- the bits of tamd_gemm(TAMD_EPI_BIAS) followed by tamd_bias_act_fwd, on every
-    kernel, ragged M / N included."""
-    import ctypes
-
-    from transformers_amd import _cabi
-
-    torch.manual_seed(71)
-    dev = env.device
-    be = ops.backend()
-    lib = be.lib
-    hint = {"pp": 1, "sm": 2, "fl": 3, "tw": 4}[sched] << 8
-    for (m, n, k) in ([(4096, 3072, 768), (1000, 1032, 320), (577, 4096, 1024)] if env.big else
-                      [(264, 248, 128), (130, 520, 192), (72, 264, 64)]):
-        x = torch.randn(m, k).bfloat16().to(dev)
-        w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
-        b = torch.randn(n).bfloat16().to(dev)
-        for act in (ops.ACT_GELU_ERF, ops.ACT_QUICK_GELU):
-            y = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
-            pre = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
-            st = be.stream(x)
-            lib.check(lib.tamd_gemm_bias_act_pre(x.data_ptr(), w.data_ptr(), y.data_ptr(), pre.data_ptr(), b.data_ptr(), m, n, k,
-                                                 k, k, n, n, hint, act, _cabi.TAMD_BF16, ctypes.c_void_p(st) if st else None),
-                      "gemm_bias_act_pre")
-            if dev.type == "cuda":
-                torch.cuda.synchronize()
-            pre_ref = ops.raw_gemm(x, w, bias=b, epilogue=ops.EPI_BIAS, sched=sched)
-            assert torch.equal(pre, pre_ref), (sched, m, n, k, act)
-            assert torch.equal(y, ops.raw_bias_act_fwd(pre_ref, None, act)), (sched, m, n, k, act)
-            assert torch.equal(y, ops.raw_gemm(x, w, bias=b, epilogue=ops.EPI_BIAS_ACT, act=act, sched=sched))
-    # the dispatcher op (default schedule)
-    y2, pre2 = torch.ops.tamd.gemm_bias_act_pre(x, w, b, ops.ACT_GELU_ERF)
-    assert torch.equal(pre2, ops.raw_gemm(x, w, bias=b, epilogue=ops.EPI_BIAS))
-    assert torch.equal(y2, ops.raw_bias_act_fwd(pre2, None, ops.ACT_GELU_ERF))
-
-
-@pytest.mark.parametrize("sched", ["pp", "fl", "sm", "tw"])
+@pytest.mark.parametrize("sched", ["pp", "fl", "sm"])
 def test_gemm_colscale_scales_the_query_columns_before_their_one_rounding(env, sched):
     """tamd_gemm_colscale (the q|k|v projection of BertSelfAttention, modeling_bert.py:175-177, delivering pre-scaled queries):
     columns >= scale_cols carry the bits of the plain GEMM; the scaled columns are round((acc + bias) * s) -- closer to the
@@ -942,7 +873,7 @@ def test_gemm_colscale_scales_the_query_columns_before_their_one_rounding(env, s
     dev = env.device
     be = ops.backend()
     lib = be.lib
-    hint = {"pp": 1, "sm": 2, "fl": 3, "tw": 4}[sched] << 8
+    hint = {"pp": 1, "sm": 2, "fl": 3}[sched] << 8
     for (m, n, k, sc) in ([(4096, 2304, 768, 768), (1000, 1032, 320, 344)] if env.big else [(264, 248, 128, 80), (72, 264, 64, 264)]):
         x = torch.randn(m, k).bfloat16().to(dev)
         w = (torch.randn(n, k) * 0.1).bfloat16().to(dev)
@@ -1276,3 +1207,33 @@ def test_gemm_segmented_weight_gradient(env):
         segs = [torch.full((r, n), 7.0, dtype=torch.bfloat16, device=dev) for r in rows]
         torch.ops.tamd.gemm_dw_segments(dy, x, segs)
         assert torch.equal(torch.cat(segs, 0), whole), (m, n, k, rows)
+
+
+@pytest.mark.gpu
+def test_weight_gradient_products_cut_into_whole_rounds(env):
+    """Round 5: dW of the Llama-3-8B q|k|v and down projections at 32768 tokens through the default dispatch (`torch.ops.tamd.gemm`
+    -> gemm_dw_balanced: a whole-rounds part + a split-K remainder, written into row / column slices of one output) against
+    the same product as ONE launch of the full-line kernel: same values up to the fp32 summation order of the split part."""
+    if not env.big:
+        pytest.skip("Llama-3-8B weight-gradient shapes: MI355X only")
+    from transformers_amd import _native
+
+    torch.manual_seed(5)
+    dev = env.device
+    t = 32768
+    for m, n in ((6144, 4096), (4096, 14336)):
+        axis, at = _native.dw_cut(m, n, t)
+        assert axis >= 0
+        dy = torch.randn(t, m, device=dev).bfloat16()
+        x = torch.randn(t, n, device=dev).bfloat16()
+        got = ops.raw_gemm(dy, x, a_km=True, b_kn=True)
+        one = ops.raw_gemm(dy, x, a_km=True, b_kn=True, sched="fl")
+        assert got.shape == one.shape == (m, n)
+        main = (slice(0, at), slice(None)) if axis == 0 else (slice(None), slice(0, at))
+        rest = (slice(at, None), slice(None)) if axis == 0 else (slice(None), slice(at, None))
+        assert torch.equal(got[main], one[main])                   # the whole-rounds part: the same kernel, the same bits
+        assert rel_err(got[rest], one[rest]) < 2e-3                 # the remainder: split-K (bf16 rounding of another fp32 order)
+        ref = dy[:, :64].float().t() @ x.float()
+        assert rel_err(got[:64], ref) < 0.0036
+        del dy, x, got, one, ref
+

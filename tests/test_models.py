@@ -62,9 +62,13 @@ def test_llama_forward_backward_parity(env, padding):
     assert fast.config._attn_implementation == "tamd"
     assert type(fast.model.layers[0]).__name__ == "TamdLlamaDecoderLayer"
     dev = env.device
+    transformers_amd.fallback_calls(reset=True)
     o = fast(input_ids=ids.to(dev), labels=labels.to(dev), attention_mask=None if am is None else am.to(dev),
              use_cache=False)
     o.loss.backward()
+    # the headline architecture must run on the kernels: a regression that silently routes a layer to the reference
+    # module's own forward would still produce matching numbers
+    assert transformers_amd.fallback_calls() == {}, transformers_amd.fallback_calls()
     valid = torch.ones(b, s, dtype=torch.bool) if am is None else am.bool()
     e_fast = rel_err(o.logits[valid.to(dev)], o32.logits[valid])
     e_ref = rel_err(o_ref.logits[valid], o32.logits[valid])
@@ -319,7 +323,10 @@ def _grad_parity(fast, ref, ref32, skip=()):
         # BERT layer-0 query.weight (its gradient passes the bf16 dS of every layer's attention backward) 0.0124 against a
         # reference error of 0.0080 -- the gate is 0.0145 there, 1.17x the measurement (profiles/r03b); and query.bias, a
         # column sum of dq that nearly cancels (key.bias cancels exactly: softmax shift invariance), so its RELATIVE error
-        # amplifies whatever dq carries: 0.0170 against 0.0094 (profiles/r03c) -- those get 2.2x + 3e-3 = 0.0236 (1.39x)
+        # amplifies whatever dq carries: 0.0170 against 0.0094 (profiles/r03c) -- those get 2.2x + 3e-3 = 0.0236 (1.39x).
+        # Round 4's measurements (profiles/r04_parity.json, MI355X): worst weight bert.encoder.layer.1...key.weight 0.0162
+        # against 0.0092 -> gate 0.0163 = 1.006x the measurement; worst query.bias 0.0197 against 0.0095 -> gate 0.0239 =
+        # 1.21x: both already inside the "<= 1.25x the worst measurement" VERDICT r4 asks for, so the constants stay
         k, c = (2.2, 3e-3) if n.endswith("query.bias") else (1.5, 2.5e-3)
         assert ef <= k * er + c, (n, ef, er)
 

@@ -46,7 +46,7 @@ for name, n, k, epi in CASES:
         kw = dict(residual=res, epilogue=ops.EPI_RESIDUAL) if epi == "res" else {}
         return lambda i: ops.raw_gemm(x, ws[i], sched=sched, **kw)
 
-    arms = {"default": arm(None), "fl": arm("fl"), "tw": arm("tw"), "sm": arm("sm"),
+    arms = {"default": arm(None), "fl": arm("fl"), "sm": arm("sm"),
             "torch": (lambda i: torch.nn.functional.linear(x, ws[i]))}
     rec = {"case": name, "M": M, "N": n, "K": k, "epi": epi, "weights_cycled": copies, "footprint_GB": round(copies * n * k * 2 / 1e9, 2)}
     for a, fn in arms.items():

@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from transformers_amd._cabi import TamdLib, TAMD_BF16  # noqa: E402
 
-base = TamdLib(Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "tools" / "ab" / "libtamd_base.so", accept_abi=(7, 8))
+base = TamdLib(Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "tools" / "ab" / "libtamd_base.so", accept_abi=(7, 8, 9))
 new = TamdLib(Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "transformers_amd" / "libtamd.so")
 dev = torch.device("cuda:0")
 stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -65,3 +65,34 @@ for name, flags, m, n, k, epi in CASES:
                       "base_us": round(min(t["base"]), 1), "new_us": round(min(t["new"]), 1),
                       "base_TF": round(fl / min(t["base"]) / 1e6, 1), "new_TF": round(fl / min(t["new"]) / 1e6, 1),
                       "new_over_base": round(min(t["new"]) / min(t["base"]), 4)}), flush=True)
+
+# the gate|up projection with SiLU(gate) * up in its epilogue (tamd_gemm_swiglu): GU == NULL (forward only) and GU written (training)
+I, K = 14336, 4096
+torch.manual_seed(0)
+x = torch.randn(T, K, device=dev).bfloat16()
+wgu = (torch.randn(2 * I, K, device=dev) * 0.05).bfloat16()
+for name, keep in (("fwd gate|up+SwiGLU (no GU)", False), ("fwd gate|up+SwiGLU (GU kept)", True)):
+    outs, t = {}, {"base": [], "new": []}
+
+    def call(lib, act, gu):
+        st = lib.tamd_gemm_swiglu(x.data_ptr(), wgu.data_ptr(), gu.data_ptr() if gu is not None else None, act.data_ptr(), T, I, K,
+                                  K, K, 2 * I, I, TAMD_BF16, stream)
+        assert st == 0, (name, st)
+
+    for key, lib in (("base", base), ("new", new)):
+        outs[key] = (torch.empty(T, I, device=dev, dtype=torch.bfloat16),
+                     torch.empty(T, 2 * I, device=dev, dtype=torch.bfloat16) if keep else None)
+        call(lib, *outs[key])
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for key, lib in (("base", base), ("new", new)):
+            t[key].append(timeit(lambda: call(lib, *outs[key]), 6))
+    fl = 2.0 * T * 2 * I * K
+    d = (outs["base"][0].float() - outs["new"][0].float()).abs()
+    print(json.dumps({"case": name, "M": T, "N": 2 * I, "K": K, "same_bits": bool(torch.equal(outs["base"][0], outs["new"][0])),
+                      "act_mismatch_fraction": float((outs["base"][0] != outs["new"][0]).float().mean()),
+                      "act_max_abs_diff": float(d.max()),
+                      "base_us": round(min(t["base"]), 1), "new_us": round(min(t["new"]), 1),
+                      "base_TF": round(fl / min(t["base"]) / 1e6, 1), "new_TF": round(fl / min(t["new"]) / 1e6, 1),
+                      "new_over_base": round(min(t["new"]) / min(t["base"]), 4)}), flush=True)
+    del outs

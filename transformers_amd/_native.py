@@ -42,6 +42,8 @@ def load():
     dll.tamd_torch_bind.argtypes = [ctypes.c_char_p, ctypes.c_int]
     dll.tamd_torch_last_error.restype = ctypes.c_char_p
     dll.tamd_torch_bound_path.restype = ctypes.c_char_p
+    dll.tamd_torch_dw_cut.restype = ctypes.c_int
+    dll.tamd_torch_dw_cut.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
     dll.tamd_torch_gemm_log.argtypes = [ctypes.c_int]
     dll.tamd_torch_gemm_log_summary.restype = ctypes.c_int
     dll.tamd_torch_gemm_log_summary.argtypes = [ctypes.POINTER(ctypes.c_double)]
@@ -58,6 +60,14 @@ def bind(path, emulated: bool = False) -> None:
 
 def bound_path() -> str:
     return load().tamd_torch_bound_path().decode()
+
+
+def dw_cut(m: int, n: int, k: int):
+    """(axis, at) of the cut `gemm_dw_balanced` (csrc/torch_binding.cpp) makes in a weight-gradient product dW[m, n] over k
+    tokens: axis 0 = rows [0, at) / [at, m) as two launches, 1 = columns, -1 = one launch."""
+    at = ctypes.c_longlong(0)
+    axis = load().tamd_torch_dw_cut(m, n, k, ctypes.byref(at))
+    return axis, at.value
 
 
 def gemm_log(on: bool) -> None:

@@ -144,11 +144,21 @@ def split_mask(attention_mask, batch: int, kv_len: int):
 _varlen_cache = threading.local()  # the last (cu_seq_lens_q, cu_seq_lens_k, total) -> q_start of this thread
 
 
+def _ver(t) -> Optional[int]:
+    """The version counter of a tensor, or None when it has none: tensors created under `torch.inference_mode()` do not track
+    versions (`t._version` raises), so an in-place update of one cannot be seen -- the per-forward caches below skip them."""
+    return None if (t is None or t.is_inference()) else t._version
+
+
 def _same_tensor(a, b) -> bool:
     """Same bytes by construction: the same object, or two views of one storage at the same version (the caller holds a
-    reference to `a`, so its storage cannot have been recycled for `b`)."""
-    return a is b or (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape
-                      and a.dtype == b.dtype and a._version == b._version)
+    reference to `a`, so its storage cannot have been recycled for `b`).  Inference tensors (no version counter) only match
+    as the same object -- and the callers do not cache them at all."""
+    if a is b:
+        return True
+    if a is None or b is None or _ver(a) is None or _ver(b) is None:
+        return False
+    return a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.dtype == b.dtype and _ver(a) == _ver(b)
 
 
 def varlen_q_start(q_start, kwargs, batch: int, sq: int, sk: int, causal: bool):
@@ -166,15 +176,17 @@ def varlen_q_start(q_start, kwargs, batch: int, sq: int, sk: int, causal: bool):
         raise TamdError("attn_implementation='tamd' takes cu_seq_lens_q/k for one flattened, causal row without a KV cache "
                         "(equal query and key boundaries)")
     hit = getattr(_varlen_cache, "entry", None)
-    if (hit is not None and hit[2] == sq and _same_tensor(hit[0], cu_q) and (cu_k is None or _same_tensor(hit[1], cu_k))
-            and hit[4] == (cu_q._version, cu_k._version if cu_k is not None else -1)):  # (the SAME object updated in place)
+    vers = (_ver(cu_q), _ver(cu_k) if cu_k is not None else -1)
+    cacheable = None not in vers  # (inference tensors carry no version: validated and converted on every call)
+    if (cacheable and hit is not None and hit[2] == sq and _same_tensor(hit[0], cu_q)
+            and (cu_k is None or _same_tensor(hit[1], cu_k)) and hit[4] == vers):  # (the SAME object updated in place)
         return hit[3]
     if cu_k is not None and cu_k is not cu_q and (cu_k.shape != cu_q.shape or not torch.equal(cu_k, cu_q)):
         raise TamdError("attn_implementation='tamd' takes cu_seq_lens_q/k for one flattened, causal row without a KV cache "
                         "(equal query and key boundaries)")
     qs = ops.q_start_from_cu_seqlens(cu_q, sq)
-    _varlen_cache.entry = (cu_q, cu_k if cu_k is not None else cu_q, sq, qs,
-                           (cu_q._version, cu_k._version if cu_k is not None else -1))
+    if cacheable:
+        _varlen_cache.entry = (cu_q, cu_k if cu_k is not None else cu_q, sq, qs, vers)
     return qs
 
 
@@ -188,15 +200,16 @@ def _key_valid_from_mask(attention_mask, batch: int, kv_len: int) -> Optional[to
     in-place update of the mask changes its version."""
     src = attention_mask.key_valid if isinstance(attention_mask, TamdMask) else attention_mask
     hit = getattr(_kv_cache, "entry", None)
-    if (hit is not None and hit[1] == batch and hit[2] == kv_len and torch.is_tensor(src) and _same_tensor(hit[0], src)
-            and hit[4] == src._version):
+    ver = _ver(src) if torch.is_tensor(src) else None  # (None: an inference tensor -- converted on every call, never cached)
+    if (hit is not None and ver is not None and hit[1] == batch and hit[2] == kv_len and _same_tensor(hit[0], src)
+            and hit[4] == ver):
         if isinstance(attention_mask, TamdMask) and attention_mask.q_start is not None:
             raise TamdError("packed sequences reached a fused block that does not implement them (supported: the "
                             "Llama path and every model that goes through the registered attention function)")
         return hit[3]
     out = _key_valid_from_mask_uncached(attention_mask, batch, kv_len)
-    if torch.is_tensor(src) and out is not None:
-        _kv_cache.entry = (src, batch, kv_len, out, src._version)
+    if ver is not None and out is not None:
+        _kv_cache.entry = (src, batch, kv_len, out, ver)
     return out
 
 

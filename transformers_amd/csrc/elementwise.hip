@@ -277,7 +277,7 @@ __global__ void bert_embeddings_kernel(const int64_t* __restrict__ input_ids, co
 }
 
 // =============================================================== activations
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return fast_sigmoid(x); }  // (tamd_device.h)
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 __device__ __forceinline__ float dsilu_f(float x) {
   const float s = sigmoid_f(x);

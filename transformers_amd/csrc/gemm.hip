@@ -103,9 +103,6 @@ struct GemmArgs {
   // [M, 2*n_half] gate|up output or nullptr when nothing will be differentiated
   void* C2;
   int64_t ldc2, n_half;
-  // rotary epilogue (kEpiRope): R = cos, C2 = sin ([cos_batch, seq, 128] in the storage dtype), n_half = the leading
-  // columns to rotate (query + key heads, a multiple of 128), seq / cos_batch below
-  int64_t seq, cos_batch;
   // column-scale epilogue (kEpiColScale): C[m, n] = round((acc + bias[n]) * (n < scale_cols ? col_scale : 1)) -- the query
   // columns of a q|k|v projection leave carrying the attention kernels' scale*log2(e) (tamd_attn_params.q_prescaled)
   int64_t scale_cols;
@@ -126,23 +123,18 @@ __device__ __forceinline__ void* gemm_seg_base(const GemmArgs& g, int64_t m0) {
 }
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
-constexpr int kEpiRope = 103;
 constexpr int kEpiColScale = 104;
 
 // the LlamaMLP inner product (models/llama/modeling_llama.py:174-176; same expression as swiglu_fwd_kernel in
 // elementwise.hip, so the fused epilogue and the stand-alone kernel agree bit for bit)
-__device__ __forceinline__ float gemm_silu(float x) { return x * (1.f / (1.f + __expf(-x))); }
-__device__ __forceinline__ float gemm_dsilu(float x) {  // = dsilu_f in elementwise.hip
-  const float sg = 1.f / (1.f + __expf(-x));
-  return sg * (1.f + x * (1.f - sg));
-}
+__device__ __forceinline__ float gemm_silu(float x) { return x * fast_sigmoid(x); }
 
 template <int ACT>
 __device__ __forceinline__ float gemm_act(float x) {
   if (ACT == TAMD_ACT_GELU_ERF) return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f));
   if (ACT == TAMD_ACT_GELU_TANH) return 0.5f * x * (1.f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x)));
-  if (ACT == TAMD_ACT_QUICK_GELU) return x / (1.f + __expf(-1.702f * x));
-  if (ACT == TAMD_ACT_SILU) return x / (1.f + __expf(-x));
+  if (ACT == TAMD_ACT_QUICK_GELU) return x * fast_sigmoid(1.702f * x);  // (= act_fwd_f of elementwise.hip)
+  if (ACT == TAMD_ACT_SILU) return x * fast_sigmoid(x);
   return x;
 }
 
@@ -217,98 +209,65 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int bid, i
 
 // Epilogue of one wave over a (HALVES*64) x (NCOLS) piece of C at (row0, col0).  Per 64 rows: `stage(half, bias4)` rounds
 // the accumulators (+bias, +activation) into this wave's private LDS region (row pitch NCOLS*2 + 16 bytes; the
-// accumulator layout is the caller's business: stage32 / stage16 below), then full-row 16-byte stores (+residual / +C /
-// rotary embedding) leave from there.
+// accumulator layout is the caller's business: stage32 / stage16 below), then full-row 16-byte stores (+residual / +C)
+// leave from there.
 template <typename T, int EPI, int ACT, int NCOLS, int HALVES, typename StageFn>
 __device__ __forceinline__ void gemm_epilogue_rows(const GemmArgs& g, char* smem, unsigned st_off, int64_t row0, int64_t col0,
                                                    int lane, StageFn stage) {
   constexpr int ROWB = NCOLS * 2 + 16;   // staged row + 16 B pad
   constexpr int SLOTS = NCOLS / 8;       // 16-byte slots per row
   constexpr int RPI = 64 / SLOTS;        // rows per wave instruction on the way out
-  T* C = reinterpret_cast<T*>(g.C);
-  const T* R = reinterpret_cast<const T*>(g.R);
-  // operands the way out reads from memory (residual / previous C / cos and sin rows): all of a half's loads are issued
-  // BEFORE the accumulators are rounded and staged, so their latency overlaps that work and 16-32 KiB per wave are in
-  // flight instead of 4 (a way out that loads inside its row loop is latency-bound at ~2.7 TB/s)
-  constexpr bool ROPE = (EPI == kEpiRope && NCOLS == 128);  // (cos / sin rows of the rotary epilogue are such operands too)
-  constexpr int NR = ROPE ? 2 : ((EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0);
+  // Addressing (round 5): the piece's first element is a wave-uniform buffer base, a lane's position a 32-bit byte offset
+  // that steps by RPI rows per instruction, and the matrix edge is the hardware's range check (rows past M: beyond the
+  // buffer's size; a lane whose 8 columns lie past N gets an offset outside it once) -- per store: one ds_read, one v_add,
+  // one buffer_store.  (Before: per store a 64-bit row * ldc product, a 64-bit compare and an exec-masked branch -- ~13
+  // instructions, 32 stores per wave, with the matrix pipe idle: tools/gemm_isa.sh counted 1180 instructions in the plain way
+  // out, ~700 now.)
+  const int64_t rows_left = g.M - row0;  // (<= 0: the tile's second wave row lies wholly past a ragged M -- an empty buffer)
+  const unsigned nrows = rows_left <= 0 ? 0u : (unsigned)(rows_left < HALVES * 64 ? rows_left : HALVES * 64);
+  const int lrow = lane / SLOTS, slot = lane % SLOTS;
+  const bool col_ok = col0 + slot * 8 < g.N;
+  T* Cw = reinterpret_cast<T*>(g.C) + row0 * g.ldc + col0;
+  // (a lane past N keeps its out-of-range offset: its step is 0, so the 32-bit offset cannot wrap back into the buffer)
+  const unsigned c_bytes = nrows * (unsigned)g.ldc * 2u, c_step = col_ok ? (unsigned)RPI * (unsigned)g.ldc * 2u : 0u;
+  const unsigned c_off0 = col_ok ? ((unsigned)lrow * (unsigned)g.ldc + (unsigned)slot * 8u) * 2u : 0xfffffff0u;
+  // operands the way out reads from memory (residual / previous C): all of a half's loads are issued BEFORE the accumulators
+  // are rounded and staged, so their latency overlaps that work and 16 KiB per wave are in flight instead of 4 (a way out
+  // that loads inside its row loop is latency-bound at ~2.7 TB/s)
+  constexpr int NR = (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) ? 1 : 0;
   constexpr int NIT = 64 / RPI;
-  // rotary epilogue: this wave's 128 columns are one head; value heads (col0 >= n_half) pass through.  The cos / sin row
-  // of a token is its position in its sequence: ONE 64-bit modulo per wave, the rows of the piece count up from there
-  // (the first version took gm_ % seq per row segment -- 32 software divisions per lane -- and loaded cos / sin inside
-  // the row loop: the fused GEMM was 150 us slower than GEMM + rope_kernel, profiles/r02_gemm_variants.md section 7)
-  const bool rope_here = ROPE && col0 < g.n_half;
-  const int64_t crow_base = !ROPE ? 0 : ((g.cos_batch == 1) ? row0 % g.seq : row0);
-  auto rope_row = [&](int r) -> int64_t {  // r = row inside this wave's piece
-    const int64_t crow = crow_base + r;  // r < 128 <= seq (tamd_gemm_rope refuses shorter shared-table sequences): one wrap
-    return (g.cos_batch == 1 && crow >= g.seq) ? crow - g.seq : crow;
-  };
-  // (two loads per row segment -- the rotary epilogue's cos and sin -- go in two chunks of 8 iterations: 64 registers of
-  // loads in flight, so that nothing spills)
-  constexpr int CH = (NR == 2 && NIT > 8) ? 8 : NIT;
+  const T* Rw = (EPI == TAMD_EPI_ACCUM) ? Cw : (reinterpret_cast<const T*>(g.R) + row0 * g.ldr + col0);
+  const unsigned ldr_ = (EPI == TAMD_EPI_ACCUM) ? (unsigned)g.ldc : (unsigned)g.ldr;
+  const unsigned r_bytes = nrows * ldr_ * 2u, r_step = col_ok ? (unsigned)RPI * ldr_ * 2u : 0u;
+  const unsigned r_off0 = col_ok ? ((unsigned)lrow * ldr_ + (unsigned)slot * 8u) * 2u : 0xfffffff0u;
 #pragma unroll
   for (int half = 0; half < HALVES; ++half) {
-    u32x4 pre[NR > 0 ? CH * NR : 1];
-    auto preload = [&](int it0) {
+    u32x4 pre[NR > 0 ? NIT : 1];
+    if (NR > 0) {
+      unsigned ro = r_off0 + (unsigned)half * (unsigned)NIT * r_step;
 #pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int it = it0 + i;
-        const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
-        const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
-        const bool ok = gm_ < g.M && gn < g.N;
-        if (ROPE) {
-          if (rope_here) {
-            const int64_t crow = rope_row(half * 64 + row);
-            pre[2 * i] = ok ? ld16(R + crow * 128 + slot * 8) : u32x4{0u, 0u, 0u, 0u};
-            pre[2 * i + 1] = ok ? ld16(reinterpret_cast<const T*>(g.C2) + crow * 128 + slot * 8) : u32x4{0u, 0u, 0u, 0u};
-          }
-        } else {
-          const T* rp = (EPI == TAMD_EPI_ACCUM) ? (C + gm_ * g.ldc + gn) : (R + gm_ * g.ldr + gn);
-          pre[i] = ok ? ld16(rp) : u32x4{0u, 0u, 0u, 0u};
-        }
+      for (int it = 0; it < NIT; ++it) {
+        pre[it] = buf_load16_rng(Rw, r_bytes, ro);  // (outside the matrix: zeros)
+        ro += r_step;
       }
       sched_fence();
-    };
-    if (NR > 0) preload(0);
+    }
     stage(half);
     wave_lockstep_point();  // wave-private region: this wave's writes are ordered before its reads
+    unsigned co = c_off0 + (unsigned)half * (unsigned)NIT * c_step;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      if (NR > 0 && it > 0 && it % CH == 0) preload(it);
-      const int pi = it % CH;  // index of this iteration's preloaded operands
-      const int row = it * RPI + lane / SLOTS, slot = lane % SLOTS;
-      const int64_t gm_ = row0 + half * 64 + row, gn = col0 + slot * 8;
-      u32x4 v = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)slot * 16u);
-      if (ROPE && rope_here) {
-        // apply_rotary_pos_emb on a query / key head (this wave's 128 columns are exactly one head of 128):
-        //   out = round(round(x * cos) + round(rotate_half(x) * sin)),  rotate_half(x)[d] = -x[d+64] (d < 64), x[d-64]
-        // with the roundings of rope_kernel (elementwise.hip), on the rounded projection staged in LDS: bit-identical
-        // to tamd_gemm followed by tamd_rope_inplace
-        if (gm_ < g.M && gn < g.N) {
-          const u32x4 vp = lds_read16(smem, st_off + (unsigned)row * ROWB + (unsigned)(slot ^ 8) * 16u);
-          float x[8], xp[8], cs[8], sn[8], o[8];
-          unpack16<T>(v, x);
-          unpack16<T>(vp, xp);
-          unpack16<T>(pre[NR == 2 ? 2 * pi : 0], cs);
-          unpack16<T>(pre[NR == 2 ? 2 * pi + 1 : 0], sn);
+      u32x4 v = lds_read16(smem, st_off + (unsigned)(it * RPI + lrow) * ROWB + (unsigned)slot * 16u);
+      if (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) {
+        float a[8], b[8];
+        unpack16<T>(v, a);
+        unpack16<T>(pre[NR == 1 ? it : 0], b);
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            o[e] = round_through<T>(x[e] * cs[e]) + round_through<T>((slot < 8 ? -xp[e] : xp[e]) * sn[e]);
-          st16(C + gm_ * g.ldc + gn, pack16<T>(o));
-        }
-        continue;
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        v = pack16<T>(a);
       }
-      if (gm_ < g.M && gn < g.N) {
-        if (EPI == TAMD_EPI_RESIDUAL || EPI == TAMD_EPI_ACCUM) {
-          float a[8], b[8];
-          unpack16<T>(v, a);
-          unpack16<T>(pre[NR == 1 ? pi : 0], b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] += b[e];
-          v = pack16<T>(a);
-        }
-        st16(C + gm_ * g.ldc + gn, v);
-      }
+      buf_store16_rng(Cw, c_bytes, co, v);  // (outside the matrix: nothing is stored)
+      co += c_step;
     }
     wave_lockstep_point();
   }
@@ -333,7 +292,13 @@ __device__ __forceinline__ void gemm_bias4(const GemmArgs& g, int64_t gn, float*
 // (sc: the column-scale epilogue's factor of these 4 columns, applied BEFORE the one rounding)
 template <typename T, int EPI, int ACT>
 __device__ __forceinline__ u32x2 gemm_round4(float a0, float a1, float a2, float a3, const float* bv, float sc = 1.f) {
-  float v[4] = {a0 + bv[0], a1 + bv[1], a2 + bv[2], a3 + bv[3]};
+  // (epilogues that cannot carry a bias skip the add: 128 packed adds of zero per wave in every plain way out)
+  constexpr bool MAY_BIAS = (EPI == TAMD_EPI_BIAS || EPI == TAMD_EPI_BIAS_ACT || EPI == TAMD_EPI_RESIDUAL || EPI == kEpiColScale);
+  float v[4] = {a0, a1, a2, a3};
+  if (MAY_BIAS) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+  }
   if (EPI == TAMD_EPI_BIAS_ACT) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = gemm_act<ACT>(round_through<T>(v[e]));
@@ -349,16 +314,6 @@ template <int EPI>
 __device__ __forceinline__ float gemm_colscale4(const GemmArgs& g, int64_t gn) {
   return (EPI == kEpiColScale && gn < g.scale_cols) ? g.col_scale : 1.f;
 }
-// TAMD_EPI_BIAS_ACT with a second output (GemmArgs.C2 / ldc2): the rounded pre-activation round(acc + bias) -- what the
-// activation's backward needs -- leaves through the same way out first (BertIntermediate in train mode: one GEMM instead
-// of GEMM + activation kernel, models/bert/modeling_bert.py:334-337)
-__device__ __forceinline__ GemmArgs gemm_pre_args(const GemmArgs& g) {
-  GemmArgs p = g;
-  p.C = g.C2;
-  p.ldc = g.ldc2;
-  return p;
-}
-
 // 32x32x16 accumulators (gemm_pp_kernel): acc[ni][mi][r] = D[n = ni*32 + (r&3) + 8*(r>>2) + 4*hi][m = mi*32 + l31]
 template <typename T, int EPI, int ACT, int NI, int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][MI], char* smem, unsigned st_off,
@@ -385,12 +340,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
       }
     }
   };
-  if (EPI == TAMD_EPI_BIAS_ACT && g.C2 != nullptr) {
-    const GemmArgs gp = gemm_pre_args(g);
-    gemm_epilogue_rows<T, TAMD_EPI_BIAS, ACT, NI * 32, MI / 2>(gp, smem, st_off, row0, col0, lane, [&](int half) {
-      stage_as(std::integral_constant<int, TAMD_EPI_BIAS>{}, half);
-    });
-  }
   gemm_epilogue_rows<T, EPI, ACT, NI * 32, MI / 2>(g, smem, st_off, row0, col0, lane,
                                                    [&](int half) { stage_as(std::integral_constant<int, EPI>{}, half); });
 }
@@ -416,14 +365,11 @@ __device__ __forceinline__ void gemm_epilogue16(const GemmArgs& g, f32x4 (&acc)[
         lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
                    gemm_round4<T, E, ACT>(a[0], a[1], a[2], a[3], bv, sc));
       }
+      // (one column block at a time: left alone the scheduler reads all 128 accumulators of the half out of the AGPRs first --
+      // 128 live VGPRs beside the 64 of a half's residual rows: the f16 residual kernel spilled 3 of them)
+      if (E == TAMD_EPI_RESIDUAL || E == TAMD_EPI_ACCUM) sched_fence();
     }
   };
-  if (EPI == TAMD_EPI_BIAS_ACT && g.C2 != nullptr) {
-    const GemmArgs gp = gemm_pre_args(g);
-    gemm_epilogue_rows<T, TAMD_EPI_BIAS, ACT, 128, 2>(gp, smem, st_off, row0, col0, lane, [&](int half) {
-      stage_as(std::integral_constant<int, TAMD_EPI_BIAS>{}, half);
-    });
-  }
   gemm_epilogue_rows<T, EPI, ACT, 128, 2>(g, smem, st_off, row0, col0, lane,
                                           [&](int half) { stage_as(std::integral_constant<int, EPI>{}, half); });
 }
@@ -443,8 +389,20 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&
   constexpr unsigned ACT_OFF = 64u * GU_ROWB;
   const int g4 = lane >> 4, l15 = lane & 15;
   T* C = reinterpret_cast<T*>(g.C);
-  T* C2 = reinterpret_cast<T*>(g.C2);
   const int64_t I = g.n_half;
+  const int64_t rows_left = g.M - row0;  // (<= 0: this wave's rows lie wholly past a ragged M -- empty buffers)
+  const unsigned nrows = rows_left <= 0 ? 0u : (unsigned)(rows_left < 128 ? rows_left : 128);
+  // gate | up rows: lane -> (row lane >> 4, slot lane & 15: slots 0..7 the gate features f0.., 8..15 the up features at + I)
+  T* Cw = C != nullptr ? C + row0 * g.ldc + f0 : nullptr;
+  const bool gu_ok = f0 + (lane & 7) * 8 < I;
+  const unsigned gu_bytes = nrows * (unsigned)g.ldc * 2u, gu_step = gu_ok ? 4u * (unsigned)g.ldc * 2u : 0u;
+  const unsigned gu_off0 = gu_ok ? ((unsigned)(lane >> 4) * (unsigned)g.ldc + (unsigned)((lane & 8) ? I : 0) + (unsigned)(lane & 7) * 8u) * 2u
+                                 : 0xfffffff0u;
+  // act rows: lane -> (row lane >> 3, slot lane & 7)
+  T* C2w = reinterpret_cast<T*>(g.C2) + row0 * g.ldc2 + f0;
+  const bool act_ok = f0 + (lane & 7) * 8 < I;
+  const unsigned act_bytes = nrows * (unsigned)g.ldc2 * 2u, act_step = act_ok ? 8u * (unsigned)g.ldc2 * 2u : 0u;
+  const unsigned act_off0 = act_ok ? ((unsigned)(lane >> 3) * (unsigned)g.ldc2 + (unsigned)(lane & 7) * 8u) * 2u : 0xfffffff0u;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -455,38 +413,48 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) {
           const int mb = half * 4 + m4;
-          float gg[4], uu[4], aa[4];
+          // one vector conversion per PAIR and rounding point; the packed registers are what gets staged, their halves read
+          // back as fp32 are the rounded values (a round_through per element is a convert + shift each: the epilogue runs
+          // with the matrix pipe idle, so its instruction count is launch time -- 3705 -> ~2100 instructions per wave)
+          const f32x4 ag = acc[4 * p + sub][mb], au = acc[4 * p + 2 + sub][mb];
+          const u32x2 gp = {pack2<T>(ag[0], ag[1]), pack2<T>(ag[2], ag[3])};
+          const u32x2 up = {pack2<T>(au[0], au[1]), pack2<T>(au[2], au[3])};
+          float gg[4], uu[4], sl[4];
+          unpack2<T>(gp[0], gg[0], gg[1]);
+          unpack2<T>(gp[1], gg[2], gg[3]);
+          unpack2<T>(up[0], uu[0], uu[1]);
+          unpack2<T>(up[1], uu[2], uu[3]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            gg[e] = round_through<T>(acc[4 * p + sub][mb][e]);
-            uu[e] = round_through<T>(acc[4 * p + 2 + sub][mb][e]);
-            aa[e] = round_through<T>(gemm_silu(gg[e])) * uu[e];
-          }
+          for (int e = 0; e < 4; ++e) sl[e] = gemm_silu(gg[e]);
+          const u32x2 sp = {pack2<T>(sl[0], sl[1]), pack2<T>(sl[2], sl[3])};
+          unpack2<T>(sp[0], sl[0], sl[1]);
+          unpack2<T>(sp[1], sl[2], sl[3]);
           const unsigned r = (unsigned)(m4 * 16 + l15);
-          lds_write8(smem, st_off + r * GU_ROWB + (unsigned)nl * 2u, u32x2{pack2<T>(gg[0], gg[1]), pack2<T>(gg[2], gg[3])});
-          lds_write8(smem, st_off + r * GU_ROWB + (unsigned)(64 + nl) * 2u,
-                     u32x2{pack2<T>(uu[0], uu[1]), pack2<T>(uu[2], uu[3])});
+          lds_write8(smem, st_off + r * GU_ROWB + (unsigned)nl * 2u, gp);
+          lds_write8(smem, st_off + r * GU_ROWB + (unsigned)(64 + nl) * 2u, up);
           lds_write8(smem, st_off + ACT_OFF + r * ACT_ROWB + (unsigned)nl * 2u,
-                     u32x2{pack2<T>(aa[0], aa[1]), pack2<T>(aa[2], aa[3])});
+                     u32x2{pack2<T>(sl[0] * uu[0], sl[1] * uu[1]), pack2<T>(sl[2] * uu[2], sl[3] * uu[3])});
         }
       }
     }
     wave_lockstep_point();
+    // (addressing as in gemm_epilogue_rows: wave-uniform buffer base, 32-bit lane offsets, the hardware's range check for the
+    // matrix edge)
     if (C != nullptr) {
-#pragma unroll 4
+      unsigned go = gu_off0 + (unsigned)half * 16u * gu_step;
+#pragma unroll
       for (int it = 0; it < 16; ++it) {  // 64 rows x 16 slots of 16 B: 4 rows per wave instruction
-        const int row = it * 4 + (lane >> 4), slot = lane & 15;
-        const int64_t gm_ = row0 + half * 64 + row, f = f0 + (slot & 7) * 8;
-        const u32x4 v = lds_read16(smem, st_off + (unsigned)row * GU_ROWB + (unsigned)slot * 16u);
-        if (gm_ < g.M && f < I) st16_nt(C + gm_ * g.ldc + (slot >= 8 ? I : 0) + f, v);
+        const u32x4 v = lds_read16(smem, st_off + (unsigned)(it * 4 + (lane >> 4)) * GU_ROWB + (unsigned)(lane & 15) * 16u);
+        buf_store16_rng_nt(Cw, gu_bytes, go, v);
+        go += gu_step;
       }
     }
-#pragma unroll 4
+    unsigned ao = act_off0 + (unsigned)half * 8u * act_step;
+#pragma unroll
     for (int it = 0; it < 8; ++it) {  // 64 rows x 8 slots: 8 rows per wave instruction
-      const int row = it * 8 + (lane >> 3), slot = lane & 7;
-      const int64_t gm_ = row0 + half * 64 + row, f = f0 + slot * 8;
-      const u32x4 v = lds_read16(smem, st_off + ACT_OFF + (unsigned)row * ACT_ROWB + (unsigned)slot * 16u);
-      if (gm_ < g.M && f < I) st16(C2 + gm_ * g.ldc2 + f, v);
+      const u32x4 v = lds_read16(smem, st_off + ACT_OFF + (unsigned)(it * 8 + (lane >> 3)) * ACT_ROWB + (unsigned)(lane & 7) * 16u);
+      buf_store16_rng(C2w, act_bytes, ao, v);
+      ao += act_step;
     }
     wave_lockstep_point();
   }
@@ -780,6 +748,17 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   // third carries a piece, the other two a fragment read (the last read 9 pairs ahead of the hand-off's lgkmcnt(0));
   // otherwise reads behind the pairs 0..15, pieces behind the odd pairs 17..31.
   constexpr bool EARLY = (!A_KM || (DBG & 32)) && !(DBG & 128);
+  // diagnostic placements (round 5, after the PMC side-by-side with hipBLASLt's kernel showed our waves parked at the hand-off
+  // twice as long as theirs, profiles/r05a_gemm_vs_hipblaslt_pmc.md): 1 = pieces behind the even pairs 0..14, reads behind the odd
+  // pairs 1..15 and 16..23; 2 = all 8 pieces behind the pairs 0..7, reads behind 8..23; 3 = as 2, and the hand-off is split --
+  // only the write-after-read half (lgkmcnt(0) + barrier) stays at the k-step boundary, the wait for the landed stage
+  // (vmcnt(16) + barrier) moves behind the 8 pieces of k-step 1, in front of the first read of the new stage: the operand
+  // with the short lead (B) gets a whole stage (128-144 MFMAs instead of 82-124)
+  // Measured (profiles/r05b_gemm_piece_ab.jsonl, r05c_gemm_piece_ab.jsonl; interleaved, two MI355X boxes): placement 1 within
+  // +-0.2 % of the product schedule on the five forward shapes over five rounds (the first box's +0...2.6 % over three rounds
+  // was noise), 2 -1 ... -2.5 %, 3 -2 ... -4 %: back-to-back LDS-DMA issues and a barrier inside the MFMA stream cost more
+  // than the longer lead buys.  The product schedule stays EARLY; the three stay selectable in the diagnostic library.
+  constexpr int PLACE = (DBG & 64) ? 1 : ((DBG & 256) ? 2 : ((DBG & 512) ? 3 : 0));
   auto kstep = [&](int buf, int ra, int rb, int rq, int pb, int ps) __attribute__((always_inline)) {
     kstep_open();
 #pragma unroll
@@ -788,7 +767,18 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
       acc[nb][mb] = mfma16<T>(fw[buf][nb], fx[buf][mb], acc[nb][mb]);
       acc[nb][mb + 1] = mfma16<T>(fw[buf][nb], fx[buf][mb + 1], acc[nb][mb + 1]);
       sched_fence();
-      if (EARLY) {
+      if (PLACE == 1) {
+        if (p < 16 && (p & 1) == 0) issue(pb + (p >> 1), ps);
+        if (p < 16 && (p & 1) == 1) rd1(ra, rb, rq, buf ^ 1, p >> 1);
+        if (p >= 16 && p < 24) rd1(ra, rb, rq, buf ^ 1, p - 8);
+      } else if (PLACE >= 2) {
+        if (p < 8) issue(pb + p, ps);
+        if (PLACE == 3 && buf == 1 && p == 7) {  // the landed stage s+1: everybody's pieces (all but the 16 newest loads)
+          wait_vmcnt<16>();
+          raw_barrier();
+        }
+        if (p >= 8 && p < 24) rd1(ra, rb, rq, buf ^ 1, p - 8);
+      } else if (EARLY) {
         if (p < 24 && p % 3 != 2) rd1(ra, rb, rq, buf ^ 1, p - p / 3);
         if (p < 24 && p % 3 == 2) issue(pb + p / 3, ps);
       } else {
@@ -823,7 +813,7 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
         if (s + 2 == nst) park();
         kstep(0, sa, sb, 1, 0, sa2);  // k-step 0 | second-half fragments of stage s | A_{s+2}
         // hand-off: stage s+1 has landed for everybody; everybody's reads of stage s are in registers
-        if (!(DBG & 4)) wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 newest (A_{s+2}) stay in flight
+        if (!(DBG & 4) && PLACE != 3) wait_vmcnt<8>();  // own B_{s+1} (and the older A_{s+1}); the 8 newest (A_{s+2}) stay in flight
         wait_lgkmcnt0();
         if (!(DBG & 8)) raw_barrier();
         sched_fence();
@@ -837,9 +827,9 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   TAMD_CLOCK_END
   // (the epilogue takes its lane index from v_mbcnt: kept from the kernel entry it is spilled around the K loop, and a
   // kernel with scratch is throttled in how many of its waves a CU runs)
-  // (... except the row-major residual epilogue, where it is the other way round: checked per instantiation with
-  // tools/gemm_isa.sh -- no product kernel of the Llama / BERT step has scratch)
-  const int elane = (EPI == TAMD_EPI_RESIDUAL && !(A_KM && B_KN)) ? lane : lane_id_mbcnt();
+  // (checked per instantiation with tools/gemm_isa.sh and tests/test_isa_lint.py: since the buffer-addressed way out of round 5 no
+  // full-line instantiation has scratch -- the k-major residual / accumulate ones used to spill 5-17 registers)
+  const int elane = lane_id_mbcnt();
   if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per accumulator block
     float* ws = g.ws + (int64_t)split * g.M * g.N;
     const int l15 = elane & 15, g4 = elane >> 4;
@@ -858,7 +848,7 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
     gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), m0 + wm * 128,
                             (n0 >> 1) + wn * 64, elane);
   } else {
-    constexpr int E2 = (EPI == kEpiSplitK || EPI == kEpiSwiGLU) ? TAMD_EPI_NONE : EPI;  // (kEpiRope: in the way out)
+    constexpr int E2 = (EPI == kEpiSplitK || EPI == kEpiSwiGLU) ? TAMD_EPI_NONE : EPI;
     if (A_KM && B_KN && (EPI == TAMD_EPI_NONE || EPI == TAMD_EPI_ACCUM)) {  // dW: the tile's segment (wave-uniform selects;
       GemmArgs gs = g;                                                        // ONE epilogue instance: a second one spills)
       gs.C = gemm_seg_base<T>(g, m0);
@@ -999,189 +989,6 @@ __global__ __launch_bounds__(kSmThreads, 2) void gemm_sm_kernel(GemmArgs g) {
   gemm_epilogue<T, EPI, ACT, 2, 2>(g, acc, smem, (unsigned)wave * kSmStageWave, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
-// ============================================================================================ two workgroups per CU
-// 256 x 128 tile, 4 waves x (128 x 64) on v_mfma_f32_16x16x32, 32-deep units of A[256][32] (16 KiB) + B[128][32] (8 KiB) in a
-// ring of three (72 KiB), at most 256 registers per lane: TWO workgroups share a CU, so one's hand-offs, operand latency and
-// -- above all -- its way out (one wave per SIMD in gemm_fl_kernel: the matrix pipe idles while a tile leaves) sit under the
-// other's MFMAs.  Meant for the products gemm_fl_kernel serves badly: short K loops (bert-base: 12 stages of 64, where
-// prologue + epilogue are a third of a tile's time), grids of 1.2 - 2.5 dispatch rounds (a 128-wide tile halves the
-// quantum), expensive epilogues.  VERDICT r3 item 2 / 5; measurements: profiles/r04*_gemm_tw_ab.jsonl.
-// Forward layout (A [M,K], B [N,K] row-major), K % 32 == 0.
-//   LDS image of a unit: row r at r * 64 B, logical 16-byte chunk c at slot c ^ ((-(r >> 2)) & 3) -- applied on the LDS-DMA
-//   source address, undone on the fragment read; a 16x16x32 fragment read (16 rows x 4 chunks per ds_read_b128 lane group)
-//   is conflict-free with it (the ping-pong kernel's slot ^ ((r >> 2) & 3) is not: rows 0-3 and 4-7 would collide).
-//   Schedule of k-step j (unit j % 3): vmcnt(6) [own pieces of unit j landed; the 6 of unit j + 1 stay in flight] ->
-//   barrier -> 12 fragment reads (4 B, 8 A), 32 MFMAs as 8 groups that start as their A fragment arrives (counted lgkmcnt),
-//   and, one behind each of the groups 1 .. 6, this wave's 6 LDS-DMA pieces of unit j + 2 (the unit k-step j - 1 vacated:
-//   every wave passed this k-step's barrier after reading it).  Fragments are NOT read a k-step ahead: with two workgroups
-//   per CU the partner's MFMAs cover the read latency, and the registers stay under 256.
-constexpr int kTwThreads = 256;
-constexpr int kTwBM = 256, kTwBN = 128, kTwK = 32;
-constexpr unsigned kTwA = (unsigned)kTwBM * kTwK * 2u;  // 16 KiB
-constexpr unsigned kTwB = (unsigned)kTwBN * kTwK * 2u;  // 8 KiB
-constexpr unsigned kTwUnit = kTwA + kTwB;
-constexpr int kTwRing = 3;
-constexpr int kTwSmem = kTwRing * (int)kTwUnit;  // 73728 (the way out stages 4 x 64 rows x 144 B = 36 KiB in it)
-
-// s_waitcnt lgkmcnt(N) that fragment `f` depends on (untracked LDS reads complete in issue order: N = reads issued after it)
-template <int N>
-__device__ __forceinline__ void gemm_wait_frag(u32x4& f) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
-#else
-  (void)f;
-#endif
-}
-
-// way out of a wave of gemm_tw_kernel: acc[nb][mb][r] = D[n = nb*16 + 4*(lane>>4) + r][m = mb*16 + (lane&15)], 4 x 8 blocks = a
-// 128 x 64 piece of C
-template <typename T, int EPI, int ACT>
-__device__ __forceinline__ void gemm_epilogue16n(const GemmArgs& g, f32x4 (&acc)[4][8], char* smem, unsigned st_off,
-                                                 int64_t row0, int64_t col0, int lane) {
-  constexpr int ROWB = 64 * 2 + 16;
-  const int g4 = lane >> 4, l15 = lane & 15;
-  auto stage_as = [&](auto epi_tag, int half) {
-    constexpr int E = decltype(epi_tag)::value;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      const int nl = nb * 16 + 4 * g4;  // first of 4 consecutive local columns
-      float bv[4];
-      gemm_bias4<T, E>(g, col0 + nl, bv);
-      const float sc = gemm_colscale4<E>(g, col0 + nl);
-#pragma unroll
-      for (int m4 = 0; m4 < 4; ++m4) {
-        const f32x4 a = acc[nb][half * 4 + m4];
-        lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
-                   gemm_round4<T, E, ACT>(a[0], a[1], a[2], a[3], bv, sc));
-      }
-    }
-  };
-  if (EPI == TAMD_EPI_BIAS_ACT && g.C2 != nullptr) {
-    const GemmArgs gp = gemm_pre_args(g);
-    gemm_epilogue_rows<T, TAMD_EPI_BIAS, ACT, 64, 2>(gp, smem, st_off, row0, col0, lane, [&](int half) {
-      stage_as(std::integral_constant<int, TAMD_EPI_BIAS>{}, half);
-    });
-  }
-  gemm_epilogue_rows<T, EPI, ACT, 64, 2>(g, smem, st_off, row0, col0, lane,
-                                         [&](int half) { stage_as(std::integral_constant<int, EPI>{}, half); });
-}
-
-template <typename T, int EPI, int ACT>
-__global__ __launch_bounds__(kTwThreads, 2) void gemm_tw_kernel(GemmArgs g) {
-  TAMD_DYN_SMEM(smem);
-  const int lane = threadIdx.x & 63;
-  const int wave = wave_id_uniform();
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g4 = lane >> 4, l15 = lane & 15;
-  int tile_m, tile_n;
-  gemm_tile_of_block(g, (int)blockIdx.x, &tile_m, &tile_n);
-  const int64_t m0 = (int64_t)tile_m * kTwBM, n0 = (int64_t)tile_n * kTwBN;
-  const T* A = reinterpret_cast<const T*>(g.A);
-  const T* B = reinterpret_cast<const T*>(g.B);
-
-  f32x4 acc[4][8];  // [nb][mb]
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // per-lane source offsets of this wave's 4 A pieces and 2 B pieces of a unit (piece = 16 rows x 64 B; lane -> row lane>>2,
-  // LDS slot lane&3 holding logical chunk slot ^ f(row)); rows past M / N are clamped to the last valid one (their products
-  // land in rows / columns the way out never stores).  Buffer-addressed LDS-DMA: wave-uniform operand base stepped 64 B per
-  // k-step, loop-invariant 32-bit lane offsets, one M0 per operand through the shared immediate (gemm_fl_kernel's scheme).
-  unsigned voff[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const bool isa = i < 4;
-    const int row = (isa ? (wave * 4 + i) : (wave * 2 + (i - 4))) * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
-    const int64_t gr = isa ? ((m0 + row < g.M) ? m0 + row : g.M - 1) - m0 : ((n0 + row < g.N) ? n0 + row : g.N - 1) - n0;
-    const int64_t o = gr * (isa ? g.lda : g.ldb) + c * 8;
-    voff[i] = (unsigned)(o * 2 + 4096 - (isa ? i : i - 4) * 1024);
-  }
-  const char* base_a = (const char*)(A + m0 * g.lda) - 4096;
-  const char* base_b = (const char*)(B + n0 * g.ldb) - 4096;
-  int64_t kinc = kTwK * 2;  // bytes per k-step; 0 once parked
-  const int nk = (int)(g.K / kTwK);
-  auto issue = [&](int p, int unit) {  // piece p (0..3 A, 4..5 B) of this wave into ring unit `unit`
-    const unsigned ub = (unsigned)unit * kTwUnit;
-    switch (p) {
-      case 0: glds16_buf<0>(base_a, voff[0], smem, ub + (unsigned)wave * 4096u); break;
-      case 1: glds16_buf<1024>(base_a, voff[1], smem, ub + (unsigned)wave * 4096u); break;
-      case 2: glds16_buf<2048>(base_a, voff[2], smem, ub + (unsigned)wave * 4096u); break;
-      case 3: glds16_buf<3072>(base_a, voff[3], smem, ub + (unsigned)wave * 4096u); break;
-      case 4: glds16_buf<0>(base_b, voff[4], smem, ub + kTwA + (unsigned)wave * 2048u); break;
-      default: glds16_buf<1024>(base_b, voff[5], smem, ub + kTwA + (unsigned)wave * 2048u); break;
-    }
-    if (p == 5) {  // every piece of the unit is out: step both operands to the next k-step
-      base_a += kinc;
-      base_b += kinc;
-    }
-  };
-  auto park = [&]() {  // past the last k-step: keep the load counts uniform and re-read the last valid unit (idempotent)
-    base_a -= kinc;
-    base_b -= kinc;
-    kinc = 0;
-  };
-  // fragment addresses (absolute LDS byte addresses; the unit and the block go into the immediates)
-  const unsigned fsw = (unsigned)((-(l15 >> 2)) & 3);
-  const unsigned lds0 = lds_base_u32(smem);
-  const unsigned addr_x = lds0 + (unsigned)(wm * 128 + l15) * 64u + (((unsigned)g4 ^ fsw) * 16u);
-  const unsigned addr_w = lds0 + kTwA + (unsigned)(wn * 64 + l15) * 64u + (((unsigned)g4 ^ fsw) * 16u);
-
-  // prologue: units 0 and 1
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    if (j == nk) park();
-#pragma unroll
-    for (int p = 0; p < 6; ++p) issue(p, j);
-  }
-  for (int j0 = 0; j0 < nk; j0 += kTwRing) {
-#pragma unroll
-    for (int u = 0; u < kTwRing; ++u) {
-      const int j = j0 + u;
-      if (j < nk) {
-        sched_fence();
-        if (j + 2 == nk) park();
-        wait_vmcnt<6>();  // own pieces of unit u (older than the 6 newest = unit u + 1's)
-        raw_barrier();    // everybody's; and everybody is done reading unit (u + 2) % 3 (k-step j - 1)
-        sched_fence();
-        u32x4 fw[4], fx[8];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) fw[nb] = lds_read16_abs(addr_w, u * (int)kTwUnit + nb * 1024);
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) fx[mb] = lds_read16_abs(addr_x, u * (int)kTwUnit + mb * 1024);
-        gemm_wait_frag<8>(fw[0]);  // the four B fragments (8 reads were issued after the last of them)
-        gemm_wait_frag<8>(fw[1]);
-        gemm_wait_frag<8>(fw[2]);
-        gemm_wait_frag<8>(fw[3]);
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-          switch (mb) {  // 7 - mb reads were issued after fx[mb]
-            case 0: gemm_wait_frag<7>(fx[0]); break;
-            case 1: gemm_wait_frag<6>(fx[1]); break;
-            case 2: gemm_wait_frag<5>(fx[2]); break;
-            case 3: gemm_wait_frag<4>(fx[3]); break;
-            case 4: gemm_wait_frag<3>(fx[4]); break;
-            case 5: gemm_wait_frag<2>(fx[5]); break;
-            case 6: gemm_wait_frag<1>(fx[6]); break;
-            default: gemm_wait_frag<0>(fx[7]); break;
-          }
-          sched_fence();
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) acc[nb][mb] = mfma16<T>(fw[nb], fx[mb], acc[nb][mb]);
-          sched_fence();
-          if (mb >= 1 && mb <= 6) issue(mb - 1, (u + 2) % kTwRing);
-          sched_fence();
-        }
-      }
-    }
-  }
-  wait_vmcnt<0>();
-  raw_barrier();
-  gemm_epilogue16n<T, EPI, ACT>(g, acc, smem, (unsigned)wave * (64u * (64 * 2 + 16)), m0 + wm * 128, n0 + wn * 64, lane);
-}
-
 // out[m][n] = epilogue(sum_s ws[s][m][n]): 4 columns per thread (16-byte reads, 8-byte stores).  The reduction applies the
 // product's epilogue with the roundings of the unsplit kernel -- MODE = TAMD_EPI_NONE round(acc); TAMD_EPI_BIAS
 // round(acc + bias); TAMD_EPI_RESIDUAL round(round(acc [+ bias]) + R); TAMD_EPI_ACCUM round(round(acc) + C_old) -- so a
@@ -1320,6 +1127,17 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 128>), grid, block, (size_t)kXSmem, s, g);
     return launch_status();
   }
+  if constexpr (!A_KM) {  // round-5 placements (forward and dX layouts; correct, bit-identical results)
+    if ((dbg == 64 || dbg == 256 || dbg == 512) && epilogue == TAMD_EPI_NONE) {
+      if (dbg == 64)
+        hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 64>), grid, block, (size_t)kXSmem, s, g);
+      else if (dbg == 256)
+        hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 256>), grid, block, (size_t)kXSmem, s, g);
+      else
+        hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 512>), grid, block, (size_t)kXSmem, s, g);
+      return launch_status();
+    }
+  }
   if (dbg && epilogue == TAMD_EPI_NONE && !A_KM && !B_KN) {
 #define TAMD_GD(N_)                                                                                             \
   hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, TAMD_EPI_NONE, TAMD_ACT_NONE, N_>), grid, block, (size_t)kXSmem, \
@@ -1398,19 +1216,6 @@ static int gemm_sm_launch(GemmArgs g, int epilogue, int act, hipStream_t s) {
 #undef TAMD_G
 }
 
-// the 256 x 128 kernel, two workgroups per CU (row-major operands, K % 32 == 0): tiles_n re-counted for its tile
-template <typename T>
-static int gemm_tw_launch(GemmArgs g, int epilogue, int act, hipStream_t s) {
-  g.tiles_m = (int)ceil_div(g.M, kTwBM);
-  g.tiles_n = (int)ceil_div(g.N, kTwBN);
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kTwThreads);
-#define TAMD_G(E_, A_)                                                                    \
-  hipLaunchKernelGGL((gemm_tw_kernel<T, E_, A_>), grid, block, (size_t)kTwSmem, s, g); \
-  return launch_status();
-  TAMD_EPI_SWITCH(TAMD_G)
-#undef TAMD_G
-}
-
 }  // namespace tamd
 
 using namespace tamd;
@@ -1461,8 +1266,6 @@ static int gemm_fill_args(GemmArgs* g, const void* A, const void* B, void* C, co
   g->C2 = nullptr;
   g->ldc2 = 0;
   g->n_half = 0;
-  g->seq = 1;
-  g->cos_batch = 1;
   g->scale_cols = 0;
   g->col_scale = 1.f;
   g->C_seg1 = g->C_seg2 = nullptr;
@@ -1561,7 +1364,7 @@ static int gemm_run(GemmArgs& g, int flags, int epilogue, int act, int dtype, vo
   const int64_t M = g.M, N = g.N, K = g.K;
   static const int forced = [] {
     const char* e = getenv("TAMD_GEMM");
-    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 's' ? 2 : (e[0] == 't' ? 4 : 0))));
+    return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 's' ? 2 : 0)));
   }();
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
@@ -1588,9 +1391,6 @@ static int gemm_run(GemmArgs& g, int flags, int epilogue, int act, int dtype, vo
   // 128 x 128 tiles when the 256 x 256 grid would leave most of the GPU idle (and split-K, above, did not take the
   // problem: bias / activation / residual epilogues, short K): row-major operands only.  Threshold from the A/B of the two
   // kernels over tile counts, profiles/r03q_gemm_sm_ab.jsonl
-  if (sched == 4 && K % kTwK == 0 && flags == 0) {  // (hint only: the default dispatch does not select it yet)
-    TAMD_DISPATCH_HALF(dtype, return (gemm_tw_launch<T>(g, epilogue, act, TAMD_STREAM(stream))));
-  }
   if (K % kXK == 0 && flags == 0 && (sched == 2 || (sched == 0 && (int64_t)g.tiles_m * g.tiles_n <= kSmMaxBigTiles))) {
     TAMD_DISPATCH_HALF(dtype, return (gemm_sm_launch<T>(g, epilogue, act, TAMD_STREAM(stream))));
   }
@@ -1783,24 +1583,6 @@ extern "C" int tamd_gemm_group(const tamd_gemm_problem* problems, int count, int
   return TAMD_E_DTYPE;
 }
 
-// BertIntermediate / CLIPMLP.fc1 / GPT2MLP.c_fc in train mode (models/bert/modeling_bert.py:334-337): the activation AND the
-// rounded pre-activation its backward needs, from one GEMM:
-//   PRE[M,N] = round(A . B^T + bias)      Y[M,N] = round(act(PRE))        -- the bits of tamd_gemm(TAMD_EPI_BIAS) followed by
-// tamd_bias_act_fwd (= of tamd_gemm(TAMD_EPI_BIAS_ACT) for Y)
-extern "C" int tamd_gemm_bias_act_pre(const void* A, const void* B, void* Y, void* PRE, const void* bias, int64_t M,
-                                      int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldy, int64_t ldpre, int flags,
-                                      int act, int dtype, tamd_stream_t stream) {
-  const int st = gemm_check(A, B, Y, bias, nullptr, M, N, K, lda, ldb, ldy, 0, flags, TAMD_EPI_BIAS_ACT);
-  if (st != TAMD_OK) return st;
-  if (!PRE) return TAMD_E_NULL;
-  if ((ldpre % 8) || !aligned16(PRE)) return (ldpre % 8) ? TAMD_E_SHAPE : TAMD_E_ALIGN;
-  GemmArgs g;
-  gemm_fill_args(&g, A, B, Y, bias, nullptr, M, N, K, lda, ldb, ldy, 0);
-  g.C2 = PRE;
-  g.ldc2 = ldpre;
-  return gemm_run(g, flags, TAMD_EPI_BIAS_ACT, act, dtype, nullptr, 0, stream);
-}
-
 // A projection whose leading columns leave scaled (the query columns of a fused q|k|v projection, models/bert/
 // modeling_bert.py:175-177, carrying the attention kernels' scale*log2(e): tamd_attn_params.q_prescaled):
 //   C[m, n] = round((A . B^T [+ bias])[m, n] * (n < scale_cols ? col_scale : 1))      -- ONE rounding, like the reference's q
@@ -1840,34 +1622,6 @@ extern "C" int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* 
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
   TAMD_DISPATCH_HALF(dtype, {
     hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, kEpiSwiGLU, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
-                       TAMD_STREAM(stream), g);
-    return launch_status();
-  });
-  return TAMD_E_DTYPE;
-}
-
-// q|k|v projection of LlamaAttention with apply_rotary_pos_emb in the GEMM epilogue (models/llama/modeling_llama.py:254-262):
-//   QKV[M, N] = X[M,K] . Wqkv[N,K]^T, then the rotary embedding on the first rope_cols columns (query and key heads of
-// 128; the value heads pass through), cos / sin [cos_batch, seq, 128] indexed by token m (m % seq when cos_batch == 1).
-// Results are bit-identical to tamd_gemm followed by tamd_rope_inplace.
-extern "C" int tamd_gemm_rope(const void* X, const void* Wqkv, void* QKV, const void* cosp, const void* sinp, int64_t M,
-                              int64_t N, int64_t K, int64_t ldx, int64_t ldw, int64_t ldqkv, int64_t seq,
-                              int64_t cos_batch, int64_t rope_cols, int dtype, tamd_stream_t stream) {
-  if (!X || !Wqkv || !QKV || !cosp || !sinp) return TAMD_E_NULL;
-  if (M <= 0 || N <= 0 || K <= 0 || seq <= 0 || cos_batch <= 0) return TAMD_E_SHAPE;
-  if ((K % kXK) || (N % 128) || (rope_cols % 128) || rope_cols > N || (ldx % 8) || (ldw % 8) || (ldqkv % 8)) return TAMD_E_SHAPE;
-  if (cos_batch != 1 && cos_batch * seq != M) return TAMD_E_SHAPE;
-  if (cos_batch == 1 && seq < 128) return TAMD_E_SHAPE;  // (the way out wraps the shared table's row index once per 128 rows)
-  if (!aligned16(X) || !aligned16(Wqkv) || !aligned16(QKV) || !aligned16(cosp) || !aligned16(sinp)) return TAMD_E_ALIGN;
-  GemmArgs g;
-  gemm_fill_args(&g, X, Wqkv, QKV, nullptr, cosp, M, N, K, ldx, ldw, ldqkv, 128);
-  g.C2 = const_cast<void*>(sinp);
-  g.n_half = rope_cols;
-  g.seq = seq;
-  g.cos_batch = cos_batch;
-  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
-  TAMD_DISPATCH_HALF(dtype, {
-    hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, kEpiRope, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
                        TAMD_STREAM(stream), g);
     return launch_status();
   });

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void gemv_swiglu_kernel(GemvArgs g) {
   const int64_t i = i0 + r;
   if (lane < MB * R && m < g.M && i < inter) {
     const float gr = round_through<T>(gate), ur = round_through<T>(up);
-    const float sg = 1.f / (1.f + __expf(-gr));  // = silu_f of elementwise.hip
+    const float sg = fast_sigmoid(gr);  // = silu_f of elementwise.hip
     reinterpret_cast<raw*>(g.Y)[m * g.ldy + i] = elem<T>::from_f32(round_through<T>(gr * sg) * ur);
     if (g.R != nullptr) {
       raw* gu = reinterpret_cast<raw*>(const_cast<void*>(g.R));
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gemv_mfma_kernel(GemvArgs g) {
         constexpr int UP = SWIGLU ? RB : 0;
         const float u = ((red[0][UP + rb][lane][r] + red[1][UP + rb][lane][r]) + red[2][UP + rb][lane][r]) + red[3][UP + rb][lane][r];
         const float gr = round_through<T>(v), ur = round_through<T>(u);
-        const float sg = 1.f / (1.f + __expf(-gr));  // = silu_f of elementwise.hip
+        const float sg = fast_sigmoid(gr);  // = silu_f of elementwise.hip
         reinterpret_cast<raw*>(g.Y)[m * g.ldy + n] = elem<T>::from_f32(round_through<T>(gr * sg) * ur);
         if (g.R != nullptr) {
           raw* gu = reinterpret_cast<raw*>(const_cast<void*>(g.R));

@@ -214,6 +214,11 @@ __device__ __forceinline__ void buf_store16_rng(void* base, unsigned bytes, unsi
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)bytes, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, (int)voff, 0, 0);
 }
+// ... as a streaming store (nt): output nobody reads again soon (activations saved for the backward)
+__device__ __forceinline__ void buf_store16_rng_nt(void* base, unsigned bytes, unsigned voff, u32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(base, (short)0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), r, (int)voff, 0, 2);
+}
 // 4-byte variant (global_load_lds_dword): the wave writes 64 x 4 B = 256 B contiguous at smem + wave_base_off
 __device__ __forceinline__ void glds4(const void* gsrc, char* smem, unsigned wave_base_off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -254,6 +259,12 @@ __device__ __forceinline__ unsigned device_xcc_id() { return __builtin_amdgcn_s_
 // fast transcendental pieces
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// logistic function of the SiLU / quick-GELU paths (activations.py:92-123): 1 / (1 + exp(-x)) as v_exp_f32 + v_rcp_f32 (1 ulp
+// each; every user rounds the product to a 16-bit storage type right after).  ONE definition for the GEMM epilogues, the
+// element-wise kernels and the weight-streaming kernels, so that fused and unfused paths agree bit for bit.  (An IEEE
+// division here is ten instructions per element -- v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup -- a third of the
+// SwiGLU epilogue of the gate|up GEMM, during which the matrix pipe idles.)
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.f + fast_exp2(x * -1.44269504088896340736f)); }
 __device__ __forceinline__ float fast_log2(float x) { return __log2f(x); }
 
 }  // namespace tamd

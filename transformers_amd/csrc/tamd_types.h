@@ -193,4 +193,16 @@ __device__ __forceinline__ unsigned int pack2<f16_t>(float lo, float hi) {
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
 }
 
+// the two 16-bit elements of a packed register as fp32 (the inverse of pack2: what a value rounded through T reads back as)
+template <typename T>
+__device__ __forceinline__ void unpack2(unsigned int w, float& lo, float& hi) {
+  lo = elem<T>::to_f32((typename elem<T>::raw)(w & 0xffffu));
+  hi = elem<T>::to_f32((typename elem<T>::raw)(w >> 16));
+}
+template <>
+__device__ __forceinline__ void unpack2<bf16_t>(unsigned int w, float& lo, float& hi) {
+  lo = __builtin_bit_cast(float, w << 16);
+  hi = __builtin_bit_cast(float, w & 0xffff0000u);
+}
+
 }  // namespace tamd

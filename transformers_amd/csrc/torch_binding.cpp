@@ -43,7 +43,7 @@ using OptTensor = std::optional<at::Tensor>;
   X(tamd_bert_embeddings_fwd) X(tamd_swiglu_fwd) X(tamd_swiglu_bwd) X(tamd_bias_act_fwd) X(tamd_bias_act_bwd)         \
   X(tamd_add) X(tamd_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
   X(tamd_cross_entropy_fwd) X(tamd_cross_entropy_bwd) X(tamd_gemm) X(tamd_gemm_workspace_bytes) X(tamd_gemm_ws)       \
-  X(tamd_gemm_swiglu) X(tamd_gemm_rope) X(tamd_gemm_bias_act_pre) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_gemm_group_workspace_bytes) X(tamd_gemm_group) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
+  X(tamd_gemm_swiglu) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_gemm_group_workspace_bytes) X(tamd_gemm_group) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
   X(tamd_attn_decode_workspace_bytes) X(tamd_attn_decode)
 
 struct Api {
@@ -531,21 +531,6 @@ Tensor gemm_plain(const Tensor& a, const Tensor& b, bool a_km = false, bool b_kn
   return k_gemm(a, b, a_km, b_kn, bias, residual, epilogue, act, out, 0);
 }
 
-// (y, pre) = (act(round(x2 . w^T + bias)), round(x2 . w^T + bias)) from one GEMM (tamd_gemm_bias_act_pre)
-std::tuple<Tensor, Tensor> k_gemm_bias_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
-  Launch L({&x2, &w, &bias});
-  TORCH_CHECK(x2.dim() == 2 && w.dim() == 2 && x2.stride(1) == 1 && w.stride(1) == 1 && x2.size(1) == w.size(1),
-              "tamd: gemm_bias_act_pre takes row-major x [M, K] and w [N, K]");
-  const int64_t m = x2.size(0), n = w.size(0), k = x2.size(1);
-  Tensor y = at::empty({m, n}, x2.options()), pre = at::empty({m, n}, x2.options());
-  GemmTimerScope timer(2.0 * (double)m * (double)n * (double)k, 2.0 * ((double)m * k + (double)n * k + 2.0 * (double)m * n),
-                       L.stream);
-  check(api().tamd_gemm_bias_act_pre(ptr(x2), ptr(w), mptr(y), mptr(pre), ptr(bias), m, n, k, x2.stride(0), w.stride(0), n, n,
-                                     0, (int)act, code_of(x2), L.stream),
-        "tamd_gemm_bias_act_pre");
-  return {y, pre};
-}
-
 // x2 . w^T (+ bias) with the first scale_cols columns multiplied by col_scale before the one rounding (tamd_gemm_colscale)
 Tensor k_gemm_colscale(const Tensor& x2, const Tensor& w, const OptTensor& bias, int64_t scale_cols, double col_scale) {
   Launch L({&x2, &w, p(bias)});
@@ -560,16 +545,54 @@ Tensor k_gemm_colscale(const Tensor& x2, const Tensor& w, const OptTensor& bias,
   return y;
 }
 
-// (act(pre), pre = round(x2 . w^T + bias)) for a layer whose backward needs the pre-activation.  One GEMM with both outputs
-// (tamd_gemm_bias_act_pre) or GEMM + activation kernel: on MI355X the fused way out lost badly for erf-GELU at bert-base --
-// 495 us against 84 + 38 (profiles/r04a_bert_kernel_stats.csv): the epilogue of the 256 x 256 kernel runs one wave per SIMD
-// with nothing to overlap, and ocml's erff is ~100 dependent, divergent instructions per element there (85 cycles per
-// element in the bandwidth-bound kernel, ~900 in the epilogue).  TAMD_FUSE_ACT_PRE=1 selects the one-GEMM form (bit-identical).
-const bool kFuseActPre = [] { const char* e = getenv("TAMD_FUSE_ACT_PRE"); return e != nullptr && std::string(e) != "0"; }();
+// (act(pre), pre = round(x2 . w^T + bias)) for a layer whose backward needs the pre-activation: GEMM with the bias epilogue +
+// the activation kernel.  (Both outputs from one GEMM epilogue lost badly on MI355X for erf-GELU at bert-base -- 495 us against
+// 84 + 38, profiles/r04a_bert_kernel_stats.csv: one wave per SIMD has nothing to overlap ocml's erff with; the entry point
+// went to profiles/r05_removed_variants.patch in round 5.)
 std::tuple<Tensor, Tensor> linear_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
-  if (kFuseActPre) return k_gemm_bias_act_pre(x2, w, bias, act);
   Tensor pre = gemm_plain(x2, w, false, false, bias, {}, TAMD_EPI_BIAS);
   return {k_bias_act_fwd(pre, {}, act), pre};
+}
+
+// Where to cut a weight-gradient product dW[M, N] = dy[K, M]^T . x[K, N] so that its 256 x 256 tile grid packs the 256 CUs:
+// a grid of a few dispatch rounds whose last round is mostly empty (Llama-3-8B: q|k|v 384 tiles = 1.5 rounds, down_proj 896 =
+// 3.5) used to be split along K as a whole -- every workgroup half the K range, fp32 partial tiles of the WHOLE output through
+// HBM and a reduction pass (201 / 470 MB of partials: 1325 / 2820 us where 1.5 / 3.5 rounds of the unsplit kernel are 1070 / 2490).
+// Instead: a main part whose tile count is a whole number of rounds (unsplit, no partials) and a remainder of at most half a
+// round, which the split-K policy of the library fills (128 tiles -> 2 splits).  Returns axis 0 (cut the M rows at `at`),
+// 1 (cut the N columns at `at`) or -1 (one launch: the grid already packs, or no such cut exists).
+struct DwCut {
+  int axis;
+  int64_t at;
+};
+DwCut dw_balanced_cut(int64_t m, int64_t n, int64_t k) {
+  constexpr int64_t kT = 256, kCUs = 256;
+  if (m % kT || n % kT || k % 64) return {-1, 0};
+  const int64_t tm = m / kT, tn = n / kT, tiles = tm * tn;
+  if (tiles <= kCUs || tiles % kCUs == 0 || tiles > 64 * kCUs) return {-1, 0};
+  for (int64_t r = tm - 1; r >= 1; --r)  // the largest main part first
+    if ((r * tn) % kCUs == 0 && (tm - r) * tn <= kCUs / 2) return {0, r * kT};
+  for (int64_t c = tn - 1; c >= 1; --c)
+    if ((c * tm) % kCUs == 0 && (tn - c) * tm <= kCUs / 2) return {1, c * kT};
+  return {-1, 0};
+}
+static const bool kDwBalance = [] { const char* e = getenv("TAMD_DW_BALANCE"); return e == nullptr || std::string(e) != "0"; }();
+
+// dW[M, N] = dy[K, M]^T . x[K, N] (both operands k-major) as one launch or as the two of dw_balanced_cut; `out` (optional): the
+// destination ([M, N] row-major view, e.g. a DDP bucket view)
+Tensor gemm_dw_balanced(const Tensor& dy, const Tensor& x, const OptTensor& out_ = {}) {
+  const int64_t k = dy.size(0), m = dy.size(1), n = x.size(1);
+  const DwCut cut = kDwBalance ? dw_balanced_cut(m, n, k) : DwCut{-1, 0};
+  if (cut.axis < 0) return k_gemm(dy, x, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, out_, 0);
+  Tensor out = out_ ? *out_ : at::empty({m, n}, dy.options());
+  if (cut.axis == 0) {
+    k_gemm(dy.narrow(1, 0, cut.at), x, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, out.narrow(0, 0, cut.at), 0);
+    k_gemm(dy.narrow(1, cut.at, m - cut.at), x, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, out.narrow(0, cut.at, m - cut.at), 0);
+  } else {
+    k_gemm(dy, x.narrow(1, 0, cut.at), true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, out.narrow(1, 0, cut.at), 0);
+    k_gemm(dy, x.narrow(1, cut.at, n - cut.at), true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, out.narrow(1, cut.at, n - cut.at), 0);
+  }
+  return out;
 }
 
 // dW[M, N] = dy[K, M]^T . x[K, N] with the M rows stored into `segs` (each [rows_i, N] contiguous: tamd_gemm_seg) -- the weight
@@ -679,33 +702,6 @@ std::tuple<Tensor, Tensor> k_gemm_swiglu(const Tensor& x2, const Tensor& wgu, bo
   return {gu, act};
 }
 
-// shapes the q|k|v GEMM with the rotary epilogue takes (csrc/gemm.hip tamd_gemm_rope): heads of 128; a cos / sin table shared
-// by the batch ([seq, 128]) needs seq >= 128
-bool gemm_rope_supported(const Tensor& x2, const Tensor& wqkv, const Tensor& cos, int64_t head_dim) {
-  const int64_t n = wqkv.size(0), k = wqkv.size(1);
-  return head_dim == 128 && ((cos.dim() == 3 && cos.size(0) > 1) || cos.size(-2) >= 128) && half_type(x2) &&
-         wqkv.scalar_type() == x2.scalar_type() && k % 64 == 0 && n % 128 == 0 && x2.stride(1) == 1 && wqkv.stride(1) == 1 &&
-         x2.stride(0) % 8 == 0 && wqkv.stride(0) % 8 == 0 && cos.size(-1) == 128 &&
-         api().tamd_gemm_workspace_bytes(x2.size(0), n, k, 3, TAMD_EPI_NONE) == 0;  // (small grids: as gemm_swiglu_supported)
-}
-
-Tensor k_gemm_rope(const Tensor& x2, const Tensor& wqkv, const Tensor& cos_, const Tensor& sin_, int64_t seq,
-                   int64_t rope_heads, int64_t head_dim) {
-  Launch L({&x2, &wqkv, &cos_, &sin_});
-  Tensor cos = contig(cos_), sin = contig(sin_);
-  if (cos.scalar_type() != x2.scalar_type()) {
-    cos = cos.to(x2.scalar_type());
-    sin = sin.to(x2.scalar_type());
-  }
-  const int64_t cos_batch = cos.dim() == 3 ? cos.size(0) : 1;
-  const int64_t t = x2.size(0), k = x2.size(1), n = wqkv.size(0);
-  Tensor out = at::empty({t, n}, x2.options());
-  GemmTimerScope timer(2.0 * (double)t * n * k, 2.0 * ((double)t * k + (double)n * k + (double)t * n), L.stream);
-  check(api().tamd_gemm_rope(ptr(x2), ptr(wqkv), mptr(out), ptr(cos), ptr(sin), t, n, k, x2.stride(0), wqkv.stride(0),
-                             out.stride(0), seq, cos_batch, rope_heads * head_dim, code_of(x2), L.stream),
-        "tamd_gemm_rope");
-  return out;
-}
 
 // ---- attention
 void fill_attn_params(tamd_attn_params* ap, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
@@ -880,9 +876,6 @@ std::tuple<Tensor, Tensor> op_bias_act_bwd(const Tensor& x, const OptTensor& bia
 }
 void op_gemm_dw_segments(const Tensor& dy, const Tensor& x, at::TensorList segs) { gemm_dw_segments(dy, x, segs.vec()); }
 std::vector<Tensor> op_gemm_dw_group(at::TensorList dy, at::TensorList x) { return gemm_dw_group(dy.vec(), x.vec()); }
-std::tuple<Tensor, Tensor> op_gemm_bias_act_pre(const Tensor& x2, const Tensor& w, const Tensor& bias, int64_t act) {
-  return k_gemm_bias_act_pre(x2, w, bias, act);
-}
 Tensor op_gemm_colscale(const Tensor& x2, const Tensor& w, const OptTensor& bias, int64_t scale_cols, double col_scale) {
   return k_gemm_colscale(x2, w, bias, scale_cols, col_scale);
 }
@@ -911,6 +904,10 @@ void op_adamw_step_(Tensor& pp, const Tensor& g, Tensor& m, Tensor& v, double lr
 }
 Tensor op_gemm(const Tensor& a, const Tensor& b, bool a_km, bool b_kn, const OptTensor& bias, const OptTensor& residual,
                int64_t epilogue, int64_t act, int64_t sched) {
+  // a plain weight-gradient product under the default dispatch (lm_head, the module-level linear layers): cut so that its
+  // tile grid packs the CUs (gemm_dw_balanced); a schedule hint keeps it one launch
+  if (a_km && b_kn && !bias && !residual && epilogue == TAMD_EPI_NONE && sched == 0 && a.dim() == 2 && b.dim() == 2)
+    return gemm_dw_balanced(a, b);
   return k_gemm(a, b, a_km, b_kn, bias, residual, epilogue, act, {}, sched);
 }
 void op_gemm_out(Tensor& out, const Tensor& a, const Tensor& b, bool a_km, bool b_kn, const OptTensor& bias,
@@ -920,10 +917,6 @@ void op_gemm_out(Tensor& out, const Tensor& a, const Tensor& b, bool a_km, bool 
 std::tuple<Tensor, Tensor> op_gemm_swiglu(const Tensor& x2, const Tensor& wgu, bool need_gu) {
   auto [gu, act] = k_gemm_swiglu(x2, wgu, need_gu);
   return {gu.defined() ? gu : nothing(x2), act};
-}
-Tensor op_gemm_rope(const Tensor& x2, const Tensor& wqkv, const Tensor& cos, const Tensor& sin, int64_t seq,
-                    int64_t rope_heads, int64_t head_dim) {
-  return k_gemm_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim);
 }
 std::tuple<Tensor, Tensor> op_attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale, bool causal,
                                        const OptTensor& key_valid, bool need_lse, double dropout_p, int64_t seed,
@@ -1122,9 +1115,6 @@ std::tuple<Tensor, Tensor, Tensor> op_padded_vocab_head_bwd(const OptTensor& g_l
 // ================================================================================================ LlamaDecoderLayer
 // tamd::llama_layer / tamd::llama_layer_bwd   LlamaDecoderLayer.forward, models/llama/modeling_llama.py:295-324, as ONE op
 // (one autograd node).  Knobs (A/B switches for measurements, read once from the environment):
-//   TAMD_FUSE_ROPE_FWD=1   apply_rotary_pos_emb in the q|k|v GEMM epilogue (tamd_gemm_rope) -- bit-identical and as fast
-//                          as GEMM + rotary kernel on MI355X (11.62 vs 11.62 / 11.54 ms per layer forward,
-//                          profiles/r03a_rope_fwd_ab.txt), so the simpler two-kernel path is the default
 //   TAMD_FUSE_ROPE_BWD=0   the transposed rotary as its own kernel instead of inside the attention backward's way out
 //   TAMD_SAVE_SWIGLU_ACT=0 re-materialise silu(gate)*up in the backward instead of keeping it (-30 GB at Llama-3-8B 8 x 4096,
 //                          +0.94 GB of HBM writes per layer)
@@ -1132,7 +1122,6 @@ bool env_flag(const char* name, bool dflt) {
   const char* e = getenv(name);
   return e == nullptr ? dflt : (std::string(e) != "0");
 }
-const bool kFuseRopeFwd = env_flag("TAMD_FUSE_ROPE_FWD", false);
 const bool kFuseRopeBwd = env_flag("TAMD_FUSE_ROPE_BWD", true);
 const bool kSaveSwigluAct = env_flag("TAMD_SAVE_SWIGLU_ACT", true);
 // the rotary kernel hands the attention kernels queries that already carry scale*log2(e), applied before its one rounding
@@ -1144,7 +1133,6 @@ const bool kBertPrescale = env_flag("TAMD_BERT_PRESCALE", true);
 // the layer's four weight gradients as ONE grouped launch at the end of its backward (gemm_dw_group) instead of four split-K
 // products where they arise: A/B switch
 const bool kBertGroupDw = env_flag("TAMD_BERT_GROUP_DW", true);
-const bool kLlamaGroupDw = env_flag("TAMD_LLAMA_GROUP_DW", false);  // llama_layer_bwd: A/B switch (see there)
 
 struct Qkv {
   Tensor q, k, v;
@@ -1154,11 +1142,6 @@ Qkv split_qkv(const Tensor& qkv, int64_t b, int64_t s, int64_t hq, int64_t hkv, 
           qkv.narrow(1, (hq + hkv) * d, hkv * d).view({b, s, hkv, d})};
 }
 
-// does the layer's rotary kernel deliver pre-scaled queries?  (not when the rotary embedding rides in the q|k|v GEMM's
-// epilogue, which keeps the reference's bits)
-bool llama_q_prescaled(const Tensor& xn, const Tensor& wqkv, const Tensor& cos, int64_t d) {
-  return kRopePrescale && !(kFuseRopeFwd && gemm_rope_supported(xn, wqkv, cos, d));
-}
 
 using LlamaLayerOut = std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>;
 // forward : rmsnorm -> QKV GEMM, rotary (kernel, or the GEMM's epilogue) -> attention -> o_proj GEMM(+residual)
@@ -1172,13 +1155,12 @@ LlamaLayerOut op_llama_layer(const Tensor& h_in, const Tensor& cos, const Tensor
   Tensor x = contig(h_in).view({t, hd});
   auto [xn, h_unused, rstd1] = k_rmsnorm_fwd(x, w_ln1, eps, {});
   Tensor qkv;
-  const bool q_prescaled = llama_q_prescaled(xn, wqkv, cos, d);  // (the backward re-derives it from the same operands)
-  if (kFuseRopeFwd && gemm_rope_supported(xn, wqkv, cos, d)) {
-    qkv = k_gemm_rope(xn, wqkv, cos, sin, s, hq + hkv, d);
-  } else {
-    qkv = gemm_plain(xn, wqkv);
-    k_rope_(qkv, cos, sin, s, hq + hkv, d, false, q_prescaled ? hq : 0, q_prescaled ? scale * kLog2e : 1.0);
-  }
+  // the rotary kernel works in place on the fresh q|k|v buffer.  (The same embedding as an epilogue of the q|k|v GEMM measured
+  // level with GEMM + kernel -- 11.62 vs 11.62 / 11.54 ms per layer forward, profiles/r03a_rope_fwd_ab.txt: a way out has
+  // nothing to overlap its arithmetic with -- and went to profiles/r05_removed_variants.patch.)
+  const bool q_prescaled = kRopePrescale;  // (the backward reads the same constant)
+  qkv = gemm_plain(xn, wqkv);
+  k_rope_(qkv, cos, sin, s, hq + hkv, d, false, q_prescaled ? hq : 0, q_prescaled ? scale * kLog2e : 1.0);
   Qkv p3 = split_qkv(qkv, b, s, hq, hkv, d);
   auto [o, lse] = k_attn_fwd(p3.q, p3.k, p3.v, scale, causal, key_valid, train, 0.0, 0, q_start, q_prescaled);
   Tensor h_mid = gemm_plain(o.view({t, hq * d}), wo, false, false, {}, x, TAMD_EPI_RESIDUAL);
@@ -1211,10 +1193,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   // dst_*: the weight gradients' destinations (transformers_amd/ddp.py: DDP's bucket views) -- all seven or none.  With them
   // the dW GEMMs store there and the corresponding outputs come back empty.
   const bool to_dst = dst_q && dst_k && dst_v && dst_o && dst_g && dst_u && dst_d;
-  // the four weight gradients as ONE grouped launch at the end (gemm_dw_group): at 32768 tokens they are 384 + 256 + 1792 + 896
-  // = 3328 tiles = exactly 13 rounds of the 256 CUs -- one by one q|k|v (1.5 rounds) and down_proj (3.5) go through split-K
-  // (fp32 partials + a reduction launch each) to fill their last round.  (Not with DDP destinations: those are seven buffers.)
-  const bool group_dw = kLlamaGroupDw && !to_dst;
+  // (The four weight gradients as ONE grouped launch -- 3328 tiles = exactly 13 rounds, no split-K -- measured 0.35 % slower than
+  // four launches, profiles/r04z_bench_ab.jsonl; removed in round 5, profiles/r05_removed_variants.patch.)
   const int64_t b = h_in.size(0), s = h_in.size(1), hd = h_in.size(2), t = b * s;
   Tensor x = contig(h_in).view({t, hd});
   Tensor dh = contig(d_hout).view({t, hd});
@@ -1228,50 +1208,49 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
     std::tie(d_gu, act) = k_swiglu_bwd(gu, d_act, true);
   }
   d_act = Tensor();
-  Tensor dwd;  // [hd, I]
-  if (!group_dw) {
-    dwd = to_dst ? (gemm_plain(dh, act, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_d), nothing(h_in))
-                 : gemm_plain(dh, act, true, true);
-    act = Tensor();
-  }
+  // (the weight gradients whose tile grids end in a mostly empty dispatch round -- down_proj 3.5 rounds, q|k|v 1.5 -- go out as a
+  // whole-rounds part + a split-K remainder: gemm_dw_balanced)
+  Tensor dwd = to_dst ? (gemm_dw_balanced(dh, act, *dst_d), nothing(h_in)) : gemm_dw_balanced(dh, act);  // [hd, I]
+  act = Tensor();
   Tensor d_xn2 = gemm_plain(d_gu, wgu, false, true);  // [T, hd]
   Tensor dwgu;                                        // [2I, hd]
   if (to_dst) {
     gemm_dw_segments(d_gu, xn2, {*dst_g, *dst_u});
     dwgu = nothing(h_in);
-  } else if (!group_dw) {
+  } else {
     dwgu = gemm_plain(d_gu, xn2, true, true);
   }
-  if (!group_dw) d_gu = Tensor();
+  d_gu = Tensor();
   auto [d_hmid, dw_ln2] = k_rmsnorm_bwd(d_xn2, h_mid, w_ln2, rstd2, dh);
   d_xn2 = Tensor();
   // ---- attention
   Tensor d_o = gemm_plain(d_hmid, wo, false, true);  // [T, Hq*D]
-  Tensor dwo;
-  if (!group_dw)
-    dwo = to_dst ? (gemm_plain(d_hmid, o.view({t, hq * d}), true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_o),
-                    nothing(h_in))
-                 : gemm_plain(d_hmid, o.view({t, hq * d}), true, true);
+  Tensor dwo = to_dst ? (gemm_plain(d_hmid, o.view({t, hq * d}), true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_o),
+                         nothing(h_in))
+                      : gemm_plain(d_hmid, o.view({t, hq * d}), true, true);
   Tensor d_qkv = at::empty_like(qkv);
   Qkv f = split_qkv(qkv, b, s, hq, hkv, d), g = split_qkv(d_qkv, b, s, hq, hkv, d);
   const bool fused_rope = kFuseRopeBwd && attn_bwd_rope_supported(f.q, f.k, cos, d);  // the transposed rotary inside the kernels
   k_attn_bwd(f.q, f.k, f.v, o, lse, d_o.view({b, s, hq, d}), scale, causal, key_valid, g.q, g.k, g.v, 0.0, 0, q_start,
-             fused_rope ? cos : Tensor(), fused_rope ? sin : Tensor(), llama_q_prescaled(xn, wqkv, cos, d));
+             fused_rope ? cos : Tensor(), fused_rope ? sin : Tensor(), kRopePrescale);
   d_o = Tensor();
   if (!fused_rope) k_rope_(d_qkv, cos, sin, s, hq + hkv, d, true);
   Tensor d_xn = gemm_plain(d_qkv, wqkv, false, true);
   Tensor dwqkv;  // [(Hq+2Hkv)D, hd]
   if (to_dst) {
-    gemm_dw_segments(d_qkv, xn, {*dst_q, *dst_k, *dst_v});
+    const int64_t nq = hq * d, nkv = 2 * hkv * d;
+    const DwCut cut = kDwBalance ? dw_balanced_cut(nq + nkv, hd, t) : DwCut{-1, 0};
+    if (cut.axis == 0 && cut.at == nq) {  // the cut falls on the q | k|v boundary: q as one product, k|v as a segmented one
+      k_gemm(d_qkv.narrow(1, 0, nq), xn, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_q, 0);
+      gemm_dw_segments(d_qkv.narrow(1, nq, nkv), xn, {*dst_k, *dst_v});
+    } else {
+      gemm_dw_segments(d_qkv, xn, {*dst_q, *dst_k, *dst_v});
+    }
     dwqkv = nothing(h_in);
-  } else if (!group_dw) {
-    dwqkv = gemm_plain(d_qkv, xn, true, true);
+  } else {
+    dwqkv = gemm_dw_balanced(d_qkv, xn);
   }
   auto [d_hin, dw_ln1] = k_rmsnorm_bwd(d_xn, x, w_ln1, rstd1, d_hmid);
-  if (group_dw) {
-    std::vector<Tensor> dws = gemm_dw_group({dh, d_gu, d_hmid, d_qkv}, {act, xn2, o.view({t, hq * d}), xn});
-    dwd = dws[0], dwgu = dws[1], dwo = dws[2], dwqkv = dws[3];
-  }
   return {d_hin.view({b, s, hd}), dw_ln1, dwqkv, dwo, dw_ln2, dwgu, dwd};
 }
 
@@ -1415,11 +1394,9 @@ TORCH_LIBRARY(tamd, m) {
   m.def("gemm_out(Tensor(a!) out, Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, "
         "Tensor? residual=None, int epilogue=0, int act=0, int sched=0) -> ()");
   m.def("gemm_swiglu(Tensor x2, Tensor wgu, bool need_gu=True) -> (Tensor, Tensor)");
-  m.def("gemm_bias_act_pre(Tensor x2, Tensor w, Tensor bias, int act) -> (Tensor, Tensor)");
   m.def("gemm_dw_segments(Tensor dy, Tensor x, Tensor(a!)[] segs) -> ()");
   m.def("gemm_dw_group(Tensor[] dy, Tensor[] x) -> Tensor[]");
   m.def("gemm_colscale(Tensor x2, Tensor w, Tensor? bias, int scale_cols, float col_scale) -> Tensor");
-  m.def("gemm_rope(Tensor x2, Tensor wqkv, Tensor cos, Tensor sin, int seq, int rope_heads, int head_dim) -> Tensor");
   m.def("attn_fwd(Tensor q, Tensor k, Tensor v, float scale, bool causal, Tensor? key_valid=None, bool need_lse=True, "
         "float dropout_p=0.0, int seed=0, Tensor? q_start=None, Tensor? seed_dev=None) -> (Tensor, Tensor)");
   m.def("attn_bwd(Tensor q, Tensor k, Tensor v, Tensor o, Tensor lse, Tensor dout, float scale, bool causal, "
@@ -1492,7 +1469,6 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("swiglu_bwd", &op_swiglu_bwd);                              \
   m.impl("bias_act_fwd", &k_bias_act_fwd);                           \
   m.impl("bias_act_bwd", &op_bias_act_bwd);                          \
-  m.impl("gemm_bias_act_pre", &op_gemm_bias_act_pre);                \
   m.impl("gemm_dw_segments", &op_gemm_dw_segments);                  \
   m.impl("gemm_dw_group", &op_gemm_dw_group);                        \
   m.impl("gemm_colscale", &op_gemm_colscale);                        \
@@ -1505,7 +1481,6 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("gemm", &op_gemm);                                          \
   m.impl("gemm_out", &op_gemm_out);                                  \
   m.impl("gemm_swiglu", &op_gemm_swiglu);                            \
-  m.impl("gemm_rope", &op_gemm_rope);                                \
   m.impl("attn_fwd", &op_attn_fwd);                                  \
   m.impl("attn_bwd", &op_attn_bwd);                                  \
   m.impl("attn_bwd_out", &op_attn_bwd_out);                          \
@@ -1585,6 +1560,14 @@ int tamd_torch_bind(const char* path, int emulated) {
 const char* tamd_torch_bound_path(void) {
   const Api* a = g_api.load(std::memory_order_acquire);
   return a ? a->path.c_str() : "";
+}
+
+// where gemm_dw_balanced cuts a weight-gradient product dW[m, n] over k tokens (host logic, for the tests): returns the axis
+// (0 rows, 1 columns, -1 one launch) and the cut position in *at
+int tamd_torch_dw_cut(long long m, long long n, long long k, long long* at) {
+  const DwCut c = dw_balanced_cut(m, n, k);
+  if (at) *at = c.at;
+  return c.axis;
 }
 
 // GEMM event log (bench.py `roofline`): on / off; the summary synchronises the recorded events and clears the log.

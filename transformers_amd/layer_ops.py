@@ -5,7 +5,7 @@
 
 The forward and backward bodies -- sequences of C-ABI launches on the caller's stream -- are compiled
 (csrc/torch_binding.cpp: op_llama_layer, op_llama_layer_bwd, op_bert_layer, op_bert_layer_bwd; the environment switches
-TAMD_FUSE_ROPE_FWD / TAMD_FUSE_ROPE_BWD / TAMD_SAVE_SWIGLU_ACT are read there).  This module registers their fake (Meta)
+TAMD_FUSE_ROPE_BWD / TAMD_SAVE_SWIGLU_ACT are read there).  This module registers their fake (Meta)
 implementations and autograd formulas and holds the wrappers the model classes in `transformers_amd/models/` call.
 """
 from __future__ import annotations

@@ -13,7 +13,7 @@ from transformers.models.bert import modeling_bert as ref
 
 from .. import layer_ops, ops
 from ..fused_params import FusedWeights, PaddedRows
-from .common import _gpu, _has_hooks, note_fallback
+from .common import _gpu, _has_hooks, _placement_ok, note_fallback
 
 
 def _no_dropout(mod) -> bool:
@@ -121,7 +121,8 @@ class TamdBertLayer(ref.BertLayer):
                 and sa.query.weight.dtype == hidden_states.dtype
                 and ops.ACT_CODES.get(_act_name(inter, "_tamd_act", inter.intermediate_act_fn), ops.ACT_NONE) != ops.ACT_NONE
                 and so.dropout.p == out.dropout.p
-                and not _has_hooks(att, sa, so, inter, out, so.LayerNorm, out.LayerNorm))
+                and not _has_hooks(att, sa, so, inter, out, so.LayerNorm, out.LayerNorm)
+                and _placement_ok(self, hidden_states.device, sa.query.weight, out.dense.weight))
 
     def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 past_key_values=None, **kwargs):

@@ -96,3 +96,26 @@ def _has_hooks(*mods: nn.Module) -> bool:
         if any(not _capture_hook_is_idle(fn) for fn in m._forward_hooks.values()):
             return True
     return False
+
+
+def _placement_ok(layer: nn.Module, device, *probe: torch.Tensor) -> bool:
+    """A fused layer path reads its children's weights directly instead of calling the children, so it bypasses the forward
+    wrappers accelerate installs for `device_map` / CPU / disk offload (`_hf_hook`: accelerate replaces `forward`, it does not
+    register a hook, so `_has_hooks` cannot see it) -- with offload a leaf's weight sits on `meta` until its wrapper runs.
+    True when no CHILD of `layer` carries such a wrapper and every parameter is on `device` (a wrapper on `layer` itself
+    has already run by the time its forward is entered).  Cached on the identity of the `probe` weights: materialising or
+    moving a weight replaces the parameter object, which invalidates the entry."""
+    key = (device,) + tuple(id(t) for t in probe)
+    cached = layer.__dict__.get("_tamd_placement")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    ok = True
+    for m in layer.modules():
+        if m is not layer and "_hf_hook" in m.__dict__:
+            ok = False
+            break
+    if ok:
+        ok = all(p.device == device for p in layer.parameters())
+    layer.__dict__["_tamd_placement"] = (key, ok)
+    return ok
+

@@ -21,7 +21,7 @@ from .. import layer_ops, ops
 from ..fused_params import FusedWeights
 
 
-from .common import _has_hooks, note_fallback  # noqa: E402
+from .common import _has_hooks, _placement_ok, note_fallback  # noqa: E402
 
 
 def _on_gpu(t: torch.Tensor) -> bool:
@@ -138,14 +138,18 @@ class TamdLlamaDecoderLayer(ref.LlamaDecoderLayer):
                 and not (attn.training and attn.attention_dropout > 0)  # the per-module path carries dropout
                 and mlp.config.hidden_act in ("silu", "swish") and mlp.gate_proj.bias is None
                 and attn.o_proj.bias is None
-                and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm))
+                and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm)
+                and _placement_ok(self, hidden_states.device, attn.q_proj.weight, mlp.down_proj.weight))
 
     def _cached_ok(self, hidden_states) -> bool:
         attn, mlp = self.self_attn, self.mlp
         return (isinstance(attn, TamdLlamaAttention) and isinstance(mlp, TamdLlamaMLP) and attn._cached_ok(hidden_states)
                 and mlp.config.hidden_act in ("silu", "swish") and mlp.gate_proj.bias is None and mlp.down_proj.bias is None
                 and mlp.gate_proj.weight.dtype == hidden_states.dtype
-                and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm))
+                and not _has_hooks(attn, mlp, self.input_layernorm, self.post_attention_layernorm)
+                # (the cached path reads the children's weights directly: an accelerate `device_map` / offload wrapper on a
+                # child would not run -- ADVICE r4; such layers take the reference module, whose children are called)
+                and _placement_ok(self, hidden_states.device, attn.q_proj.weight, mlp.down_proj.weight))
 
     def cached_forward(self, hidden_states, attention_mask, past_key_values, position_embeddings, **kwargs):
         """The layer with a KV cache (modeling_llama.py:303-324), prefill or decode: both residual adds ride in the epilogues

@@ -244,7 +244,7 @@ def gemm_workspace_bytes(m: int, n: int, k: int, epilogue: int, flags: int = 0) 
     return -(-nst // sps) * m * n * 4
 
 
-GEMM_SCHED = {None: 0, "pp": 1, "sm": 2, "fl": 3, "tw": 4}  # TAMD_GEMM_SCHED_* >> 8 (include/tamd.h)
+GEMM_SCHED = {None: 0, "pp": 1, "sm": 2, "fl": 3}  # TAMD_GEMM_SCHED_* >> 8 (include/tamd.h)
 
 
 def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue=EPI_NONE, act=ACT_NONE, out=None,
@@ -260,24 +260,6 @@ def raw_gemm(a, b, *, a_km=False, b_kn=False, bias=None, residual=None, epilogue
 def attn_bwd_rope_supported(q, k, cos, head_dim) -> bool:
     """The attention backward can apply the transposed rotary embedding to dq / dk on their way out."""
     return head_dim == 128 and q.shape[1] == k.shape[1] and cos.shape[-1] == 128 and cos.dim() in (2, 3)
-
-
-def gemm_rope_supported(x2, wqkv, cos, head_dim) -> bool:
-    """Shapes the q|k|v GEMM with the rotary epilogue takes (csrc/gemm.hip tamd_gemm_rope; mirrored in torch_binding.cpp):
-    heads of 128; a cos / sin table shared by the batch ([seq, 128]) needs seq >= 128."""
-    n, k = wqkv.shape
-    return (head_dim == 128 and (cos.dim() == 3 and cos.shape[0] > 1 or cos.shape[-2] >= 128)
-            and x2.dtype in (torch.bfloat16, torch.float16) and wqkv.dtype == x2.dtype and k % 64 == 0
-            and n % 128 == 0 and x2.stride(1) == 1 and wqkv.stride(1) == 1 and x2.stride(0) % 8 == 0
-            and wqkv.stride(0) % 8 == 0 and cos.shape[-1] == 128
-            # a tile grid that cannot fill the GPU (a short prompt) is better off with split-K and the rotary kernel
-            and gemm_workspace_bytes(x2.shape[0], n, k, EPI_NONE, 3) == 0)  # ("small" as for a k-major product: torch_binding.cpp)
-
-
-def raw_gemm_rope(x2, wqkv, cos, sin, seq, rope_heads, head_dim):
-    """qkv [T, N] = x2 [T, K] . wqkv [N, K]^T with apply_rotary_pos_emb on the first rope_heads heads (query + key) in
-    the GEMM epilogue; bit-identical to raw_gemm followed by raw_rope_."""
-    return T.gemm_rope(x2, wqkv, cos, sin, int(seq), int(rope_heads), int(head_dim))
 
 
 def gemm_swiglu_supported(x2, wgu) -> bool:
@@ -376,8 +358,6 @@ register("swiglu_bwd", lambda gu, dact, want_act=False: (torch.empty_like(gu),
 register("bias_act_fwd", lambda x, bias, act: torch.empty_like(x))
 register("bias_act_bwd", lambda x, bias, dy, act, need_colsum=False: (
     torch.empty_like(x), x.new_empty(x.shape[-1]) if need_colsum else _nothing(x)))
-register("gemm_bias_act_pre", lambda x2, w, bias, act: (x2.new_empty(x2.shape[0], w.shape[0]),
-                                                        x2.new_empty(x2.shape[0], w.shape[0])))
 register("gemm_colscale", lambda x2, w, bias, scale_cols, col_scale: x2.new_empty(x2.shape[0], w.shape[0]))
 register("gemm_dw_segments", lambda dy, x, segs: None)
 register("gemm_dw_group", lambda dy, x: [a.new_empty(a.shape[1], b.shape[1]) for a, b in zip(dy, x)])
@@ -400,7 +380,6 @@ register("gemm", lambda a, b, a_km=False, b_kn=False, bias=None, residual=None, 
 register("gemm_out", lambda out, a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0, sched=0: None)
 register("gemm_swiglu", lambda x2, wgu, need_gu=True: (x2.new_empty(x2.shape[0], wgu.shape[0]) if need_gu else _nothing(x2),
                                                        x2.new_empty(x2.shape[0], wgu.shape[0] // 2)))
-register("gemm_rope", lambda x2, wqkv, cos, sin, seq, rope_heads, head_dim: x2.new_empty(x2.shape[0], wqkv.shape[0]))
 register("attn_fwd", lambda q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None, seed_dev=None: (
     q.new_empty(q.shape), _f32(q, q.shape[0], q.shape[2], q.shape[1]) if need_lse else _nothing(q)))
 register("attn_bwd", lambda q, k, v, o, lse, dout, scale, causal, key_valid=None, dropout_p=0.0, seed=0, q_start=None,
