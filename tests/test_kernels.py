@@ -1195,7 +1195,7 @@ def test_gemm_group_weight_gradients(env):
 
 def test_gemm_segmented_weight_gradient(env):
     """tamd_gemm_seg (ABI 8): dW = dY^T . X of a fused q|k|v / gate|up projection with each member's rows stored into its own
-    buffer -- the bits of the one-buffer product, with and without split-K."""
+    buffer -- the bits of the one-buffer product of the same entry point, with and without split-K."""
     torch.manual_seed(93)
     dev = env.device
     cases = ([(6144, 4096, 4096, (4096, 1024, 1024)), (1536, 768, 16384, (768, 768))] if env.big else
@@ -1203,10 +1203,15 @@ def test_gemm_segmented_weight_gradient(env):
     for (m, n, k, rows) in cases:
         dy = torch.randn(k, m).bfloat16().to(dev)
         x = torch.randn(k, n).bfloat16().to(dev)
-        whole = ops.raw_gemm(dy, x, a_km=True, b_kn=True)          # default dispatch (split-K where the policy picks it)
+        # the one-buffer product through the SAME entry point and split-K policy (one segment).  (The default dispatch of
+        # `raw_gemm` is no longer that: since round 5 it cuts a 1.5-round product into a whole-rounds part and a split-K
+        # remainder -- gemm_dw_balanced -- whose unsplit part has another fp32 summation order: compared by value below.)
+        whole = torch.full((m, n), 7.0, dtype=torch.bfloat16, device=dev)
+        torch.ops.tamd.gemm_dw_segments(dy, x, [whole])
         segs = [torch.full((r, n), 7.0, dtype=torch.bfloat16, device=dev) for r in rows]
         torch.ops.tamd.gemm_dw_segments(dy, x, segs)
         assert torch.equal(torch.cat(segs, 0), whole), (m, n, k, rows)
+        assert rel_err(whole, ops.raw_gemm(dy, x, a_km=True, b_kn=True)) < 2e-3, (m, n, k, rows)
 
 
 @pytest.mark.gpu

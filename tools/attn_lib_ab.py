@@ -82,7 +82,7 @@ def reference(q, k, v, do, scale, causal, nb=1, nh=2):
 def main():
     base = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "tools" / "ab" / "libtamd_base.so"
     new = Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "transformers_amd" / "libtamd.so"
-    libs = {"base": TamdLib(base, accept_abi=(6, 7, 8)), "new": TamdLib(new)}  # (the struct grew at its end: ABI 6 reads a prefix)
+    libs = {"base": TamdLib(base, accept_abi=(6, 7, 8, 9)), "new": TamdLib(new)}  # (the struct grew at its end: ABI 6 reads a prefix)
     if os.environ.get("AB_LIBS"):  # e.g. AB_LIBS=new under rocprofv3: kernel names of one build only
         libs = {k: v for k, v in libs.items() if k in os.environ["AB_LIBS"].split(",")}
     dev = torch.device("cuda:0")
