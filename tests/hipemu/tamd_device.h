@@ -346,6 +346,42 @@ template <int IMM>
 inline void glds16_buf(const void* base, unsigned voff, char* smem, unsigned lds_base_off) {
   glds16<0>(reinterpret_cast<const char*>(base) + voff + IMM, smem, lds_base_off + (unsigned)IMM);
 }
+// range-checked LDS-DMA: a lane whose soff + voff .. + size is not inside [0, bytes) fetches nothing, zeros land in its slot
+// (the scalar offset IS part of the range check on gfx950: tests/test_gpu_probe.py probe 7)
+namespace hipemu_detail {
+inline void glds_rng(const void* base, unsigned bytes, unsigned voff, unsigned soff, char* smem, unsigned lds_base_off, int size) {
+  const int lane = hipemu::cur_lane();
+  unsigned b = lds_base_off;
+  memcpy(hipemu::cur_wave().in[lane], &b, 4);
+  hipemu::wave_collective([&](hipemu::WaveState& w, int n) {
+    unsigned b0;
+    memcpy(&b0, w.in[0], 4);
+    for (int l = 1; l < n; ++l) {
+      unsigned bl;
+      memcpy(&bl, w.in[l], 4);
+      if (bl != b0) {
+        fprintf(stderr, "hipemu: glds_buf_rng LDS base not wave-uniform (lane %d: %u vs %u)\n", l, bl, b0);
+        hipemu::g_fail.store(1);
+      }
+    }
+  });
+  emu_check_bounds(smem + lds_base_off + lane * size, (size_t)size, "glds_buf_rng");
+  EmuPendingGlds p;
+  p.dst = smem + lds_base_off + lane * size;
+  p.size = size;
+  memset(p.data, 0, sizeof(p.data));
+  if ((unsigned long long)soff + (unsigned long long)voff + (unsigned long long)size <= (unsigned long long)bytes)
+    memcpy(p.data, reinterpret_cast<const char*>(base) + soff + voff, (size_t)size);
+  memset(p.dst, 0xff, (size_t)size);
+  emu_pending().push_back(p);
+}
+}  // namespace hipemu_detail
+inline void glds16_buf_rng(const void* base, unsigned bytes, unsigned voff, char* smem, unsigned lds_base_off) {
+  hipemu_detail::glds_rng(base, bytes, voff, 0u, smem, lds_base_off, 16);
+}
+inline void glds4_buf_rng(const void* base, unsigned bytes, unsigned voff, unsigned soff, char* smem, unsigned lds_base_off) {
+  hipemu_detail::glds_rng(base, bytes, voff, soff, smem, lds_base_off, 4);
+}
 inline u32x4 buf_load16(const void* base, unsigned voff) {
   u32x4 v;
   memcpy(&v, reinterpret_cast<const char*>(base) + voff, 16);

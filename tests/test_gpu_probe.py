@@ -38,11 +38,13 @@ def _inputs(which, rng):
         in2 = (rng.permutation(512)[:64].astype(np.uint32)) * 16
     elif which == 6:
         in2 = (rng.permutation(500)[:64].astype(np.uint32)) * 16  # + immediates up to 3072 + 2048: inside 16 KiB
+    elif which == 7:
+        in2 = (rng.permutation(512)[:64].astype(np.uint32)) * 16  # up to 8 KiB: half the lanes past the 4 KiB / 2 KiB buffers
     return inp, in2
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_hardware_matches_cpu_model(which):
     from emu_backend import get_emu
 

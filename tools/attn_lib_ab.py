@@ -1,5 +1,5 @@
 """A/B of the attention entry points of TWO builds of the C-ABI library in one process, interleaved on one GPU:
-    python tools/attn_lib_ab.py [base.so] [new.so]        (defaults: tools/ab/libtamd_base.so, transformers_amd/libtamd.so)
+    python tools/attn_lib_ab.py [base.so] [new.so] [more.so ...]   (defaults: tools/ab/libtamd_base.so, transformers_amd/libtamd.so)
 Both libraries are driven through ctypes (include/tamd.h: tamd_attn_fwd / tamd_attn_bwd) on the same tensors; per shape it
 prints forward / backward time and TFLOP/s of each and the error of each against an fp32 eager restatement on a slice
 (forward 4*B*H*Sq*Sk*D flops, x0.5 causal; backward 2.5x).  The base library is a build of an earlier commit kept as a
@@ -83,6 +83,8 @@ def main():
     base = Path(sys.argv[1]) if len(sys.argv) > 1 else ROOT / "tools" / "ab" / "libtamd_base.so"
     new = Path(sys.argv[2]) if len(sys.argv) > 2 else ROOT / "transformers_amd" / "libtamd.so"
     libs = {"base": TamdLib(base, accept_abi=(6, 7, 8, 9)), "new": TamdLib(new)}  # (the struct grew at its end: ABI 6 reads a prefix)
+    for extra in sys.argv[3:]:  # further builds of the current ABI (tools/build_variant.py), tagged by their file name
+        libs[Path(extra).stem.replace("libtamd_", "")] = TamdLib(Path(extra))
     if os.environ.get("AB_LIBS"):  # e.g. AB_LIBS=new under rocprofv3: kernel names of one build only
         libs = {k: v for k, v in libs.items() if k in os.environ["AB_LIBS"].split(",")}
     dev = torch.device("cuda:0")
@@ -100,7 +102,7 @@ def main():
         do = torch.randn(b, s, hq, d, device=dev).bfloat16()
         scale = 1 / math.sqrt(d)
         fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
-        ref = reference(q, k, v, do, scale, causal) if s <= 4096 and DROPOUT == 0 else None
+        ref = reference(q, k, v, do, scale, causal) if s <= 4096 and DROPOUT == 0 and not os.environ.get("AB_NOREF") else None
         row = {"shape": name, "dropout_p": DROPOUT}
         runs = {}
         for tag, lib in libs.items():
@@ -126,6 +128,10 @@ def main():
                                      "dk": round(rel(dk[:nb, :, :nk], gk), 5),
                                      "dv": round(rel(dv[:nb, :, :nk], gv), 5)}
             runs[tag] = (fwd, bwd, (o, lse, dq, dk, dv, delta, fp, bp))
+            if tag != "base" and "base" in runs:  # the same bits as the base build?
+                bo, _, bdq, bdk, bdv = runs["base"][2][:5]
+                row[f"{tag}_same_bits"] = {"o": bool(torch.equal(o, bo)), "dq": bool(torch.equal(dq, bdq)),
+                                           "dk": bool(torch.equal(dk, bdk)), "dv": bool(torch.equal(dv, bdv))}
         tf = {t: [] for t in runs}
         tb = {t: [] for t in runs}
         for _ in range(3):  # interleaved rounds

@@ -9,6 +9,8 @@ exec < /dev/null
 #   kernels [which...]       tools/gpu_bench_kernels.py (gemm attn hbm layer)
 #   gemm_pmc                 tools/gemm_vs_vendor_pmc.py under one rocprofv3 --pmc pass per counter set (ours vs hipBLASLt)
 #   gemm_ab / attn_ab        this tree's library against tools/ab/libtamd_base.so (tools/build_base_lib.sh), interleaved
+#   attn_variants            ... and every tools/ab/libtamd_[v-z]*.so (tools/build_variant.py), attention entry points
+#   attn_pmc                 rocprofv3 --pmc passes over the attention kernels of this tree (tools/attn_pmc.py)
 #   attn_prof                per-kernel times of the attention kernels at the Llama-3-8B shape (rocprofv3)
 #   bert / bert_graph / llava   the other BASELINE configurations' bench lines
 #   ddp                      bench.py --force-ddp over RCCL at world size 1: zero-copy on / off / collective forced / --verify-ddp
@@ -81,6 +83,32 @@ step_gemm_ab() {
 step_attn_ab() {
   timeout 300 python tools/attn_lib_ab.py > $out/${tag}_attn_lib_ab.jsonl 2> $out/${tag}_attn_lib_ab.err
   cut -c1-300 $out/${tag}_attn_lib_ab.jsonl; tail -2 $out/${tag}_attn_lib_ab.err
+}
+step_attn_variants() {  # tools/ab/libtamd_base.so, this tree's library and every tools/ab/libtamd_[v-z]*.so (tools/build_variant.py)
+  AB_SHAPES=${AB_SHAPES:-llama3-8b,bidir-128} timeout 500 python tools/attn_lib_ab.py tools/ab/libtamd_base.so transformers_amd/libtamd.so $(ls tools/ab/libtamd_[v-z]*.so 2>/dev/null) > $out/${tag}_attn_variants_ab.jsonl 2> $out/${tag}_attn_variants_ab.err
+  python - <<PY
+import json
+for l in open("$out/${tag}_attn_variants_ab.jsonl"):
+    r = json.loads(l)
+    print(r["shape"])
+    for k, v in r.items():
+        if isinstance(v, dict) and "fwd_ms" in v:
+            print(f"  {k:6s} fwd {v['fwd_ms']:.4f} ms {v['fwd_TF']:5d} TF | bwd {v['bwd_ms']:.4f} ms {v['bwd_TF']:5d} TF | err {r.get(k + '_err')} same {r.get(k + '_same_bits')}")
+PY
+  tail -3 $out/${tag}_attn_variants_ab.err
+}
+step_attn_pmc() {  # counters of the three attention kernels of THIS tree's library (one rocprofv3 --pmc pass per counter set)
+  local i=0
+  mkdir -p $out/$tag/attn_pmc
+  cd /tmp
+  python $R/tools/attn_pmc.py passes | while read -r set; do
+    i=$((i + 1))
+    AB_LIBS=new AB_SHAPES=llama3-8b AB_NOREF=1 timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$tag/attn_pmc/pass$i -o p -- python $R/tools/attn_lib_ab.py > $out/$tag/attn_pmc/pass$i.log 2>&1
+    echo "pass $i exit $?: $set"
+  done
+  cd $R
+  find $out/$tag/attn_pmc -name "*.csv" -size +4M -delete
+  python tools/attn_pmc.py table $out/$tag/attn_pmc $out/${tag}_attn_pmc.md | tail -40
 }
 step_attn_prof() {
   ( cd /tmp && AB_LIBS=new AB_SHAPES=llama3-8b timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag/attn -o ab -- python $R/tools/attn_lib_ab.py > /dev/null 2>&1 )

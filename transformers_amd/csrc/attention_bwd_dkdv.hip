@@ -40,9 +40,6 @@
 
 namespace tamd {
 
-__device__ __attribute__((aligned(16))) static const unsigned int g_ninf32[4] = {0xff800000u, 0xff800000u, 0xff800000u,
-                                                                                0xff800000u};
-
 // s_waitcnt lgkmcnt(N) that the four fragments depend on: MFMAs consuming them cannot be scheduled above it
 template <int N>
 __device__ __forceinline__ void wait_frags(u32x4& f0, u32x4& f1, u32x4& f2, u32x4& f3) {
@@ -188,51 +185,72 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     pq[i] = (unsigned)r * (unsigned)a.qss * 2u + sl;
     po[i] = (unsigned)r * (unsigned)a.oss * 2u + sl;
   }
-  // tile `it` -> LDS buffer `buf`.  Order: q-tiles from the LAST one down to the first visible one, the query
-  // heads of the group innermost.  Every workgroup of a (batch, kv-head) group then walks the same (tile, head)
-  // sequence from the same starting point, so the 32 CUs of an XCD request a Q/dO tile at about the same time and
-  // 31 of them hit in L2; walking up from each workgroup's own first visible tile (the previous order) streamed
-  // the tiles from MALL/HBM 16 times over: 8.8 GB per launch, a 1.05 ms floor at the Llama-3-8B shape.
-  // (a padding tile it >= niter -- the loop runs an even number of tiles -- addresses rows past seq_q only: zeros)
+  // Order of the tiles: q-tiles from the LAST one down to the first visible one, the query heads of the group innermost.
+  // Every workgroup of a (batch, kv-head) group then walks the same (tile, head) sequence from the same starting point, so
+  // the 32 CUs of an XCD request a Q/dO tile at about the same time and 31 of them hit in L2; walking up from each
+  // workgroup's own first visible tile (the previous order) streamed the tiles from MALL/HBM 16 times over: 8.8 GB per
+  // launch, a 1.05 ms floor at the Llama-3-8B shape.
+  // Round 5 -- the tile feed, rebuilt.  Until then the 9 LDS-DMA pieces of a tile went out in one clump behind the hand-off
+  // barrier, from per-lane 64-bit pointers: ~150 instructions per tile (64-bit products of (batch, head, tile) per tile, the
+  // lane offsets parked in AGPRs and copied back, a zero page select per piece) with no MFMA running beside them -- a tenth
+  // of the kernel (profiles/r03d_dkdv_ablation.txt).  Now:
+  //   * a tile's source is three wave-uniform 64-bit bases (Q, dO, the statistics rows) that STEP from tile to tile (one
+  //     select + one 64-bit add each), pieces are buffer-addressed (base in SGPRs + a loop-invariant 32-bit lane offset);
+  //   * the rows a tile does not have (the ragged last q-tile, the padding tile of an odd count) are cut off by the buffer's
+  //     size -- the hardware range check delivers zeros (tamd_device.h glds16_buf_rng), which is what such rows must
+  //     contribute: Q = dO = 0 and statistics 0 give S'' = 0, p = 1, dP - delta = 0, dS = 0 -- no branch, no zero page;
+  //   * tile it+1 is requested DURING tile it, one piece behind each of its first nine MFMA groups (an LDS-DMA issue holds
+  //     the wave 60-185 cycles: behind four queued MFMAs the matrix pipe works through that time), into the buffer the
+  //     hand-off of tile it-1 released; it has landed at the hand-off of tile it (vmcnt(0) + barrier), like before.
+  // (elements) the next head of the group: + step_*_h; past the group's last head also + wrap_*: back to its first head, one tile down
+  const int64_t step_q_h = a.qsh, wrap_q = -(int64_t)kQT * a.qss - (int64_t)group * a.qsh;
+  const int64_t step_o_h = a.osh, wrap_o = -(int64_t)kQT * a.oss - (int64_t)group * a.osh;
+  const int64_t step_s_h = a.seq_q, wrap_s = -(int64_t)kQT - (int64_t)group * a.seq_q;
   int iss_h = 0, iss_qt = nqt64 - 1;  // (head, q-tile) of the next tile to issue: no division in the loop
-  auto issue = [&](int it, int buf) {
-    const bool pad = it >= niter;
-    const int hg = pad ? 0 : iss_h, qt = pad ? nqt64 : iss_qt;
-    if (++iss_h == group) {
+  const T* iss_q = reinterpret_cast<const T*>(a.q) + (int64_t)b * a.qsb + (int64_t)(hkv * group) * a.qsh + (int64_t)iss_qt * kQT * a.qss;
+  const T* iss_o = reinterpret_cast<const T*>(g.dout) + (int64_t)b * a.osb + (int64_t)(hkv * group) * a.osh + (int64_t)iss_qt * kQT * a.oss;
+  const float* iss_s = (const float*)g.delta + ((int64_t)b * a.heads_q + hkv * group) * a.seq_q + (int64_t)iss_qt * kQT;  // -delta rows
+  const int64_t lse_plane = (int64_t)a.batch * a.heads_q * a.seq_q;  // -lse*log2(e): the second plane (elements)
+  const unsigned pstat = (unsigned)lane * 4u;
+  // the tile being issued: its bases and how many of its 64 rows exist (0: a padding tile)
+  const T* src_q = iss_q;
+  const T* src_o = iss_o;
+  const float* src_s = iss_s;
+  int src_rows = 0;
+  auto issue_begin = [&](int it) {  // (wave-uniform scalar work: once per tile)
+    src_q = iss_q;
+    src_o = iss_o;
+    src_s = iss_s;
+    const int left = a.seq_q - iss_qt * kQT;
+    src_rows = it < niter ? (left < kQT ? left : kQT) : 0;
+    const bool wrap = ++iss_h == group;
+    if (wrap) {
       iss_h = 0;
       --iss_qt;
     }
-    const int h = hkv * group + hg;
-    const char* bq = (const char*)(reinterpret_cast<const T*>(a.q) + (int64_t)b * a.qsb + (int64_t)h * a.qsh +
-                                   (int64_t)qt * kQT * a.qss);
-    const char* bo = (const char*)(reinterpret_cast<const T*>(g.dout) + (int64_t)b * a.osb + (int64_t)h * a.osh +
-                                   (int64_t)qt * kQT * a.oss);
+    // (mask arithmetic, not a select between two kernel-argument values: hipcc turns that into a select between their
+    // ADDRESSES -- a scratch copy of the steps and a flat load per tile)
+    const int64_t wm = -(int64_t)wrap;
+    iss_q += step_q_h + (wm & wrap_q);
+    iss_o += step_o_h + (wm & wrap_o);
+    iss_s += step_s_h + (wm & wrap_s);
+  };
+  constexpr int NPIECE = 2 * NI + 1;  // Q pieces, dO pieces, one piece of statistics
+  auto issue_piece = [&](int buf, int n) {
     const unsigned q_off = (unsigned)buf * BUFB, do_off = q_off + TILEB, st_off = do_off + TILEB;
-    const int rows_left = a.seq_q - qt * kQT;  // wave-uniform
-    if (rows_left >= kQT) {
+    if (n < NI)
+      glds16_buf_rng(src_q, (unsigned)src_rows * (unsigned)a.qss * 2u, pq[n], smem, q_off + (unsigned)(wave * NI + n) * 1024u);
+    else if (n < 2 * NI)
+      glds16_buf_rng(src_o, (unsigned)src_rows * (unsigned)a.oss * 2u, po[n - NI], smem, do_off + (unsigned)(wave * NI + n - NI) * 1024u);
+    else  // waves 0 / 2: -lse*log2(e) of the tile's 64 rows, waves 1 / 3: -delta (twice the same bytes: no branch); the plane
+          // goes into the base, not into a scalar offset: that would count towards the range
+      glds4_buf_rng(src_s + ((wave & 1) ? 0 : lse_plane), (unsigned)src_rows * 4u, pstat, 0u, smem,
+                    st_off + (unsigned)(wave & 1) * (kQT * 4));
+  };
+  auto issue = [&](int it, int buf) {  // the whole tile at once (prologue)
+    issue_begin(it);
 #pragma unroll
-      for (int i = 0; i < NI; ++i) glds16(bq + pq[i], smem, q_off + (unsigned)(wave * NI + i) * 1024u);
-#pragma unroll
-      for (int i = 0; i < NI; ++i) glds16(bo + po[i], smem, do_off + (unsigned)(wave * NI + i) * 1024u);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const bool ok = (wave * NI + i) * RPI + lane_row < rows_left;
-        glds16(ok ? (const void*)(bq + pq[i]) : (const void*)g_zero16a, smem, q_off + (unsigned)(wave * NI + i) * 1024u);
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const bool ok = (wave * NI + i) * RPI + lane_row < rows_left;
-        glds16(ok ? (const void*)(bo + po[i]) : (const void*)g_zero16a, smem, do_off + (unsigned)(wave * NI + i) * 1024u);
-      }
-    }
-    if (wave < 2) {  // wave 0: -lse*log2(e) of the tile's 64 rows, wave 1: -delta; rows past seq_q read -inf / 0 (p = 0)
-      const int qr = qt * kQT + lane;
-      const float* src = (const float*)g.delta + (wave ? 0 : (int64_t)a.batch * a.heads_q * a.seq_q) +
-                         ((int64_t)b * a.heads_q + h) * a.seq_q + qr;  // wave 0: -lse*log2(e) (second half)
-      const void* p = (qr < a.seq_q) ? (const void*)src : (wave ? (const void*)g_zero16a : (const void*)g_ninf32);
-      glds4(p, smem, st_off + (unsigned)wave * (kQT * 4));
-    }
+    for (int n = 0; n < NPIECE; ++n) issue_piece(buf, n);
   };
 
   // absolute LDS addresses of this lane's fragment reads (untracked reads take base + 16-bit immediate)
@@ -300,7 +318,6 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   constexpr int NSTAT = (DBG & 1) ? 0 : (FOLD_DELTA ? 8 : 4);  // LDS reads of one load_stats
 
   if (niter > 0) issue(0, 0);
-  if (niter > 0) issue(1, 1);  // (a padding tile when niter == 1)
   wait_vmcnt0();
   block_sync();
   // Straight-line loop body (no per-wave skip of fully masked tiles: the causal mask zeroes them, and the two
@@ -344,7 +361,30 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       wait_lgkmcnt0();
       if (!(DBG & 16)) raw_barrier();
       sched_fence();
-      if (it + 2 < niter2 && !(DBG & 8)) issue(it + 2, cur);
+    };
+    // tile it+1 goes out behind the first NPIECE MFMA groups of this tile (the last tile of the loop requests nothing)
+    // (no branch: behind the last tile of the loop issue_begin finds no rows, the pieces fetch nothing and zeros land in the
+    // buffer nobody reads any more)
+    if (!(DBG & 8)) issue_begin(it + 1);
+    // ... strictly BEHIND the group's MFMAs (the scheduler otherwise puts the piece behind the first one: one queued MFMA to
+    // cover a 60-185 cycle issue instead of four)
+#ifndef TAMD_X_DKDV_FEED
+#define TAMD_X_DKDV_FEED 0
+#endif
+    auto feed_piece = [&](int gidx) {
+      if (DBG & 8) return;
+      sched_fence();
+      if (TAMD_X_DKDV_FEED == 0) {  // one piece per group, groups 0 .. NPIECE-1
+        if (gidx < NPIECE) issue_piece(cur ^ 1, gidx);
+      } else {  // two pieces behind each of the first NI groups (S / dP of sub-tile 0: four MFMAs and four reads, nothing else), the
+                // statistics behind the next one: the groups that carry softmax arithmetic carry no tile piece
+        if (gidx < NI) {
+          issue_piece(cur ^ 1, 2 * gidx);
+          issue_piece(cur ^ 1, 2 * gidx + 1);
+        } else if (gidx == NI) {
+          issue_piece(cur ^ 1, 2 * NI);
+        }
+      }
     };
     // key visible to local query row r of this tile iff mask_lim <= r (padding / out-of-range keys: never)
     const int mask_lim = key_ok ? (CAUSAL ? krow - (qt0 + off) : -0x40000000) : 0x40000000;
@@ -417,7 +457,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x402, 14, 0);  // VALU or TRANS, in the scheduler's own order (a fixed
+#ifndef TAMD_X_DKDV_SGB
+#define TAMD_X_DKDV_SGB 4
+#endif
+        __builtin_amdgcn_sched_group_barrier(0x402, TAMD_X_DKDV_SGB, 0);  // VALU or TRANS, in the scheduler's own order (a fixed
                                                              // exp slot put every v_exp next to its consumer: 46
                                                              // trans-use hazard NOPs per tile)
       }
@@ -471,6 +514,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           for (int c = 0; c < NCH_A; ++c) softmax_chunk(0, ga * NCH_A + c, d4[c]);
           mfma_valu_interleave();
         }
+        feed_piece(gidx);
         sched_fence();
       }
     }
@@ -517,6 +561,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
           for (int c = 0; c < NCH_C; ++c) softmax_chunk(1, gc * NCH_C + c, d4[c]);
           mfma_valu_interleave();
         }
+        feed_piece(gidx);
         sched_fence();
       }
     }

@@ -185,6 +185,16 @@ __device__ __forceinline__ void wait_frag(u32x4& f) {
   (void)f;
 #endif
 }
+// The two fragments are "produced" here: whatever computes them cannot be sunk below this point, nothing that reads them hoisted
+// above it (an empty asm: no instruction)
+__device__ __forceinline__ void pin_frags(u32x4& f0, u32x4& f1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(f0), "+v"(f1));
+#else
+  (void)f0;
+  (void)f1;
+#endif
+}
 // wait_frag<min(n, CAP)> for a compile-time-foldable n (unrolled loop index arithmetic)
 template <int CAP>
 __device__ __forceinline__ void constexpr_wait_frag(int n, u32x4& f) {

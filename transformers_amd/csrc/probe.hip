@@ -81,6 +81,18 @@ __global__ void probe_kernel(const unsigned int* __restrict__ in, const unsigned
     out[2048 + lane * 2 + 1] = t[1];
     out[2304 + lane * 2] = t2[0];
     out[2304 + lane * 2 + 1] = t2[1];
+  } else if (which == 7) {  // range-checked buffer LDS-DMA: lanes past the buffer's size write ZEROS; a scalar offset counts towards the range
+    for (int i = lane; i < 512; i += 64) lds_write16(smem, (unsigned)i * 16u, u32x4{0xdeadbeefu, 7, 8, 9});
+    block_sync();
+    const char* base = reinterpret_cast<const char*>(in);
+    glds16_buf_rng(base, 4096u, in2[lane], smem, 1024u);                 // offsets up to 8 KiB: about half out of range
+    glds16_buf_rng(base + 1024, 0u, in2[lane], smem, 2048u);              // an empty buffer: every lane zero
+    glds4_buf_rng(base, 2048u, in2[lane] >> 2, 4096u, smem, 3072u);       // 4-byte pieces; scalar offset past the size: all zeros
+    glds4_buf_rng(base, 6144u, in2[lane] >> 2, 4096u, smem, 3584u);       // ... inside it: offsets below 2048 fetch
+    glds4_buf_rng(base, 0x7fffffffu, (unsigned)lane * 4u, 512u, smem, 3328u);
+    wait_vmcnt0();
+    block_sync();
+    for (int i = lane; i < 512; i += 64) st16(out + i * 4, lds_read16(smem, (unsigned)i * 16u));
   }
 }
 

@@ -197,6 +197,23 @@ __device__ __forceinline__ void glds16_buf(const void* base, unsigned voff, char
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_base_off), 16,
                                            (int)voff, 0, IMM, 0);
 }
+// The same with the hardware's range check (wave-uniform `bytes` = the buffer's size): a lane whose access does not lie inside
+// [0, bytes) fetches nothing and ZEROS land in its LDS slot -- ragged and padding tiles cost no branch and no zero page
+// (tests/test_gpu_probe.py probe 7 checks this on silicon -- and that a scalar offset counts towards the range: MI355X
+// returned zeros for every lane of a piece whose `soff` alone was past `bytes`).
+__device__ __forceinline__ void glds16_buf_rng(const void* base, unsigned bytes, unsigned voff, char* smem, unsigned lds_base_off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_base_off), 16,
+                                           (int)voff, 0, 0, 0);
+}
+// 4-byte pieces (buffer_load_dword ... offen lds): the wave writes 64 x 4 B at smem + lds_base_off; `soff` (wave-uniform) is
+// added to the source address AND range-checked with the lane offset: soff + voff + 4 <= bytes
+__device__ __forceinline__ void glds4_buf_rng(const void* base, unsigned bytes, unsigned voff, unsigned soff, char* smem,
+                                              unsigned lds_base_off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_base_off), 4,
+                                           (int)voff, (int)soff, 0, 0);
+}
 // 16-byte buffer load into registers (buffer_load_dwordx4 ... offen): wave-uniform `base`, per-lane 32-bit byte offset
 __device__ __forceinline__ u32x4 buf_load16(const void* base, unsigned voff) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, 0x7fffffff, 0x00020000);
