@@ -31,11 +31,38 @@ def _regs(text):
     return out
 
 
+def _self_loops_twice(lines):
+    """A basic block that branches back to its own label (the hand-placed tile loops: one block per loop) is laid out twice in a
+    row, so that reads requested at its bottom for the top of the next trip (the fragments of the next tile's first MFMA groups)
+    meet the waits that cover them: the straight-line analysis below then sees the loop-carried reads too."""
+    out, i = [], 0
+    while i < len(lines):
+        t = lines[i].strip()
+        if t.startswith(".LBB") and ":" in t:
+            label = t.split(":")[0]
+            j = i + 1
+            while j < len(lines) and not (lines[j].strip().startswith(".LBB") and ":" in lines[j]):
+                j += 1
+            block = lines[i:j]
+            back = [k for k, b in enumerate(block) if re.match(r"\s*s_c?branch\w*\s+" + re.escape(label) + r"\b", b)]
+            if back:
+                # first trip (label, body up to and including the branch), then the body again WITHOUT the label (state carried)
+                out += block[:back[-1]] + block[1:]
+            else:
+                out += block
+            i = j
+        else:
+            out.append(lines[i])
+            i += 1
+    return out
+
+
 def lint_kernel(name, lines):
     """lines: the assembly of one kernel.  Returns a list of violations."""
     pending = []  # [(set of dst regs)] of untracked LDS reads in issue order (they complete in order)
     bad = []
     in_asm = False
+    lines = _self_loops_twice(lines)
     for ln in lines:
         t = ln.strip()
         if t.startswith(";;#ASMSTART"):

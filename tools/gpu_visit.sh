@@ -9,7 +9,7 @@ exec < /dev/null
 #   kernels [which...]       tools/gpu_bench_kernels.py (gemm attn hbm layer)
 #   gemm_pmc                 tools/gemm_vs_vendor_pmc.py under one rocprofv3 --pmc pass per counter set (ours vs hipBLASLt)
 #   gemm_ab / attn_ab        this tree's library against tools/ab/libtamd_base.so (tools/build_base_lib.sh), interleaved
-#   attn_variants            ... and every tools/ab/libtamd_[v-z]*.so (tools/build_variant.py), attention entry points
+#   attn_variants            ... and every tools/ab/libtamd_[p-z]*.so (tools/build_variant.py), attention entry points
 #   attn_pmc                 rocprofv3 --pmc passes over the attention kernels of this tree (tools/attn_pmc.py)
 #   attn_prof                per-kernel times of the attention kernels at the Llama-3-8B shape (rocprofv3)
 #   bert / bert_graph / llava   the other BASELINE configurations' bench lines
@@ -84,8 +84,8 @@ step_attn_ab() {
   timeout 300 python tools/attn_lib_ab.py > $out/${tag}_attn_lib_ab.jsonl 2> $out/${tag}_attn_lib_ab.err
   cut -c1-300 $out/${tag}_attn_lib_ab.jsonl; tail -2 $out/${tag}_attn_lib_ab.err
 }
-step_attn_variants() {  # tools/ab/libtamd_base.so, this tree's library and every tools/ab/libtamd_[v-z]*.so (tools/build_variant.py)
-  AB_SHAPES=${AB_SHAPES:-llama3-8b,bidir-128} timeout 500 python tools/attn_lib_ab.py tools/ab/libtamd_base.so transformers_amd/libtamd.so $(ls tools/ab/libtamd_[v-z]*.so 2>/dev/null) > $out/${tag}_attn_variants_ab.jsonl 2> $out/${tag}_attn_variants_ab.err
+step_attn_variants() {  # tools/ab/libtamd_base.so, this tree's library and every tools/ab/libtamd_[p-z]*.so (tools/build_variant.py)
+  AB_SHAPES=${AB_SHAPES:-llama3-8b,bidir-128} timeout 500 python tools/attn_lib_ab.py tools/ab/libtamd_base.so transformers_amd/libtamd.so $(ls tools/ab/libtamd_[p-z]*.so 2>/dev/null) > $out/${tag}_attn_variants_ab.jsonl 2> $out/${tag}_attn_variants_ab.err
   python - <<PY
 import json
 for l in open("$out/${tag}_attn_variants_ab.jsonl"):

@@ -329,9 +329,35 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     sn[r] = 0.f;
     dpn[r] = 0.f;
   }
+  // FINE (every variant without dropout): the tile loop as a hand-placed stream -- see tile_pair_fine below
+  constexpr bool FINE = !DROP;
+  constexpr int NGRP = 2 * NGA + 2 * NGC;  // MFMA groups of a tile
+  // fragment j of group m of the tile in LDS buffer `buf` -> slot j of the ring half m & 1 (one b128 read, or two transposing
+  // reads): groups 0 .. 2*NGA-1 are S / dP of the two sub-tiles (Q(ks0) dO(ks0) Q(ks0+1) dO(ks0+1)), the others dV / dK
+  // (dO^T(dt0,j) Q^T(dt0,j) dO^T(dt1,j) Q^T(dt1,j))
+  auto req = [&](int buf, int m, int j) {
+    if (DBG & 2) return;
+    const unsigned q_off = (unsigned)buf * BUFB, do_off = q_off + TILEB;
+    u32x4(&f)[4] = (m & 1) ? fb : fa;
+    if (m < 2 * NGA) {
+      const int sub = m / NGA, ga = m % NGA;
+      f[j] = lds_read16_abs(rowaddr[2 * ga + (j >> 1)], (int)((j & 1) ? do_off : q_off) + sub * 32 * ROWB);
+    } else {
+      const int c = m - 2 * NGA, half = c / NGC, gc = c % NGC;
+      f[j] = tr_frag((j & 1) ? q_off : do_off, 2 * (gc >> 1) + (j >> 1), half * 2 + (gc & 1));
+    }
+  };
   if (niter > 0) {
-    load_rows(fa, 0u, (unsigned)TILEB, 0, 0);
-    load_stats(sn, dpn, 0, 0);
+    if (FINE) {  // what the tail of a tile leaves behind for the next one
+      load_stats(sn, dpn, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) req(0, 0, j);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) req(0, 1, j);
+    } else {
+      load_rows(fa, 0u, (unsigned)TILEB, 0, 0);
+      load_stats(sn, dpn, 0, 0);
+    }
   }
   const int niter2 = (niter + 1) & ~1;  // even: an odd count gets one all-zero padding tile
   int cmp_h = 0, cmp_qt = nqt64 - 1;    // (head, q-tile) of the tile being computed
@@ -368,23 +394,10 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     if (!(DBG & 8)) issue_begin(it + 1);
     // ... strictly BEHIND the group's MFMAs (the scheduler otherwise puts the piece behind the first one: one queued MFMA to
     // cover a 60-185 cycle issue instead of four)
-#ifndef TAMD_X_DKDV_FEED
-#define TAMD_X_DKDV_FEED 0
-#endif
-    auto feed_piece = [&](int gidx) {
+    auto feed_piece = [&](int gidx) {  // one piece behind each of the groups 0 .. NPIECE-1
       if (DBG & 8) return;
       sched_fence();
-      if (TAMD_X_DKDV_FEED == 0) {  // one piece per group, groups 0 .. NPIECE-1
-        if (gidx < NPIECE) issue_piece(cur ^ 1, gidx);
-      } else {  // two pieces behind each of the first NI groups (S / dP of sub-tile 0: four MFMAs and four reads, nothing else), the
-                // statistics behind the next one: the groups that carry softmax arithmetic carry no tile piece
-        if (gidx < NI) {
-          issue_piece(cur ^ 1, 2 * gidx);
-          issue_piece(cur ^ 1, 2 * gidx + 1);
-        } else if (gidx == NI) {
-          issue_piece(cur ^ 1, 2 * NI);
-        }
-      }
+      if (gidx < NPIECE) issue_piece(cur ^ 1, gidx);
     };
     // key visible to local query row r of this tile iff mask_lim <= r (padding / out-of-range keys: never)
     const int mask_lim = key_ok ? (CAUSAL ? krow - (qt0 + off) : -0x40000000) : 0x40000000;
@@ -457,12 +470,11 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-#ifndef TAMD_X_DKDV_SGB
-#define TAMD_X_DKDV_SGB 4
-#endif
-        __builtin_amdgcn_sched_group_barrier(0x402, TAMD_X_DKDV_SGB, 0);  // VALU or TRANS, in the scheduler's own order (a fixed
-                                                             // exp slot put every v_exp next to its consumer: 46
-                                                             // trans-use hazard NOPs per tile)
+        __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);  // at most 4 VALU or TRANS beside each MFMA, in the scheduler's
+                                                            // own order (a fixed exp slot put every v_exp next to its consumer: 46
+                                                            // trans-use hazard NOPs per tile; "up to 14" -- rounds 2-4 -- put a group's
+                                                            // whole chunk behind its FIRST MFMA and queued the other three back to
+                                                            // back: +1.2 ... 2 % on the whole backward, profiles/r05g_attn_variants_ab.jsonl)
       }
     };
     // ---- phases A0, A1: S and dP of the two 32-row sub-tiles; A1 carries the softmax backward of sub-tile 0
@@ -567,6 +579,182 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     }
    }
   };
+  // ---- The tile loop as a hand-placed stream (round 5; every variant without dropout).
+  // One wave per SIMD issues in order: while it queues four MFMAs back to back nothing else of it issues, and whatever stands
+  // between two groups of MFMAs runs with the matrix pipe idle -- the counters of the grouped loop above said exactly that
+  // (profiles/r05f_attn_pmc.md: pipe busy 51 % of the time, MFMA and VALU co-executing 7 % of it; 4000 cycles per tile = 2048 of
+  // MFMA + ~1950 of everything else, nothing hidden).  Here every MFMA is followed by ITS share of the rest, pinned by a
+  // scheduling fence per gap:
+  //   gap (m, k) = behind MFMA k of group m:  the LDS read(s) of fragment (m+2, k-1) (k = 0: of (m+1, 3)) -- 4 .. 7 MFMAs
+  //   ahead of its use, into the ring slot the MFMA before just read; three instructions of softmax-backward arithmetic
+  //   (groups that carry a chunk); behind a group's last gap a piece of the next tile (groups 0 .. 8).
+  // One counted wait per group: fragment (m, 3) is the youngest of group m, requested four gaps ago; behind it went only
+  // the three fragments (m+1, 0..2) (+ six statistics reads in group 0) -- lgkmcnt(3 R) covers the group.  The tail of a tile
+  // may not read the next tile before the hand-off (start of the last group): the fragments (G, 0..2) wait for gap (G-1, 0),
+  // so the hand-off's lgkmcnt(0) finds nothing younger than three gaps.
+  auto tile_pair_fine = [&](auto plain_c, int it0) __attribute__((always_inline)) {
+   constexpr bool PLAIN = decltype(plain_c)::value != 0;
+   constexpr int G = NGRP;
+#pragma unroll
+   for (int cur = 0; cur < 2; ++cur) {
+    const int it = it0 + cur;
+    const int qt0 = it < niter ? cmp_qt * kQT : nqt64 * kQT;
+    if (++cmp_h == group) {
+      cmp_h = 0;
+      --cmp_qt;
+    }
+    if (!(DBG & 8)) issue_begin(it + 1);
+    const int mask_lim = key_ok ? (CAUSAL ? krow - (qt0 + off) : -0x40000000) : 0x40000000;
+    const int mask_hi = kend - qt0;  // PACKED: last local query row of this tile that belongs to the key's sequence
+    sched_fence();
+    f32x16 s[2], dp[2];
+    u32x4 pf[4], dsf[4];
+    s[0] = sn;  // (requested behind the previous tile's hand-off)
+    dp[0] = dpn;
+    constexpr int NCH = 4 / NGA;  // softmax chunks (4 query rows each) a group carries (NGA == NGC)
+    static_assert(NGA == NGC, "head_dim 64 / 128");
+    float pe[NCH][4], dse[NCH][4];
+    // slice k of the softmax backward of chunk qd of sub-tile sub (4 consecutive query rows: C-layout registers qd*4 .. +3):
+    // three instructions per slice for a tile that needs no mask
+    auto slice = [&](int sub, int qd, int c, int k) {
+      if (DBG & 1) {
+        if (k == 3) {
+          const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
+          pf[op][w] = f32_as_u32(s[sub][qd * 4]);
+          pf[op][w + 1] = f32_as_u32(s[sub][qd * 4 + 1]);
+          dsf[op][w] = f32_as_u32(dp[sub][qd * 4]);
+          dsf[op][w + 1] = f32_as_u32(dp[sub][qd * 4 + 1]);
+        }
+        return;
+      }
+      const int ql = sub * 32 + 8 * qd + 4 * hi;
+      auto ex = [&](int e) {
+        float x = s[sub][qd * 4 + e];
+        if (PACKED)
+          x = (mask_lim <= ql + e && ql + e <= mask_hi) ? x : -INFINITY;
+        else if (!PLAIN)
+          x = (mask_lim <= ql + e) ? x : -INFINITY;
+        pe[c][e] = fast_exp2(x);  // x = S*scale*log2(e) - lse*log2(e): the chain started from -lse*log2(e)
+      };
+      auto ml = [&](int e) { dse[c][e] = pe[c][e] * dp[sub][qd * 4 + e]; };  // (the dP chain started from -delta)
+      const int op = sub * 2 + (qd >> 1), w = (qd & 1) * 2;
+      if (k == 0) {
+        ex(0);
+        ex(1);
+        ex(2);
+      } else if (k == 1) {
+        ex(3);
+        ml(0);
+        ml(1);
+      } else if (k == 2) {
+        ml(2);
+        ml(3);
+        pf[op][w] = pack2<T>(pe[c][0], pe[c][1]);
+      } else {
+        pf[op][w + 1] = pack2<T>(pe[c][2], pe[c][3]);
+        dsf[op][w] = pack2<T>(dse[c][0], dse[c][1]);
+        dsf[op][w + 1] = pack2<T>(dse[c][2], dse[c][3]);
+      }
+    };
+    constexpr int RA = 1, RC = 2;  // LDS reads per fragment: one b128 row read, two transposing reads
+    auto nreads = [&](int m) -> int { return (DBG & 2) ? 0 : (((m % G) < 2 * NGA) ? RA : RC); };
+#pragma unroll
+    for (int m = 0; m < G; ++m) {
+      u32x4(&fc)[4] = (m & 1) ? fb : fa;
+      const bool aph = m < 2 * NGA;
+      const int sub = m / NGA, ga = m % NGA;                                      // S / dP groups
+      const int cidx = m - 2 * NGA, half = cidx / NGC, gc = cidx % NGC;           // dV / dK groups
+      const int dtp = gc >> 1, jc = half * 2 + (gc & 1);
+      // ---- this group's fragments have landed
+      if (m == G - 1) {  // hand-off: every fragment of this tile is in registers; tile it+1 (requested during this tile) has landed
+        wait_vmcnt0();
+        wait_lgkmcnt0();
+        if (!(DBG & 16)) raw_barrier();
+        sched_fence();
+        wait_frags<15>(fc[0], fc[1], fc[2], fc[3]);  // dependency only
+      } else {
+        const int behind = 3 * nreads(m + 1) + ((m == 1 && !(DBG & 1)) ? 6 : 0);  // (group 0's gaps 1 .. 3 also carry statistics reads)
+        if (behind >= 9)
+          wait_frags<9>(fc[0], fc[1], fc[2], fc[3]);
+        else if (behind >= 6)
+          wait_frags<6>(fc[0], fc[1], fc[2], fc[3]);
+        else if (behind >= 3)
+          wait_frags<3>(fc[0], fc[1], fc[2], fc[3]);
+        else
+          wait_frags<0>(fc[0], fc[1], fc[2], fc[3]);
+      }
+      if (m == 0) after_wait_acc(s[0], dp[0]);
+      if (m == 2) after_wait_acc(s[1], dp[1]);  // (requested in the gaps of groups 0 and 1: older than everything group 2 waits for)
+      sched_fence();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // ---- MFMA k of the group
+        if (aph) {
+          if (k & 1)
+            dp[sub] = mm(fc[k], vf[2 * ga + (k >> 1)], dp[sub]);
+          else
+            s[sub] = mm(fc[k], kf[2 * ga + (k >> 1)], s[sub]);
+        } else {
+          if (k & 1)
+            dkacc[2 * dtp + (k >> 1)] = mm(fc[k], dsf[jc], dkacc[2 * dtp + (k >> 1)]);
+          else
+            dvacc[2 * dtp + (k >> 1)] = mm(fc[k], pf[jc], dvacc[2 * dtp + (k >> 1)]);
+        }
+        // ---- its gap
+        // statistics that start sub-tile 1's chains: two reads in each of the gaps (0, 1), (0, 2), (0, 3), (1, 0), BEFORE the
+        // gap's fragment request (the wait counts above rely on that order)
+        {
+          const int jst = (m == 0) ? k - 1 : (m == 1 && k == 0 ? 3 : -1);
+          if (jst >= 0 && !(DBG & 1)) {
+            const u32x4 l4 = lds_read16_abs(stataddr[cur], (32 + 8 * jst) * 4);
+            const u32x4 d4 = lds_read16_abs(stataddr[cur], (32 + 8 * jst) * 4 + kQT * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s[1][4 * jst + e] = u32_as_f32(l4[e]);
+              dp[1][4 * jst + e] = u32_as_f32(d4[e]);
+            }
+          }
+          if (m == 0 && k == 0 && (DBG & 1)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              s[1][r] = 0.f;
+              dp[1][r] = 0.f;
+            }
+          }
+        }
+        // the fragment request of the gap
+        if (m == G - 1 && k == 0) {  // behind the hand-off: the next tile's first statistics, its group 0, and (below) (G, 3)
+          load_stats(sn, dpn, cur ^ 1, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) req(cur ^ 1, 0, j);
+        }
+        {
+          const int mt = k == 0 ? m + 1 : m + 2, jt = k == 0 ? 3 : k - 1;  // target fragment of gap (m, k)
+          const bool held = (m == G - 2 && k >= 1);                         // (G, 0..2): not before the hand-off
+          if (!held) {
+            if (mt >= G)
+              req(cur ^ 1, mt - G, jt);
+            else
+              req(cur, mt, jt);
+          }
+        }
+        // softmax backward: sub-tile 0 beside S / dP of sub-tile 1, sub-tile 1 beside the first half of dV / dK
+        if (aph && sub == 1) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) slice(0, ga * NCH + c, c, k);
+        }
+        if (!aph && half == 0) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) slice(1, gc * NCH + c, c, k);
+        }
+        // a piece of the next tile in the first gap of the groups 0 .. NPIECE-1 (measured level with / 0.4-0.9 % ahead of "behind
+        // the group's last MFMA", profiles/r05h_, r05i_attn_variants_ab.jsonl)
+        if (k == 0 && m < NPIECE && !(DBG & 8)) issue_piece(cur ^ 1, m);
+        sched_fence();
+      }
+    }
+   }
+  };
   int it_plain = 0;  // (even) leading tiles of this wave that take the body without the mask test
   if (!PACKED && !(DBG & 32) && ballot64(key_ok) == ~0ull) {
     int n = niter2;
@@ -579,10 +767,15 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     it_plain = n & ~1;
   }
   int it0 = 0;
-  if (!(DROP && D > 64)) {  // (two bodies of the dropout variant at head_dim 128 do not fit the registers)
-    for (; it0 < it_plain; it0 += 2) tile_pair(IntC<1>{}, it0);
+  if (FINE) {
+    for (; it0 < it_plain; it0 += 2) tile_pair_fine(IntC<1>{}, it0);
+    for (; it0 < niter2; it0 += 2) tile_pair_fine(IntC<0>{}, it0);
+  } else {
+    if (!(DROP && D > 64)) {  // (two bodies of the dropout variant at head_dim 128 do not fit the registers)
+      for (; it0 < it_plain; it0 += 2) tile_pair(IntC<1>{}, it0);
+    }
+    for (; it0 < niter2; it0 += 2) tile_pair(IntC<0>{}, it0);
   }
-  for (; it0 < niter2; it0 += 2) tile_pair(IntC<0>{}, it0);
   // the last hand-off left nothing in flight; every wave is past its LDS reads only after a barrier
   wait_vmcnt0();
   block_sync();

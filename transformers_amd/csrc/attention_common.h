@@ -129,6 +129,13 @@ struct TileFeed {
                                             int i) const {  // piece i < NI of this wave
     glds16_buf<0>(first_row, voff[i], smem, tile_off + (unsigned)(wave * NI + i) * 1024u);
   }
+  // ... range-checked: `rows` (wave-uniform, 0 .. 64) of the tile exist, the others arrive as zeros -- the ragged last tile of a
+  // sequence and "no next tile" (rows = 0: the buffer nobody reads is zero-filled) cost no branch and no second code path
+  template <typename T>
+  __device__ __forceinline__ void issue_one_rng(const T* __restrict__ first_row, int rows, int64_t stride, char* smem,
+                                                unsigned tile_off, int wave, int i) const {
+    glds16_buf_rng(first_row, (unsigned)rows * (unsigned)stride * 2u, voff[i], smem, tile_off + (unsigned)(wave * NI + i) * 1024u);
+  }
   template <typename T>
   __device__ __forceinline__ void issue(const T* __restrict__ first_row, char* smem, unsigned tile_off, int wave) const {
 #pragma unroll
@@ -194,6 +201,27 @@ __device__ __forceinline__ void pin_frags(u32x4& f0, u32x4& f1) {
   (void)f0;
   (void)f1;
 #endif
+}
+// ... for a PAIR of fragments (one s_waitcnt in front of two MFMAs: N counts the reads issued after the pair's second fragment)
+template <int N>
+__device__ __forceinline__ void wait_frag2(u32x4& f0, u32x4& f1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N) : "memory");
+#else
+  (void)f0;
+  (void)f1;
+#endif
+}
+template <int CAP>
+__device__ __forceinline__ void constexpr_wait_frag2(int n, u32x4& f0, u32x4& f1) {
+  static_assert(CAP <= 15, "lgkmcnt is a 4-bit counter");
+  if (n >= CAP) return wait_frag2<CAP>(f0, f1);
+#define TAMD_WF(N_) \
+  if (N_ < CAP && n == N_) return wait_frag2<(N_ < CAP ? N_ : 0)>(f0, f1);
+  TAMD_WF(14) TAMD_WF(13) TAMD_WF(12) TAMD_WF(11) TAMD_WF(10) TAMD_WF(9) TAMD_WF(8) TAMD_WF(7) TAMD_WF(6) TAMD_WF(5) TAMD_WF(4)
+  TAMD_WF(3) TAMD_WF(2) TAMD_WF(1)
+#undef TAMD_WF
+  wait_frag2<0>(f0, f1);
 }
 // wait_frag<min(n, CAP)> for a compile-time-foldable n (unrolled loop index arithmetic)
 template <int CAP>
