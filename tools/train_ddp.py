@@ -134,7 +134,11 @@ def main():
                    train_loss=out.training_loss, replicas_identical=bool(same),
                    tokens_per_s=timed_steps * args.per_device_train_batch_size * args.seq * world / max(dt, 1e-9),
                    ddp=type(trainer.model_wrapped).__name__, optimizer=type(getattr(trainer.optimizer, "optimizer", trainer.optimizer)).__name__,
-                   attn_implementation=model.config._attn_implementation)
+                   attn_implementation=model.config._attn_implementation,
+                   # the unchanged Trainer never asked for bucket views or a hook: transformers_amd.accelerate() arranged both
+                   # (ddp.install_trainer_dropin); zero_copy_layers counts layer backwards that wrote into the buckets
+                   gradient_as_bucket_view=bool(getattr(trainer.model_wrapped, "gradient_as_bucket_view", False)),
+                   ddp_zero_copy=dict(transformers_amd.ddp.STATS))
         Path(args.output_dir).mkdir(parents=True, exist_ok=True)
         (Path(args.output_dir) / "train_ddp.json").write_text(json.dumps(res))
         print(json.dumps(res), flush=True)

@@ -342,14 +342,20 @@ __global__ void swiglu_bwd_kernel(const T* gate, const T* up, const T* __restric
   constexpr int VE = vec16<T>::N;
   const int vpr = inter / VE;
   const int64_t total = tokens * vpr;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = idx / vpr;
-    const int c = (int)(idx % vpr) * VE;
+  // (token, column vector) of a flat index, kept by STEPPING: the grid stride is a constant number of rows and columns
+  // (round 5: the loop divided a 64-bit index by vpr in every trip -- ~60 instructions of software division beside 48 bytes of
+  // traffic -- and had one vector's three loads in flight per lane; now two vectors per trip, their six loads issued together)
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t st_t = stride / vpr;
+  const int st_c = (int)(stride % vpr);
+  int64_t t = idx0 / vpr;
+  int cv = (int)(idx0 % vpr);
+  auto one = [&](int64_t tt, int cc, const u32x4& gv, const u32x4& uv, const u32x4& dv) {
     float g[VE], u[VE], d[VE], dg[VE], du[VE], a[VE];
-    unpack16<T>(ld16(gate + t * ld_gu + c), g);
-    unpack16<T>(ld16(up + t * ld_gu + c), u);
-    unpack16<T>(ld16(dact + t * ld_act + c), d);
+    unpack16<T>(gv, g);
+    unpack16<T>(uv, u);
+    unpack16<T>(dv, d);
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
       const float s = round_through<T>(silu_f(g[i]));
@@ -358,9 +364,36 @@ __global__ void swiglu_bwd_kernel(const T* gate, const T* up, const T* __restric
       a[i] = s * u[i];
     }
     // dgate/dup may alias gate/up (in-place gradient): all loads of this vector are done.
-    st16(dgate + t * ld_gu + c, pack16<T>(dg));
-    st16(dup + t * ld_gu + c, pack16<T>(du));
-    if (WRITE_ACT) st16(act_out + t * ld_act + c, pack16<T>(a));
+    st16(dgate + tt * ld_gu + cc, pack16<T>(dg));
+    st16(dup + tt * ld_gu + cc, pack16<T>(du));
+    if (WRITE_ACT) st16(act_out + tt * ld_act + cc, pack16<T>(a));
+  };
+  auto step = [&](int64_t& tt, int& cc) {  // (tt, cc) += grid stride
+    tt += st_t;
+    cc += st_c;
+    if (cc >= vpr) {
+      cc -= vpr;
+      ++tt;
+    }
+  };
+  for (int64_t idx = idx0; idx < total; idx += 2 * stride) {
+    int64_t t2 = t;
+    int c2 = cv;
+    step(t2, c2);
+    const bool two = idx + stride < total;
+    const int c = cv * VE, cc2 = c2 * VE;
+    const u32x4 g1 = ld16(gate + t * ld_gu + c), u1 = ld16(up + t * ld_gu + c), d1 = ld16(dact + t * ld_act + c);
+    u32x4 g2 = g1, u2 = u1, d2 = d1;
+    if (two) {
+      g2 = ld16(gate + t2 * ld_gu + cc2);
+      u2 = ld16(up + t2 * ld_gu + cc2);
+      d2 = ld16(dact + t2 * ld_act + cc2);
+    }
+    one(t, c, g1, u1, d1);
+    if (two) one(t2, cc2, g2, u2, d2);
+    t = t2;
+    cv = c2;
+    step(t, cv);
   }
 }
 

@@ -47,6 +47,10 @@ def accelerate(model: nn.Module, attn_implementation: bool = True, fuse_loss: bo
             m.__class__ = repl
             n += 1
     model._tamd_swapped = n
+    if n > 0:  # the unchanged Trainer builds DDP without bucket views and registers no hook: ddp.install_trainer_dropin
+        from . import ddp
+
+        ddp.install_trainer_dropin()
     if fused_lm_head_loss:
         import types
 
