@@ -455,6 +455,31 @@ inline float fast_rcp(float x) { return 1.0f / x; }
 // division here is ten instructions per element -- v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup -- a third of the
 // SwiGLU epilogue of the gate|up GEMM, during which the matrix pipe idles.)
 inline float fast_sigmoid(float x) { return fast_rcp(1.f + fast_exp2(x * -1.44269504088896340736f)); }
+// erf-GELU (GELUActivation, activations.py:69-89): x * 0.5 * (1 + erf(x / sqrt 2)) and its derivative, from ONE exponential:
+//     erfc(z) = t (a1 + t (a2 + t (a3 + t (a4 + t a5)))) exp(-z^2),  t = 1 / (1 + p z),  z = |x| / sqrt 2     (Abramowitz & Stegun
+// 7.1.26, |error| <= 1.5e-7), 1 + erf = erfc(z) for x < 0 (no cancellation in the tail, where fp32 `1 + erff` loses every digit) and
+// 2 - erfc(z) otherwise; the same exp(-x^2 / 2) is the Gaussian of the derivative cdf + x pdf.  ~16 instructions where ocml's erff
+// is ~100 dependent, divergent ones (the activation kernels of bert-base ran at 3.3 TB/s on it: arithmetic-bound); against the
+// fp32 formula with an exact erf 0.2 % of the bf16 outputs move by one ulp (8e-8 norm-relative).  ONE definition for the
+// element-wise kernels and the GEMM epilogue, so that fused and unfused paths agree bit for bit.
+inline void gelu_erf_parts(float x, float& one_plus_erf, float& gauss) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = fast_rcp(fmaf(0.3275911f, z, 1.f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  gauss = fast_exp2((z * z) * -1.44269504088896340736f);  // exp(-x^2 / 2)
+  const float h = poly * gauss;                           // erfc(|x| / sqrt 2)
+  one_plus_erf = x < 0.f ? h : 2.f - h;
+}
+inline float gelu_erf_f(float x) {
+  float ope, g;
+  gelu_erf_parts(x, ope, g);
+  return x * 0.5f * ope;
+}
+inline float dgelu_erf_f(float x) {
+  float ope, g;
+  gelu_erf_parts(x, ope, g);
+  return 0.5f * ope + x * (0.39894228040143267794f * g);
+}
 inline float fast_log2(float x) { return log2f(x); }
 
 }  // namespace tamd

@@ -81,6 +81,17 @@ def test_argument_errors_do_not_launch():
     ap.q = ap.k = ap.v = ap.o = aligned.value
     ap.batch, ap.heads_q, ap.heads_kv, ap.seq_q, ap.seq_k, ap.head_dim = 1, 2, 1, 8, 8, 80
     assert lib.tamd_attn_fwd(ctypes.byref(ap), None) == -2  # head_dim 80 unsupported
+    # row strides: the tile loaders address 64 rows with 32-bit offsets from a scalar base and cut ragged tiles off with the
+    # buffer's size -- rows must follow each other upwards, at most 2^24 elements apart (a one-row operand's stride is ignored)
+    ap.head_dim = 64
+    for name, bad in (("k_stride_s", 0), ("v_stride_s", -64), ("q_stride_s", 1 << 25), ("o_stride_s", 32)):
+        for f in ("q_stride_s", "k_stride_s", "v_stride_s", "o_stride_s"):
+            setattr(ap, f, 128)
+        for f in ("q_stride_b", "k_stride_b", "v_stride_b", "o_stride_b", "q_stride_h", "k_stride_h", "v_stride_h", "o_stride_h"):
+            setattr(ap, f, 64)
+        ap.dtype = _cabi.TAMD_BF16
+        setattr(ap, name, bad)
+        assert lib.tamd_attn_fwd(ctypes.byref(ap), None) == -6, name
 
 
 def test_product_path_has_no_cpu_fallback():

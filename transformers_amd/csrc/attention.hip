@@ -93,6 +93,13 @@ int attn_check(const tamd_attn_params* p) {
                              p->v_stride_b, p->v_stride_s, p->v_stride_h, p->o_stride_b, p->o_stride_s, p->o_stride_h};
   for (int64_t st : strides)
     if (st % 8 != 0) return TAMD_E_ALIGN;
+  // the tile loaders address a 64-row tile with 32-bit byte offsets from a scalar base (buffer-addressed LDS-DMA) and cut ragged
+  // tiles off with the buffer's size: rows must follow each other upwards, at most 2^24 elements apart (64 rows x 2^24 x 2 B = 2^31)
+  // (a one-row operand's row stride means nothing -- torch leaves anything there: make_args replaces it)
+  const int64_t row_strides[] = {p->q_stride_s, p->k_stride_s, p->v_stride_s, p->o_stride_s};
+  const int64_t row_counts[] = {p->seq_q, p->seq_k, p->seq_k, p->seq_q};
+  for (int i = 0; i < 4; ++i)
+    if (row_counts[i] > 1 && (row_strides[i] < p->head_dim || row_strides[i] > ((int64_t)1 << 24))) return TAMD_E_ARG;
   if (!aligned16(p->q) || !aligned16(p->k) || !aligned16(p->v) || !aligned16(p->o)) return TAMD_E_ALIGN;
   return TAMD_OK;
 }
@@ -112,16 +119,16 @@ AttnArgs make_args(const tamd_attn_params* p) {
   a.seq_q = (int)p->seq_q;
   a.seq_k = (int)p->seq_k;
   a.qsb = p->q_stride_b;
-  a.qss = p->q_stride_s;
+  a.qss = p->seq_q > 1 ? p->q_stride_s : p->head_dim;  // (one row: any positive stride addresses it; see attn_check)
   a.qsh = p->q_stride_h;
   a.ksb = p->k_stride_b;
-  a.kss = p->k_stride_s;
+  a.kss = p->seq_k > 1 ? p->k_stride_s : p->head_dim;
   a.ksh = p->k_stride_h;
   a.vsb = p->v_stride_b;
-  a.vss = p->v_stride_s;
+  a.vss = p->seq_k > 1 ? p->v_stride_s : p->head_dim;
   a.vsh = p->v_stride_h;
   a.osb = p->o_stride_b;
-  a.oss = p->o_stride_s;
+  a.oss = p->seq_q > 1 ? p->o_stride_s : p->head_dim;
   a.osh = p->o_stride_h;
   a.scale_log2 = p->scale * 1.44269504088896340736f;
   const double pd = p->dropout_p;

@@ -470,11 +470,13 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x402, 4, 0);  // at most 4 VALU or TRANS beside each MFMA, in the scheduler's
-                                                            // own order (a fixed exp slot put every v_exp next to its consumer: 46
-                                                            // trans-use hazard NOPs per tile; "up to 14" -- rounds 2-4 -- put a group's
-                                                            // whole chunk behind its FIRST MFMA and queued the other three back to
-                                                            // back: +1.2 ... 2 % on the whole backward, profiles/r05g_attn_variants_ab.jsonl)
+        __builtin_amdgcn_sched_group_barrier(0x402, 14, 0);  // VALU or TRANS, in the scheduler's own order (a fixed exp slot
+                                                             // put every v_exp next to its consumer: 46 trans-use hazard NOPs per
+                                                             // tile).  (This grouped body serves the dropout variants only since
+                                                             // round 5 -- the others run tile_pair_fine -- and their ~46 hash +
+                                                             // softmax instructions per group overflow any per-gap cap: "at most
+                                                             // 4 per gap" measured 1.5 % behind "up to 14" at bert-base with
+                                                             // dropout, profiles/r05n_attn_variants_ab.jsonl.)
       }
     };
     // ---- phases A0, A1: S and dP of the two 32-row sub-tiles; A1 carries the softmax backward of sub-tile 0

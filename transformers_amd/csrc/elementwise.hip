@@ -286,7 +286,7 @@ __device__ __forceinline__ float dsilu_f(float x) {
 
 template <int ACT>
 __device__ __forceinline__ float act_f(float x) {
-  if (ACT == TAMD_ACT_GELU_ERF) return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f));  // activations.py:69-89
+  if (ACT == TAMD_ACT_GELU_ERF) return gelu_erf_f(x);  // activations.py:69-89 (tamd_device.h)
   if (ACT == TAMD_ACT_GELU_TANH)  // activations.py:58-66
     return 0.5f * x * (1.f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x)));
   if (ACT == TAMD_ACT_QUICK_GELU) return x * sigmoid_f(1.702f * x);  // activations.py:116-123
@@ -295,11 +295,7 @@ __device__ __forceinline__ float act_f(float x) {
 }
 template <int ACT>
 __device__ __forceinline__ float dact_f(float x) {
-  if (ACT == TAMD_ACT_GELU_ERF) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
-  }
+  if (ACT == TAMD_ACT_GELU_ERF) return dgelu_erf_f(x);
   if (ACT == TAMD_ACT_GELU_TANH) {
     const float k = 0.79788456080286535588f;
     const float u = k * (x + 0.044715f * x * x * x);

@@ -131,7 +131,7 @@ __device__ __forceinline__ float gemm_silu(float x) { return x * fast_sigmoid(x)
 
 template <int ACT>
 __device__ __forceinline__ float gemm_act(float x) {
-  if (ACT == TAMD_ACT_GELU_ERF) return x * 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  if (ACT == TAMD_ACT_GELU_ERF) return gelu_erf_f(x);  // (tamd_device.h: one definition with the activation kernels)
   if (ACT == TAMD_ACT_GELU_TANH) return 0.5f * x * (1.f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x)));
   if (ACT == TAMD_ACT_QUICK_GELU) return x * fast_sigmoid(1.702f * x);  // (= act_fwd_f of elementwise.hip)
   if (ACT == TAMD_ACT_SILU) return x * fast_sigmoid(x);
