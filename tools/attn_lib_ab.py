@@ -28,12 +28,13 @@ class AttnBwdParamsV6(ctypes.Structure):
     _fields_ = [("fwd", AttnParamsV6)] + [f for f in AttnBwdParams._fields_ if f[0] != "fwd"]
 
 
+KEY_VALID = None  # AB_MASK=1: a [batch, seq_k] padding mask (the last 5 + 7 b keys of row b invalid): the HAS_MASK instantiations
 DROPOUT = float(os.environ.get("AB_DROPOUT", "0"))  # attention dropout probability (timing only: the builds' masks differ)
 
 
 def params(q, k, v, o, lse, scale, causal, p):
     p.q, p.k, p.v, p.o, p.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr()
-    p.key_valid = None
+    p.key_valid = KEY_VALID.data_ptr() if KEY_VALID is not None else None
     p.batch, p.seq_q, p.heads_q, p.head_dim = q.shape
     p.seq_k, p.heads_kv = k.shape[1], k.shape[2]
     for name, t in (("q", q), ("k", k), ("v", v), ("o", o)):
@@ -101,8 +102,14 @@ def main():
         v = torch.randn(b, s, hkv, d, device=dev).bfloat16()
         do = torch.randn(b, s, hq, d, device=dev).bfloat16()
         scale = 1 / math.sqrt(d)
+        global KEY_VALID
+        KEY_VALID = None
+        if os.environ.get("AB_MASK"):
+            KEY_VALID = torch.ones(b, s, dtype=torch.uint8, device=dev)
+            for i in range(b):
+                KEY_VALID[i, s - 5 - 7 * i:] = 0
         fl = 4.0 * b * hq * s * s * d * (0.5 if causal else 1.0)
-        ref = reference(q, k, v, do, scale, causal) if s <= 4096 and DROPOUT == 0 and not os.environ.get("AB_NOREF") else None
+        ref = reference(q, k, v, do, scale, causal) if s <= 4096 and DROPOUT == 0 and KEY_VALID is None and not os.environ.get("AB_NOREF") else None
         row = {"shape": name, "dropout_p": DROPOUT}
         runs = {}
         for tag, lib in libs.items():
