@@ -308,7 +308,9 @@ int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* ACT, int64_
  *
  *   O[b,s,h,:] = softmax_k( scale * Q[b,s,h,:] . K[b,k,h/g,:]  masked ) . V[b,k,h/g,:]
  *
- * q/k/v/o are addressed by element strides (batch, seq, head); head_dim contiguous.
+ * q/k/v/o are addressed by element strides (batch, seq, head); head_dim contiguous.  The rows of an operand with more than
+ * one row must follow each other upwards, head_dim <= stride_s <= 2^24 elements (the kernels address a 64-row tile with 32-bit
+ * byte offsets from a scalar base and cut a ragged tile off with the buffer's size: TAMD_E_ARG otherwise; ABI 9 of round 5).
  * causal: key k visible to query s iff k <= s + (seq_k - seq_q)  (masking_utils.py:76-81).
  * key_valid: optional [batch, seq_k] uint8 padding mask (1 = attend); NULL = no padding.
  * lse [batch, heads_q, seq_q] fp32 (natural-log sum-exp of the scaled scores) is written for
