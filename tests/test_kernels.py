@@ -555,6 +555,29 @@ def test_attention_fwd_bwd(env):
             assert rel_err(a, r) < 0.0057, (case, name)
 
 
+def test_attention_copies_views_the_kernels_cannot_address(env):
+    """The C ABI wants rows that follow each other upwards (include/tamd.h: head_dim <= stride_s <= 2^24).  An expanded operand
+    (row stride 0: every key the same row) is copied by the op instead of being refused; values and gradients match the
+    contiguous call bit for bit."""
+    torch.manual_seed(13)
+    dev = env.device
+    b, s, hq, hkv, d = 1, 96, 2, 1, 64
+    q = torch.randn(b, s, hq, d).bfloat16().to(dev).requires_grad_(True)
+    k_row = torch.randn(b, 1, hkv, d).bfloat16().to(dev)
+    v = torch.randn(b, s, hkv, d).bfloat16().to(dev).requires_grad_(True)
+    k_view = k_row.expand(b, s, hkv, d)
+    assert k_view.stride(1) == 0
+    k_c = k_view.contiguous().requires_grad_(True)
+    scale = 1 / math.sqrt(d)
+    o1 = ops.attention(q, k_view, v, scale, True)
+    o2 = ops.attention(q, k_c, v, scale, True)
+    assert torch.equal(o1, o2)
+    do = torch.randn_like(o1)
+    g1 = torch.autograd.grad(o1, (q, v), do)
+    g2 = torch.autograd.grad(o2, (q, v), do)
+    assert all(torch.equal(a, b_) for a, b_ in zip(g1, g2))
+
+
 DROPOUT_CASES_SMALL = [(1, 130, 130, 2, 1, 64, True, False, 0.1), (2, 96, 160, 2, 2, 128, False, True, 0.5),
                        (1, 67, 131, 3, 1, 64, True, False, 0.2)]  # odd lengths: the 2 x 2 hash blocks end ragged
 DROPOUT_CASES_BIG = [(2, 1024, 1024, 8, 2, 128, True, False, 0.1), (4, 512, 512, 12, 12, 64, False, True, 0.1),

@@ -918,17 +918,29 @@ std::tuple<Tensor, Tensor> op_gemm_swiglu(const Tensor& x2, const Tensor& wgu, b
   auto [gu, act] = k_gemm_swiglu(x2, wgu, need_gu);
   return {gu.defined() ? gu : nothing(x2), act};
 }
-std::tuple<Tensor, Tensor> op_attn_fwd(const Tensor& q, const Tensor& k, const Tensor& v, double scale, bool causal,
+// An attention operand as the C ABI takes it (include/tamd.h): head_dim contiguous, rows following each other upwards at most
+// 2^24 elements apart, strides multiples of 8 elements.  A caller's view that is something else -- an expanded (stride 0) or
+// flipped tensor -- is copied once; the layer ops never pass such views.
+Tensor attn_operand(const Tensor& t) {
+  const int64_t d = t.size(3);
+  const bool rows_ok = t.size(1) <= 1 || (t.stride(1) >= d && t.stride(1) <= ((int64_t)1 << 24));
+  const bool ok = t.stride(3) == 1 && rows_ok && t.stride(0) % 8 == 0 && t.stride(1) % 8 == 0 && t.stride(2) % 8 == 0;
+  return ok ? t : t.contiguous();
+}
+std::tuple<Tensor, Tensor> op_attn_fwd(const Tensor& q_, const Tensor& k_, const Tensor& v_, double scale, bool causal,
                                        const OptTensor& key_valid, bool need_lse, double dropout_p, int64_t seed,
                                        const OptTensor& q_start, const OptTensor& seed_dev) {
+  const Tensor q = attn_operand(q_), k = attn_operand(k_), v = attn_operand(v_);
   auto [o, lse] = k_attn_fwd(q, k, v, scale, causal, key_valid, need_lse, dropout_p, seed, q_start, false, seed_word(seed_dev, 0));
   return {o, lse.defined() ? lse : nothing(q)};
 }
-std::tuple<Tensor, Tensor, Tensor> op_attn_bwd(const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
+std::tuple<Tensor, Tensor, Tensor> op_attn_bwd(const Tensor& q_, const Tensor& k_, const Tensor& v_, const Tensor& o_,
                                                const Tensor& lse, const Tensor& dout, double scale, bool causal,
                                                const OptTensor& key_valid, double dropout_p, int64_t seed,
                                                const OptTensor& q_start, const OptTensor& rope_cos,
                                                const OptTensor& rope_sin, const OptTensor& seed_dev) {
+  // (the forward op copied such operands too: the same values, and gradients are returned by shape, not by strides)
+  const Tensor q = attn_operand(q_), k = attn_operand(k_), v = attn_operand(v_), o = attn_operand(o_);
   return k_attn_bwd(q, k, v, o, lse, dout, scale, causal, key_valid, Tensor(), Tensor(), Tensor(), dropout_p, seed, q_start,
                     rope_cos ? *rope_cos : Tensor(), rope_sin ? *rope_sin : Tensor(), false, seed_word(seed_dev, 0));
 }
@@ -1018,9 +1030,10 @@ Tensor op_rope(const Tensor& x, const Tensor& cos, const Tensor& sin, int64_t nh
   return y;
 }
 
-std::tuple<Tensor, Tensor> op_attention(const Tensor& q, const Tensor& k, const Tensor& v, const OptTensor& key_valid,
+std::tuple<Tensor, Tensor> op_attention(const Tensor& q_, const Tensor& k_, const Tensor& v_, const OptTensor& key_valid,
                                         double scale, bool causal, double dropout_p, int64_t seed, const OptTensor& q_start,
                                         bool train, const OptTensor& seed_dev) {
+  const Tensor q = attn_operand(q_), k = attn_operand(k_), v = attn_operand(v_);  // (the backward goes through op_attn_bwd: same copies)
   auto [o, lse] = k_attn_fwd(q, k, v, scale, causal, key_valid, train, dropout_p, seed, q_start, false, seed_word(seed_dev, 0));
   return {o, lse.defined() ? lse : nothing(q)};
 }
