@@ -776,6 +776,34 @@ def test_clip_vision_tower_hidden_states(env):
     assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
 
 
+def test_clip_patch_embedding_weight_gradient(env):
+    """Training a CLIP tower (VERDICT r4 missing 6): the patch embedding runs as a GEMM also when its weight wants a gradient
+    (models/clip/modeling_clip.py:148-154, 209-218) -- dW through the GEMM's own backward -- and nothing falls back."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+
+    torch.manual_seed(41)
+    cfg = CLIPVisionConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2, image_size=56,
+                           patch_size=14, attn_implementation="eager")
+    ref = CLIPVisionModel(cfg).bfloat16().train()
+    ref32 = copy.deepcopy(ref).float()
+    fast = copy.deepcopy(ref).to(env.device)
+    transformers_amd.accelerate(fast)
+    transformers_amd.fallback_calls(reset=True)
+    px = torch.randn(2, 3, 56, 56)
+    g = torch.randn(2, 17, 128)
+    outs = {}
+    for name, m, x, gg in (("fast", fast, px.bfloat16().to(env.device), g.bfloat16().to(env.device)), ("ref", ref, px.bfloat16(), g.bfloat16()),
+                           ("ref32", ref32, px, g)):
+        emb = m.embeddings(x)
+        emb.backward(gg)
+        outs[name] = (emb.detach().float().cpu(), m.embeddings.patch_embedding.weight.grad.detach().float().cpu())
+    assert not any(k.startswith("TamdCLIPVisionEmbeddings") for k in transformers_amd.fallback_calls()), transformers_amd.fallback_calls()
+    assert outs["fast"][1].shape == outs["ref32"][1].shape == (128, 3, 14, 14)
+    for i in (0, 1):  # the embeddings and dW: within 1.1x of the reference's own bf16 error against its fp32 run
+        e_fast, e_ref = rel_err(outs["fast"][i], outs["ref32"][i]), rel_err(outs["ref"][i], outs["ref32"][i])
+        assert e_fast <= 1.1 * e_ref + 1e-3, (i, e_fast, e_ref)
+
+
 def test_gpt2_on_kernels(env):
     """GPT-2 blocks (Conv1D = k-major GEMM operand, gelu_new, pre-LN, tied lm_head) through the kernels."""
     from transformers import GPT2Config, GPT2LMHeadModel

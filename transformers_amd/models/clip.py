@@ -99,8 +99,9 @@ class TamdCLIPVisionEmbeddings(ref.CLIPVisionEmbeddings):
     with K zero-padded to a multiple of 64 (640) on both operands so that the MFMA kernels' 64-deep stages apply.  One
     permuting copy of the pixels replaces the convolution (MIOpen's `naive_conv_ab_nonpacked_fwd_nchw`: 0.34 ms of a 21 ms
     LLaVA-1.5-7B forward, profiles/r03r_llava_kernel_stats.csv); the class token, the concatenation and the position
-    embedding stay the reference's own lines.  Forward only (no gradient reaches the convolution's weight through the
-    padded copy): when a gradient is needed the reference's convolution runs."""
+    embedding stay the reference's own lines.  Training a tower (round 5): when a gradient is wanted the padded weight is built
+    by a differentiable `pad` instead of taken from the cache, so dW arrives through the GEMM's own backward (dY^T . patches, cut
+    back to the 588 real columns by autograd) and d(pixels), if anybody asks, through the copy's."""
 
     def _padded_weight(self):
         w = self.patch_embedding.weight
@@ -120,7 +121,6 @@ class TamdCLIPVisionEmbeddings(ref.CLIPVisionEmbeddings):
         p = self.patch_size
         b, c, height, width = pixel_values.shape
         fast = (_gpu(pixel_values) and w.dtype in (torch.bfloat16, torch.float16) and self.patch_embedding.bias is None
-                and not (torch.is_grad_enabled() and (w.requires_grad or pixel_values.requires_grad))
                 and height % p == 0 and width % p == 0 and w.shape[0] % 8 == 0
                 and tuple(self.patch_embedding.stride) == (p, p) and tuple(self.patch_embedding.kernel_size) == (p, p)
                 and tuple(self.patch_embedding.padding) == (0, 0) and self.patch_embedding.groups == 1
@@ -129,8 +129,11 @@ class TamdCLIPVisionEmbeddings(ref.CLIPVisionEmbeddings):
             note_fallback(self, pixel_values)
             return super().forward(pixel_values, interpolate_pos_encoding=interpolate_pos_encoding)
         gh, gw = height // p, width // p
-        wp = self._padded_weight()
         k = c * p * p
+        if torch.is_grad_enabled() and w.requires_grad:  # a differentiable padded copy (1024 x 640: 1.3 MB)
+            wp = torch.nn.functional.pad(w.reshape(w.shape[0], k), (0, -(-k // 64) * 64 - k))
+        else:
+            wp = self._padded_weight()
         patches = pixel_values.new_zeros((b * gh * gw, wp.shape[1]), dtype=w.dtype)
         # [B, C, gh, p, gw, p] -> [B, gh, gw, C, p, p]: one copy (with the dtype cast of `pixel_values.to(target_dtype)`)
         patches[:, :k].view(b, gh, gw, c, p, p).copy_(pixel_values.view(b, c, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5))
