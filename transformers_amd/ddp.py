@@ -114,12 +114,16 @@ def install_trainer_dropin() -> None:
     orig_init = DDP.__init__
 
     def __init__(self, module, *args, **kwargs):
+        # ours: a marked module whose caller did not choose the flag (accelerate's `DistributedDataParallelKwargs.to_kwargs()`
+        # only passes what differs from the defaults).  A caller who passes it -- bench.py, the tests, the README's by-hand
+        # form -- manages the hook himself, `--no-ddp-zero-copy` arms included.
         ours = (os.environ.get("TAMD_DDP_ZERO_COPY", "1") != "0" and getattr(module, "_tamd_swapped", 0) > 0
+                and "gradient_as_bucket_view" not in kwargs
                 and len(args) < 9)  # (gradient_as_bucket_view is the 10th positional parameter: nobody passes it that way)
-        if ours and "gradient_as_bucket_view" not in kwargs:
+        if ours:
             kwargs["gradient_as_bucket_view"] = True
         orig_init(self, module, *args, **kwargs)
-        if ours and getattr(self, "gradient_as_bucket_view", False):
+        if ours:
             handle = []
 
             def _first_forward(mod, inputs):
