@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 9
+#define TAMD_ABI_VERSION 10
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -400,6 +400,35 @@ int tamd_attn_bwd(const struct tamd_attn_bwd_params* p, tamd_stream_t stream);
 int tamd_adamw_step(void* p, const void* g, void* m, void* v, int64_t n, double lr, double beta1, double beta2,
                     double eps, double weight_decay, int64_t step, double grad_scale, int dtype, int state_dtype,
                     tamd_stream_t stream);
+
+/* ---- multi-tensor step: global gradient-norm clip + AdamW over a whole parameter set (ABI 10) ----
+ * Replaces, per optimizer step of `Trainer` (trainer.py:2538-2548 `accelerator.clip_grad_norm_(model.parameters(),
+ * args.max_grad_norm)` = torch.nn.utils.clip_grad_norm_, default max_grad_norm 1.0: training_args.py:856; then
+ * `self.optimizer.step()`, trainer.py:1783-1799 torch.optim.AdamW): per-tensor norms + a norm of norms + a scaling pass
+ * over every gradient + one optimizer launch per parameter.
+ *
+ * The parameter set of one (dtype, state_dtype) lives in ONE table of int64 words in DEVICE memory, n tensors:
+ *     [0,n) p pointers | [n,2n) g pointers | [2n,3n) m | [3n,4n) v | [4n,5n) element counts |
+ *     [5n,6n] first chunk of tensor i = sum_{j<i} ceil(numel_j / TAMD_MT_CHUNK); word 6n = total chunks
+ * (6n + 1 words).  tamd_mt_sumsq / tamd_mt_scale read only the g, numel and chunk columns.
+ * One workgroup per chunk; `total_chunks` is word 6n, passed by the host that built the table.  Pointers need no
+ * alignment (a tensor whose pointers are not all 16-byte aligned runs one element per lane). */
+#define TAMD_MT_CHUNK 65536
+/* partials[c] = sum of squares (fp32) of gradient chunk c, c in [0, total_chunks): fixed order, deterministic. */
+int tamd_mt_sumsq(const int64_t* table, int n_tensors, int64_t total_chunks, float* partials, int dtype,
+                  tamd_stream_t stream);
+/* out[0] = norm = sqrt(sum(partials[0..count))) (summed in double), out[1] = clip coefficient
+ * min(1, max_norm / (norm + 1e-6)) -- torch.nn.utils.clip_grad_norm_'s -- or 1 when max_norm <= 0.  Device memory: no
+ * host synchronisation. */
+int tamd_mt_norm_finish(const float* partials, int64_t count, float* out, double max_norm, tamd_stream_t stream);
+/* g *= *coef in place for every tensor of the table (the side effect of clip_grad_norm_; skipped when *coef == 1). */
+int tamd_mt_scale(const int64_t* table, int n_tensors, int64_t total_chunks, const float* coef, int dtype,
+                  tamd_stream_t stream);
+/* tamd_adamw_step on every tensor of the table in one launch; the gradient is scaled by grad_scale * (*grad_scale_dev)
+ * (grad_scale_dev NULL: grad_scale alone) in registers -- the clipped gradient is never written. */
+int tamd_mt_adamw_step(const int64_t* table, int n_tensors, int64_t total_chunks, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, int64_t step, double grad_scale, const float* grad_scale_dev,
+                       int dtype, int state_dtype, tamd_stream_t stream);
 
 #ifdef __cplusplus
 }

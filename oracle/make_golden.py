@@ -209,7 +209,37 @@ def main():
     st = opt.state[w]
     save("adamw_f32", p0=f32(p0), grads=np.stack(grads), params=np.stack(params), exp_avg=f32(st["exp_avg"]),
          exp_avg_sq=f32(st["exp_avg_sq"]), hyper=np.array([3e-3, 0.9, 0.95, 1e-8, 0.1], dtype=np.float64))
+    make_adamw_clip()
+
+
+def make_adamw_clip():
+    """13. What an optimizer step of `Trainer` does to the gradients and the parameters (trainer.py:2538-2548
+    `accelerator.clip_grad_norm_(model.parameters(), args.max_grad_norm)` = torch.nn.utils.clip_grad_norm_, then
+    `optimizer.step()`, trainer.py:1783-1799): 3 steps over three fp32 tensors, max_grad_norm 1.0 -- the first two steps
+    clip (norm > 1), the third does not (its gradients are tiny).  `python oracle/make_golden.py adamw_clip` writes only
+    this file."""
+    torch.manual_seed(13)
+    shapes = [(40, 24), (33,), (7, 5, 3)]
+    ws = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    p0 = [f32(w.data.clone()).ravel() for w in ws]
+    opt = torch.optim.AdamW(ws, lr=3e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, foreach=False, fused=False)
+    grads, params, norms = [], [], []
+    for t in range(3):
+        gs = [torch.randn(s) * (0.5 if t < 2 else 1e-3) for s in shapes]
+        for w, g in zip(ws, gs):
+            w.grad = g.clone()
+        norms.append(float(torch.nn.utils.clip_grad_norm_(ws, 1.0, foreach=False)))
+        opt.step()
+        grads.append(np.concatenate([f32(g).ravel() for g in gs]))
+        params.append(np.concatenate([f32(w.data).ravel() for w in ws]))
+    save("adamw_clip_f32", p0=np.concatenate(p0), sizes=np.array([int(np.prod(s)) for s in shapes], dtype=np.int64),
+         grads=np.stack(grads), params=np.stack(params), norms=np.array(norms, dtype=np.float64),
+         exp_avg=np.concatenate([f32(opt.state[w]["exp_avg"]).ravel() for w in ws]),
+         exp_avg_sq=np.concatenate([f32(opt.state[w]["exp_avg_sq"]).ravel() for w in ws]),
+         hyper=np.array([3e-3, 0.9, 0.95, 1e-8, 0.1, 1.0], dtype=np.float64))
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["adamw_clip"]:
+        sys.exit(make_adamw_clip())
     sys.exit(main())

@@ -231,6 +231,66 @@ def test_kernel_adamw_golden(env):
     assert nrel(st["exp_avg_sq"].cpu().numpy(), g["exp_avg_sq"]) < 5e-7
 
 
+def _split(flat, sizes):
+    out, o = [], 0
+    for k in sizes:
+        out.append(flat[o:o + int(k)])
+        o += int(k)
+    return out
+
+
+def test_oracle_adamw_clip_golden():
+    """torch.nn.utils.clip_grad_norm_(max_norm=1) + torch.optim.AdamW over three tensors for three steps (two clipped, one
+    not) vs the oracle's restatement: the clip coefficient scales the gradient, then the AdamW rule."""
+    g = load("adamw_clip_f32")
+    lr, b1, b2, eps, wd, max_norm = (float(x) for x in g["hyper"])
+    sizes = g["sizes"]
+    p, m, v = g["p0"], np.zeros_like(g["p0"]), np.zeros_like(g["p0"])
+    clipped = []
+    for t in range(3):
+        norm, coef = orc.clip_grad_norm(_split(g["grads"][t], sizes), max_norm)
+        assert abs(float(norm) - g["norms"][t]) < 2e-6 * g["norms"][t], t
+        clipped.append(float(coef) < 1.0)
+        p, m, v = orc.adamw_step(p, g["grads"][t] * coef, m, v, lr, b1, b2, eps, wd, t + 1)
+        assert nrel(p, g["params"][t]) < 5e-7, t
+    assert clipped == [True, True, False]
+    assert nrel(m, g["exp_avg"]) < 5e-7 and nrel(v, g["exp_avg_sq"]) < 5e-7
+
+
+@pytest.mark.parametrize("route", ["fused", "clip_then_step"])
+def test_kernel_adamw_clip_golden(env, route):
+    """The same golden run through the kernels: `fused` = TamdAdamW(max_grad_norm=1) (norm + coefficient in device memory,
+    applied inside the multi-tensor AdamW launch), `clip_then_step` = transformers_amd.optim.clip_grad_norm_ (scales the
+    gradients in place, as the reference does) followed by the plain step."""
+    import transformers_amd
+    from transformers_amd import optim
+
+    g = load("adamw_clip_f32")
+    lr, b1, b2, eps, wd, max_norm = (float(x) for x in g["hyper"])
+    sizes = g["sizes"]
+    ws = [torch.nn.Parameter(torch.from_numpy(x.copy()).to(env.device)) for x in _split(g["p0"], sizes)]
+    opt = transformers_amd.TamdAdamW(ws, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd,
+                                     max_grad_norm=max_norm if route == "fused" else None)
+    for t in range(3):
+        for w, gr in zip(ws, _split(g["grads"][t], sizes)):
+            w.grad = torch.from_numpy(gr.copy()).to(env.device)
+        if route == "fused":
+            opt.step()
+            norm = opt.grad_norm
+            for w, gr in zip(ws, _split(g["grads"][t], sizes)):  # the clipped gradient is never written
+                assert np.array_equal(w.grad.cpu().numpy(), gr)
+        else:
+            norm = optim.clip_grad_norm_(ws, max_norm)
+            opt.step()
+        assert abs(float(norm) - g["norms"][t]) < 2e-6 * g["norms"][t], t
+        got = np.concatenate([w.detach().cpu().numpy().ravel() for w in ws])
+        assert nrel(got, g["params"][t]) < 5e-7, t
+    assert len(opt._tables) == 1  # three tensors, ONE launch
+    m = np.concatenate([opt.state[w]["exp_avg"].cpu().numpy().ravel() for w in ws])
+    v = np.concatenate([opt.state[w]["exp_avg_sq"].cpu().numpy().ravel() for w in ws])
+    assert nrel(m, g["exp_avg"]) < 5e-7 and nrel(v, g["exp_avg_sq"]) < 5e-7
+
+
 def test_oracle_packed_mask_golden():
     """The reference's packed-sequence index finder and its and_masks(causal, packed) mask on restarting position ids,
     against the oracle's restatement; and the two bound arrays the kernels take describe exactly that mask."""

@@ -14,7 +14,7 @@ TAMD_BF16, TAMD_F16, TAMD_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 GEMM_A_KM, GEMM_B_KN = 1, 2
 EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_BIAS_ACT, EPI_ACCUM = 0, 1, 2, 3, 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 P = c_void_p
 I64 = c_int64
@@ -70,6 +70,11 @@ SIGNATURES = {
     "tamd_add": (c_int, [P, P, P, I64, c_int, P]),
     "tamd_adamw_step": (c_int, [P, P, P, P, I64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                 ctypes.c_double, I64, ctypes.c_double, c_int, c_int, P]),
+    "tamd_mt_sumsq": (c_int, [P, c_int, I64, P, c_int, P]),
+    "tamd_mt_norm_finish": (c_int, [P, I64, P, ctypes.c_double, P]),
+    "tamd_mt_scale": (c_int, [P, c_int, I64, P, c_int, P]),
+    "tamd_mt_adamw_step": (c_int, [P, c_int, I64, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                   ctypes.c_double, I64, ctypes.c_double, P, c_int, c_int, P]),
     "tamd_colsum_workspace_bytes": (c_size_t, [I64, I64]),
     "tamd_colsum": (c_int, [P, P, P, c_size_t, I64, I64, I64, c_int, P]),
     "tamd_transpose": (c_int, [P, P, I64, I64, I64, I64, c_int, P]),

@@ -41,7 +41,7 @@ using OptTensor = std::optional<at::Tensor>;
   X(tamd_layernorm_fwd) X(tamd_layernorm_bwd) X(tamd_layernorm_dropout_fwd) X(tamd_layernorm_dropout_bwd)             \
   X(tamd_rope_inplace) X(tamd_embedding_fwd) X(tamd_embedding_bwd_workspace_bytes) X(tamd_embedding_bwd)              \
   X(tamd_bert_embeddings_fwd) X(tamd_swiglu_fwd) X(tamd_swiglu_bwd) X(tamd_bias_act_fwd) X(tamd_bias_act_bwd)         \
-  X(tamd_add) X(tamd_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
+  X(tamd_add) X(tamd_adamw_step) X(tamd_mt_sumsq) X(tamd_mt_norm_finish) X(tamd_mt_scale) X(tamd_mt_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
   X(tamd_cross_entropy_fwd) X(tamd_cross_entropy_bwd) X(tamd_gemm) X(tamd_gemm_workspace_bytes) X(tamd_gemm_ws)       \
   X(tamd_gemm_swiglu) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_gemm_group_workspace_bytes) X(tamd_gemm_group) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
   X(tamd_attn_decode_workspace_bytes) X(tamd_attn_decode)
@@ -425,6 +425,52 @@ void k_adamw_step_(const Tensor& pp, const Tensor& g, const Tensor& m, const Ten
   check(api().tamd_adamw_step(mptr(pp), ptr(g), mptr(m), mptr(v), pp.numel(), lr, beta1, beta2, eps, weight_decay, step,
                               grad_scale, code_of(pp), code_of(m), L.stream),
         "tamd_adamw_step");
+}
+
+// ---- multi-tensor step (include/tamd.h "multi-tensor step"): `table` is the int64 device table the caller built
+// (transformers_amd/optim.py MtTable); the tensors it points at are the caller's to keep alive.
+void check_mt_table(const Tensor& table, int64_t n_tensors, int64_t total_chunks) {
+  TORCH_CHECK(table.scalar_type() == at::kLong && table.is_contiguous() && table.numel() >= 6 * n_tensors + 1,
+              "tamd: multi-tensor table must be a contiguous int64 tensor of 6 * n_tensors + 1 words");
+  TORCH_CHECK(n_tensors >= 0 && total_chunks >= 0 && n_tensors < (1 << 30), "tamd: multi-tensor table sizes");
+}
+void k_mt_sumsq(const Tensor& table, int64_t n_tensors, int64_t total_chunks, const Tensor& partials, int64_t dtype) {
+  check_mt_table(table, n_tensors, total_chunks);
+  TORCH_CHECK(partials.scalar_type() == at::kFloat && partials.is_contiguous() && partials.numel() >= total_chunks,
+              "tamd: mt_sumsq needs `total_chunks` contiguous fp32 partials");
+  Launch L({&table, &partials});
+  check(api().tamd_mt_sumsq((const int64_t*)ptr(table), (int)n_tensors, total_chunks, (float*)mptr(partials), (int)dtype,
+                            L.stream),
+        "tamd_mt_sumsq");
+}
+void k_mt_norm_finish(const Tensor& partials, const Tensor& out, double max_norm) {
+  TORCH_CHECK(partials.scalar_type() == at::kFloat && partials.is_contiguous() && out.scalar_type() == at::kFloat &&
+                  out.is_contiguous() && out.numel() >= 2,
+              "tamd: mt_norm_finish needs contiguous fp32 partials and an fp32 out[2]");
+  Launch L({&partials, &out});
+  check(api().tamd_mt_norm_finish((const float*)ptr(partials), partials.numel(), (float*)mptr(out), max_norm, L.stream),
+        "tamd_mt_norm_finish");
+}
+void k_mt_scale_(const Tensor& table, int64_t n_tensors, int64_t total_chunks, const Tensor& coef, int64_t dtype) {
+  check_mt_table(table, n_tensors, total_chunks);
+  TORCH_CHECK(coef.scalar_type() == at::kFloat && coef.numel() >= 1, "tamd: mt_scale_ needs an fp32 coefficient in device memory");
+  Launch L({&table, &coef});
+  check(api().tamd_mt_scale((const int64_t*)ptr(table), (int)n_tensors, total_chunks, (const float*)ptr(coef), (int)dtype,
+                            L.stream),
+        "tamd_mt_scale");
+}
+void k_mt_adamw_step_(const Tensor& table, int64_t n_tensors, int64_t total_chunks, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int64_t step, double grad_scale, const OptTensor& grad_scale_dev,
+                      int64_t dtype, int64_t state_dtype) {
+  check_mt_table(table, n_tensors, total_chunks);
+  if (grad_scale_dev.has_value() && grad_scale_dev->defined())
+    TORCH_CHECK(grad_scale_dev->scalar_type() == at::kFloat && grad_scale_dev->numel() >= 1,
+                "tamd: mt_adamw_step_ grad_scale_dev must be an fp32 scalar in device memory");
+  Launch L({&table, p(grad_scale_dev)});
+  check(api().tamd_mt_adamw_step((const int64_t*)ptr(table), (int)n_tensors, total_chunks, lr, beta1, beta2, eps,
+                                 weight_decay, step, grad_scale, (const float*)ptr(grad_scale_dev), (int)dtype,
+                                 (int)state_dtype, L.stream),
+        "tamd_mt_adamw_step");
 }
 
 Tensor k_colsum(const Tensor& x2d) {
@@ -1402,6 +1448,11 @@ TORCH_LIBRARY(tamd, m) {
   m.def("cross_entropy_bwd(Tensor logits2d, Tensor labels, Tensor lse, Tensor gscale, int ignore_index=-100) -> Tensor");
   m.def("adamw_step_(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, "
         "float weight_decay, int step, float grad_scale=1.0) -> ()");
+  m.def("mt_sumsq(Tensor table, int n_tensors, int total_chunks, Tensor(a!) partials, int dtype) -> ()");
+  m.def("mt_norm_finish(Tensor partials, Tensor(a!) out, float max_norm) -> ()");
+  m.def("mt_scale_(Tensor table, int n_tensors, int total_chunks, Tensor coef, int dtype) -> ()");
+  m.def("mt_adamw_step_(Tensor table, int n_tensors, int total_chunks, float lr, float beta1, float beta2, float eps, "
+        "float weight_decay, int step, float grad_scale, Tensor? grad_scale_dev, int dtype, int state_dtype) -> ()");
   m.def("gemm(Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, Tensor? residual=None, "
         "int epilogue=0, int act=0, int sched=0) -> Tensor");
   m.def("gemm_out(Tensor(a!) out, Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, "
@@ -1491,6 +1542,10 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("cross_entropy_fwd", &k_cross_entropy_fwd);                 \
   m.impl("cross_entropy_bwd", &op_cross_entropy_bwd);                \
   m.impl("adamw_step_", &op_adamw_step_);                            \
+  m.impl("mt_sumsq", &k_mt_sumsq);                                   \
+  m.impl("mt_norm_finish", &k_mt_norm_finish);                       \
+  m.impl("mt_scale_", &k_mt_scale_);                                 \
+  m.impl("mt_adamw_step_", &k_mt_adamw_step_);                       \
   m.impl("gemm", &op_gemm);                                          \
   m.impl("gemm_out", &op_gemm_out);                                  \
   m.impl("gemm_swiglu", &op_gemm_swiglu);                            \

@@ -369,6 +369,11 @@ register("cross_entropy_fwd", lambda logits2d, labels, ignore_index=-100: (_f32(
 register("cross_entropy_bwd", lambda logits2d, labels, lse, gscale, ignore_index=-100: torch.empty_strided(
     logits2d.shape, (logits2d.stride(0), 1), dtype=logits2d.dtype, device=logits2d.device))
 register("adamw_step_", lambda p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0: None)
+register("mt_sumsq", lambda table, n_tensors, total_chunks, partials, dtype: None)
+register("mt_norm_finish", lambda partials, out, max_norm: None)
+register("mt_scale_", lambda table, n_tensors, total_chunks, coef, dtype: None)
+register("mt_adamw_step_", lambda table, n_tensors, total_chunks, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                                  grad_scale_dev, dtype, state_dtype: None)
 
 
 def _gemm_shape(a, b, a_km, b_kn):
