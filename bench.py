@@ -20,6 +20,14 @@ and gradients are all-reduced over RCCL/xGMI, overlapped with the backward.
 `--fused-lm-head-loss` runs the Llama step with `accelerate(model, fused_lm_head_loss=True)` (SURVEY section 8 row f1:
 lm_head GEMM + loss chunk by chunk, no [tokens, vocab] logits): same FLOPs, same loss, ~17 GB less memory.
 
+`--train-step` (Llama configurations) times the whole optimizer step of `Trainer` instead of fwd+bwd alone: forward, backward,
+global gradient-norm clip (max_grad_norm 1.0, training_args.py:856) and AdamW (`transformers_amd.TamdAdamW(max_grad_norm=1.0)`:
+SURVEY section 8 row f2; `--optimizer torch` = torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW(fused=True) for the A/B).
+
+The default single-GPU headline run also reports, under `secondary`, the other single-GPU configurations of BASELINE.json and
+the training step -- each in its OWN process after the headline's timed region (this same script with `--config bert-base`,
+`--config llava`, `--train-step`), so that nothing they do can take the headline number down; `--no-secondary` skips them.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel family (the MFMA GEMM, csrc/gemm.hip): algorithmic FLOPs of its launches
                   in the timed region / their summed HIP-event durations, against the 2.5 PFLOP/s dense bf16 peak;
@@ -102,7 +110,8 @@ def gemm_traffic():
                 t = json.load(f)
             return {"unit": "bytes/launch", "hbm_bytes": t["hbm_bytes_per_launch"],
                     "fetch_bytes": t["fetch_bytes_per_launch"], "write_bytes": t["write_bytes_per_launch"],
-                    "source": f"profiles/{name}"}
+                    "source": f"profiles/{name}",
+                    "from": "committed rocprofv3 PMC profile of this command (an earlier run), NOT measured by this run"}
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -231,7 +240,7 @@ def layer_forward_probe(model, dev, batch, seq, iters=10, warm=3):
             "iters": iters}
 
 
-def cpu_baseline(model_cfg, seq, layers, threads=None, iters=3):
+def cpu_baseline(model_cfg, seq, layers, threads=None, iters=1):
     """Reference eager path on the host cores: ONE decoder layer at (1, seq, hidden), bf16, fwd+bwd, averaged."""
     import torch
     from transformers import LlamaConfig
@@ -318,6 +327,81 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def ddp_verify(net, model, fwd, dev, world):
+    """Reduced gradients of one step with the dW GEMMs writing into DDP's bucket views (transformers_amd/ddp.py) against one step
+    with torch's own copies into the buckets, same batch, same weights: norm-relative error and bit identity, worst parameter,
+    worst rank.  The same code on every rank (its collective is symmetric); any exception becomes `error` (and counts as "not
+    verified": the caller then times the run on torch's copies).  Leaves the gradients None."""
+    import torch
+    import torch.distributed as dist
+
+    from transformers_amd import ddp as tamd_ddp
+
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    params = [p for p in model.parameters() if p.requires_grad]
+    flag = torch.zeros(3, device=dev, dtype=torch.float64)  # max rel err, any bit differs, any rank failed
+    out = {}
+    try:
+        def one_step():
+            fwd(net).loss.backward()
+
+        before = dict(tamd_ddp.STATS)
+        model.zero_grad(set_to_none=True)
+        one_step()
+        sync()
+        zc_layers = tamd_ddp.STATS["zero_copy_layers"] - before["zero_copy_layers"]
+        # (a low-memory copy: the gradients are 16 GB for the 8B model, kept once)
+        kept = [p.grad.detach().clone() for p in params]
+        model.zero_grad(set_to_none=True)
+        was = tamd_ddp.set_enabled(False)
+        try:
+            one_step()
+            sync()
+        finally:
+            tamd_ddp.set_enabled(was)
+        for p, g0 in zip(params, kept):
+            g1 = p.grad.detach()
+            den = g1.double().norm()
+            err = (g0.double() - g1.double()).norm() / den.clamp_min(1e-30)
+            flag[0] = torch.maximum(flag[0], torch.nan_to_num(err, nan=float("inf")))
+            flag[1] = torch.maximum(flag[1], (g0 != g1).any().double())
+        del kept
+        out.update(parameters=len(params), zero_copy_layers_in_checked_step=zc_layers, ranks=world,
+                   what="reduced gradients of one step with the dW GEMMs writing into the bucket views vs one step with "
+                        "torch's copies into the buckets, same batch; worst parameter, worst rank")
+    except Exception as e:
+        flag[2] = 1.0
+        out["error"] = repr(e)
+    try:
+        model.zero_grad(set_to_none=True)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        ok = flag[2].item() == 0.0
+        # verified: no rank failed and the two hand-overs agree to reduction-order noise (a wrong view or a missed contribution
+        # is an O(1) error; `bit_identical` is reported beside it -- it holds on gloo and on RCCL at world size 1)
+        out.update(max_rel_err=flag[0].item(), bit_identical=bool(ok and flag[1].item() == 0.0),
+                   verified=bool(ok and flag[0].item() <= 1e-3))
+        if not ok and "error" not in out:
+            out["error"] = "the check failed on another rank"
+    except Exception as e:  # (the collective itself failed: nothing can be said -- not verified)
+        out.update(bit_identical=False, verified=False, error=out.get("error", repr(e)))
+    return out
+
+
+def ddp_verify_or_fall_back(args, net, model, fwd, dev, world):
+    """`ddp_verify`, and what follows from it: a hand-over that did not verify (on any rank: the verdict is all-reduced) is
+    switched off on every rank -- `args.no_ddp_zero_copy` follows, so the steps zero the gradients in place -- and the caller
+    times the run on torch's copies.  The first multi-rank run must not report a throughput measured on wrong gradients."""
+    from transformers_amd import ddp as tamd_ddp
+
+    v = ddp_verify(net, model, fwd, dev, world)
+    if not v.get("verified", False):
+        tamd_ddp.set_enabled(False)
+        args.no_ddp_zero_copy = True
+        v["disabled_zero_copy"] = True
+    return v
+
+
 def ddp_report(args, net, model, fwd, dev, world, ddp_ms):
     """What an N-GPU line says about the data-parallel step beyond its throughput.  Runs AFTER the timed region,
     the same code on every rank (its two collectives are symmetric); every leg is fenced so that a failure becomes an `error`
@@ -326,8 +410,8 @@ def ddp_report(args, net, model, fwd, dev, world, ddp_ms):
       compute_only_ms       -- `--steps`-independent: 3 untimed steps under `net.no_sync()` (same model, same batch, no all-reduce);
       exposed_allreduce_ms  -- ms_per_step - compute_only_ms (max over ranks): the part of the collective the backward did not hide;
       busbw_GBps            -- 2 (N-1)/N x gradient_bytes / exposed_allreduce_ms: the ring all-reduce's bus bandwidth IF the exposed
-                               time were the whole collective (a lower bound of the real one: most of it overlaps);
-      verify (--verify-ddp) -- reduced gradients, zero-copy hand-over vs torch's copies, on one fixed batch."""
+                               time were the whole collective (a lower bound of the real one: most of it overlaps).
+    (The zero-copy hand-over is verified BEFORE the timed region: `ddp_verify()`, `ddp_verify` in the line.)"""
     import torch
     import torch.distributed as dist
 
@@ -348,41 +432,6 @@ def ddp_report(args, net, model, fwd, dev, world, ddp_ms):
             o = fwd(net)
             o.loss.backward()
 
-    if args.verify_ddp:
-        try:
-            if args.no_ddp_zero_copy:
-                raise RuntimeError("--verify-ddp compares against the zero-copy hand-over: drop --no-ddp-zero-copy")
-            before = dict(tamd_ddp.STATS)
-            model.zero_grad(set_to_none=True)
-            one_step()
-            sync()
-            zc_layers = tamd_ddp.STATS["zero_copy_layers"] - before["zero_copy_layers"]
-            # (per-parameter norms and a low-memory copy: the gradients are 16 GB for the 8B model, kept once)
-            kept = [p.grad.detach().clone() for p in params]
-            model.zero_grad(set_to_none=True)
-            was = tamd_ddp.set_enabled(False)
-            try:
-                one_step()
-                sync()
-            finally:
-                tamd_ddp.set_enabled(was)
-            worst = torch.zeros(2, device=dev, dtype=torch.float64)
-            for p, g0 in zip(params, kept):
-                g1 = p.grad.detach()
-                den = g1.double().norm()
-                err = (g0.double() - g1.double()).norm() / den.clamp_min(1e-30)
-                worst[0] = torch.maximum(worst[0], err)
-                worst[1] = torch.maximum(worst[1], (g0 != g1).any().double())
-            del kept
-            if world > 1:
-                dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-            out["verify"] = dict(max_rel_err=worst[0].item(), bit_identical=worst[1].item() == 0.0, parameters=len(params),
-                                 zero_copy_layers_in_checked_step=zc_layers, ranks=world,
-                                 what="reduced gradients of one step with the dW GEMMs writing into the bucket views vs one "
-                                      "step with torch's copies into the buckets, same batch; worst parameter, worst rank")
-            model.zero_grad(set_to_none=True)
-        except Exception as e:  # (symmetric on every rank: same code, same state)
-            out["verify"] = {"error": repr(e)}
     if not args.no_ddp_breakdown:
         try:
             model.zero_grad(set_to_none=True)
@@ -405,6 +454,41 @@ def ddp_report(args, net, model, fwd, dev, world, ddp_ms):
                        busbw_GBps=(2.0 * (world - 1) / world * gbytes / (exposed * 1e-3) / 1e9) if (world > 1 and exposed > 0) else None)
         except Exception as e:
             out["breakdown_error"] = repr(e)
+    return out
+
+
+def secondary_legs(timeout_s=300):
+    """BASELINE.json configs 2 and 5 and one end-to-end training step, each as a child process running this script (the
+    parent has released its GPU memory): a crash, a hang (timeout) or an out-of-memory in a leg becomes an `error` entry."""
+    legs = {"bert_base": ["--config", "bert-base", "--steps", "20", "--warmup", "5"],
+            "llava": ["--config", "llava", "--steps", "20", "--warmup", "5"],
+            "train_step": ["--config", "llama3-8b", "--train-step", "--steps", "3", "--warmup", "2"]}
+    out = {}
+    for name, extra in legs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--no-cpu-baseline",
+                                "--no-secondary", *extra], capture_output=True, text=True, timeout=timeout_s)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+                continue
+            d = json.loads(lines[-1])
+            rf = d.get("roofline") or {}
+            leg = {"workload": d["config"]["workload"], "metric": d["metric"], "ms_per_step": d["ms_per_step"],
+                   "tokens_per_s": d["value"], "mfu_vs_2500TF": d["mfu_vs_2500TF"], "steps": d["steps"],
+                   "warmup": d["warmup"], "fallback_calls": d["fallback_calls"], "loss": d["loss"],
+                   "max_memory_gb": d["max_memory_gb"],
+                   "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step",
+                                                        "gemm_share_of_step_time", "measured_on")} if rf else None}
+            if "train_step" in d:
+                leg.update(d["train_step"])
+            out[name] = leg
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"timeout after {timeout_s} s"}
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+        out[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
     return out
 
 
@@ -453,9 +537,17 @@ def main():
                     help="under DDP: leave the gradient hand-over to torch (copy into the bucket views) instead of writing the "
                          "weight-gradient GEMMs straight into them (transformers_amd/ddp.py)")
     ap.add_argument("--verify-ddp", action="store_true",
-                    help="under DDP: two extra untimed steps on one fixed batch after the timed region -- the reduced gradients "
+                    help="under DDP: two extra untimed steps on one fixed batch BEFORE the timed region -- the reduced gradients "
                          "of a step with the zero-copy hand-over against a step with torch's own copies into the buckets, "
-                         "norm-relative per parameter, worst over parameters and ranks -> `ddp_verify` in the line")
+                         "norm-relative per parameter, worst over parameters and ranks -> `ddp_verify` in the line.  Always on "
+                         "with more than one rank; not bit-identical = the run is timed on torch's copies and says so")
+    ap.add_argument("--train-step", action="store_true",
+                    help="Llama configurations: time forward + backward + gradient-norm clip (1.0) + AdamW instead of fwd+bwd")
+    ap.add_argument("--optimizer", choices=("tamd", "torch"), default="tamd",
+                    help="--train-step: tamd = TamdAdamW(max_grad_norm=1.0) (one norm pass, clip folded into one multi-tensor "
+                         "AdamW launch); torch = torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW(fused=True)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="single-GPU llama3-8b headline run: skip the `secondary` legs (bert-base, llava, train step)")
     ap.add_argument("--no-ddp-breakdown", action="store_true",
                     help="under DDP: skip the untimed no_sync() steps after the timed region that price the exposed all-reduce "
                          "(`ddp.exposed_allreduce_ms`, `ddp.busbw_GBps`)")
@@ -568,12 +660,35 @@ def main():
                 args.no_ddp_zero_copy = True
                 zero_copy_error = repr(e)
 
+    opt = None
+    opt_events = []
+    if args.train_step:
+        if kind != "llama" or args.hip_graph:
+            raise SystemExit("--train-step: Llama configurations, no --hip-graph")
+        if args.optimizer == "tamd":
+            opt = transformers_amd.TamdAdamW(model.parameters(), lr=1e-5, weight_decay=0.01, max_grad_norm=1.0)
+        else:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.01, fused=True)
+        metric = metric.replace("fwd+bwd tokens/sec", "training-step (fwd+bwd+clip+AdamW) tokens/sec")
+        workload = workload.replace("fwd+bwd incl.", "fwd+bwd + grad-norm clip 1.0 + AdamW (bf16 moments) incl.")
+
+    def optimizer_step():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if args.optimizer == "torch":
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        e1.record()
+        opt_events.append((e0, e1))
+
     def step():
         if not backward:
             with torch.no_grad():
                 return fwd(net).logits[0, -1, 0].float()
         out = fwd(net)
         out.loss.backward()
+        if opt is not None:
+            optimizer_step()
         # Between steps.  Without DDP: what Trainer does (optimizer.zero_grad(), set_to_none=True).  Under DDP with
         # gradient_as_bucket_view the gradients are views of the all-reduce buckets: dropping them makes the next backward
         # hand DDP fresh tensors that it copies into the buckets and re-points, so they are zeroed in place instead --
@@ -595,6 +710,16 @@ def main():
     for _ in range(args.warmup):
         loss = step()
     barrier()
+    ddp_preverify = None
+    if ddp and backward and not args.no_ddp_zero_copy and (world > 1 or args.verify_ddp):
+        # BEFORE anything is timed: the reduced gradients of one step with the zero-copy hand-over against one step with torch's
+        # own copies into the buckets, same batch.  Not bit-identical (or the check itself fails): the hand-over is switched off
+        # on every rank -- the verdict is all-reduced -- and the run is timed on torch's copies; the line says so.
+        ddp_preverify = ddp_verify_or_fall_back(args, net, model, fwd, dev, world)
+        if ddp_preverify.get("disabled_zero_copy"):
+            for _ in range(2):  # (warm the ordinary hand-over: its first step re-points the gradients at the buckets)
+                loss = step()
+        barrier()
     run = step
     if args.hip_graph:
         # one step as ONE HIP graph.  Forward-only configurations: the host side is what bounds them.  Training steps
@@ -697,9 +822,20 @@ def main():
                 line["ddp_zero_copy"]["error"] = zero_copy_error
             line["ddp"] = dict(ms_per_step_min_rank=dt_min / args.steps * 1e3, ms_per_step_max_rank=dt_max / args.steps * 1e3,
                                bucket_mb=args.bucket_mb, **(ddp_extra or {}))
-            if ddp_extra and "verify" in ddp_extra:
-                line["ddp_verify"] = line["ddp"].pop("verify")
-        if kind == "llama" and world == 1 and not args.hip_graph:
+            if ddp_preverify is not None:
+                line["ddp_verify"] = ddp_preverify
+                line["ddp_zero_copy"]["disabled_by_verify"] = bool(ddp_preverify.get("disabled_zero_copy", False))
+        if opt is not None:
+            torch.cuda.synchronize()
+            oms = [a.elapsed_time(b) for a, b in opt_events[-args.steps:]]
+            line["train_step"] = dict(optimizer=("TamdAdamW(max_grad_norm=1.0): mt_sumsq + mt_norm_finish + one mt_adamw launch per "
+                                                 "dtype, clip coefficient in device memory" if args.optimizer == "tamd" else
+                                                 "torch.nn.utils.clip_grad_norm_(1.0) + torch.optim.AdamW(fused=True)"),
+                                      optimizer_ms=sum(oms) / max(len(oms), 1),
+                                      optimizer_hbm_bytes=(1 + 7) * sum(p.numel() * p.element_size() for p in model.parameters()),
+                                      grad_norm=(float(opt.grad_norm) if getattr(opt, "grad_norm", None) is not None else None))
+            line["train_step"]["optimizer_TBps"] = line["train_step"]["optimizer_hbm_bytes"] / (line["train_step"]["optimizer_ms"] * 1e-3) / 1e12
+        if kind == "llama" and world == 1 and not args.hip_graph and not args.train_step:
             # the north star's own number: one decoder layer's forward as a fraction of the MFMA peak (outside the timed region)
             try:
                 fb = dict(transformers_amd.fallback_calls())
@@ -720,6 +856,19 @@ def main():
                                         if kind == "llama" else cpu_baseline_bert(batch, seq))
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 line["cpu_baseline"] = {"error": repr(e)}
+        if (world == 1 and args.config == "llama3-8b" and not args.no_secondary and not args.train_step and not args.hip_graph
+                and not ddp):
+            # BASELINE configs 2 and 5 + the end-to-end training step, each in its own process (this one frees its memory first)
+            try:
+                import gc
+
+                del net, model, fwd, ids, loss
+                run = step = None
+                gc.collect()
+                torch.cuda.empty_cache()
+                line["secondary"] = secondary_legs()
+            except Exception as e:
+                line["secondary"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if ddp:
         torch.distributed.destroy_process_group()

@@ -82,14 +82,19 @@ def _worker_zero_copy(rank, world, port, out_dir, kind):
             per_step.append(dict(tddp.STATS))
         grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
         aliased = all(tddp._VIEWS[id(p)][1].data_ptr() == p.grad.data_ptr() for p in model.parameters() if id(p) in tddp._VIEWS)
-        # what `bench.py --gpus N --verify-ddp` runs after its timed region (the same function, on every rank): the reduced
-        # gradients of a zero-copy step against a step with torch's copies, then the no_sync() steps that price the all-reduce
+        # what `bench.py --gpus N` runs around its timed region (the same functions, on every rank): BEFORE it, the reduced
+        # gradients of a zero-copy step against a step with torch's copies (and the fall-back if they differ); after it, the
+        # no_sync() steps that price the all-reduce
         import argparse
 
         import bench
 
         a = argparse.Namespace(verify_ddp=True, no_ddp_breakdown=False, no_ddp_zero_copy=False, steps=3, warmup=0)
-        report = bench.ddp_report(a, net, model, lambda n: n(**_batch(cfg, rank, kind)), torch.device("cpu"), world, 1e9)
+        fwd = lambda n: n(**_batch(cfg, rank, kind))  # noqa: E731
+        verify = bench.ddp_verify_or_fall_back(a, net, model, fwd, torch.device("cpu"), world)
+        assert a.no_ddp_zero_copy is False and tddp._ENABLED
+        report = bench.ddp_report(a, net, model, fwd, torch.device("cpu"), world, 1e9)
+        report["verify"] = verify
     torch.save({"grads": grads, "stats": per_step, "aliased": aliased, "loss": out.loss.item(), "report": report},
                f"{out_dir}/rank{rank}.pt")
     dist.barrier()
@@ -174,6 +179,7 @@ def test_ddp_zero_copy_gradients_world2_gloo(tmp_path, kind):
         assert "error" not in rep["verify"] and "breakdown_error" not in rep, rep
         assert rep["verify"]["zero_copy_layers_in_checked_step"] == 2 and rep["verify"]["ranks"] == world
         assert rep["verify"]["bit_identical"] and rep["verify"]["max_rel_err"] == 0.0, rep["verify"]
+        assert rep["verify"]["verified"] and "disabled_zero_copy" not in rep["verify"]
         assert rep["compute_only_ms"] > 0 and rep["busbw_GBps"] is not None and rep["buckets_per_step"] >= 1
     assert r[0]["report"]["verify"] == r[1]["report"]["verify"]
     for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
@@ -192,6 +198,98 @@ def test_ddp_zero_copy_gradients_world2_gloo(tmp_path, kind):
         want = (per_rank[0][n] + per_rank[1][n]) / 2
         err = (gd - want).norm() / want.norm().clamp_min(1e-12)
         assert err < 1e-2, (n, err.item())  # bf16 bucket arithmetic
+
+
+def _worker_corrupted_view(rank, world, port, out_dir):
+    """A deliberately wrong registry on ONE rank: the noted bucket views of the two decoder layers' down_proj weights are
+    swapped, so layer 1 writes its dW into layer 0's slot and layer 0 into layer 1's (DDP then copies what it finds: layer 1's
+    gradient ends up being layer 0's).  `bench.ddp_verify_or_fall_back` must see it on BOTH ranks, switch the hand-over off,
+    and the next steps must reduce to the right gradients again."""
+    for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPEMU_THREADS="2")
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+
+    import bench
+    import transformers_amd
+    from emu_backend import emu_backend
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from transformers_amd import ddp as tddp
+
+    kind = "llama-tiles"
+    with emu_backend():
+        model, cfg = _build_model(kind)
+        transformers_amd.accelerate(model)
+        net = DDP(model, bucket_cap_mb=1, gradient_as_bucket_view=True, broadcast_buffers=False,
+                  find_unused_parameters=False, static_graph=True)
+        tddp.reset()
+        tddp.enable_zero_copy(net)
+        fwd = lambda n: n(**_batch(cfg, rank, kind))  # noqa: E731
+        for _ in range(3):  # registry filled, buckets rebuilt, zero-copy running
+            model.zero_grad(set_to_none=True)
+            fwd(net).loss.backward()
+        assert tddp.STATS["zero_copy_layers"] > 0
+        note = tddp._note_views
+        if rank == 1:
+            p0, p1 = (model.model.layers[i].mlp.down_proj.weight for i in (0, 1))
+
+            def corrupt(bucket):  # (the hook re-notes the views at every reduction: keep them swapped)
+                note(bucket)
+                if id(p0) in tddp._VIEWS and id(p1) in tddp._VIEWS:
+                    (r0, v0), (r1, v1) = tddp._VIEWS[id(p0)], tddp._VIEWS[id(p1)]
+                    if v0.data_ptr() < v1.data_ptr():
+                        tddp._VIEWS[id(p0)], tddp._VIEWS[id(p1)] = (r0, v1), (r1, v0)
+
+            tddp._note_views = corrupt
+            (r0, v0), (r1, v1) = tddp._VIEWS[id(p0)], tddp._VIEWS[id(p1)]
+            tddp._VIEWS[id(p0)], tddp._VIEWS[id(p1)] = (r0, v1), (r1, v0)
+        a = argparse.Namespace(verify_ddp=True, no_ddp_breakdown=True, no_ddp_zero_copy=False, steps=1, warmup=0)
+        verify = bench.ddp_verify_or_fall_back(a, net, model, fwd, torch.device("cpu"), world)
+        state = dict(no_zero_copy=a.no_ddp_zero_copy, enabled=tddp._ENABLED)
+        before = tddp.STATS["zero_copy_layers"]
+        for _ in range(2):  # what bench.py then times: torch's copies (gradients zeroed in place: `--ddp-grads zero`)
+            model.zero_grad(set_to_none=False)
+            fwd(net).loss.backward()
+        grads = {n: p.grad.detach().float().clone() for n, p in model.named_parameters()}
+        state["zero_copy_layers_after_fallback"] = tddp.STATS["zero_copy_layers"] - before
+        tddp._note_views = note
+        tddp.set_enabled(True)
+    torch.save({"verify": verify, "state": state, "grads": grads}, f"{out_dir}/rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_ddp_corrupted_view_falls_back_world2_gloo(tmp_path):
+    """the first multi-rank run must not report a throughput measured on wrong gradients."""
+    world = 2
+    mp.spawn(_worker_corrupted_view, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"rank{i}.pt") for i in range(world)]
+    for i in range(world):  # both ranks reached the same verdict, although only rank 1's registry was wrong
+        v = r[i]["verify"]
+        assert v["verified"] is False and v["bit_identical"] is False and v["disabled_zero_copy"] is True, v
+        assert v["max_rel_err"] > 0.1, v
+        assert r[i]["state"] == dict(no_zero_copy=True, enabled=False, zero_copy_layers_after_fallback=0), r[i]["state"]
+    for n in r[0]["grads"]:
+        assert torch.equal(r[0]["grads"][n], r[1]["grads"][n]), n
+    for p in (ROOT, ROOT / "tests", ROOT / "tests" / "hipemu"):
+        sys.path.insert(0, str(p))
+    import transformers_amd
+    from emu_backend import emu_backend
+
+    per_rank = []
+    with emu_backend():
+        for rank in range(world):
+            model, cfg = _build_model("llama-tiles")
+            transformers_amd.accelerate(model)
+            model(**_batch(cfg, rank, "llama-tiles")).loss.backward()
+            per_rank.append({n: p.grad.detach().float() for n, p in model.named_parameters()})
+    for n, gd in r[0]["grads"].items():
+        want = (per_rank[0][n] + per_rank[1][n]) / 2
+        err = (gd - want).norm() / want.norm().clamp_min(1e-12)
+        assert err < 1e-2, (n, err.item())
 
 
 def _run(cmd, timeout=900):

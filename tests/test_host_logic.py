@@ -201,6 +201,20 @@ def test_fused_layer_paths_respect_accelerate_wrappers():
     layer.__dict__.pop("_tamd_placement")
     assert not _placement_ok(layer, cpu, *probe)
     del layer.mlp.down_proj._hf_hook
+    # a multi-GPU `device_map="auto"` puts a plain execution-device AlignDevicesHook on EVERY submodule, also of
+    # layers that sit wholly on one device -- only hooks that offload or execute elsewhere send the layer to the reference path
+    from accelerate.hooks import AlignDevicesHook, SequentialHook
+
+    for hook, want in ((AlignDevicesHook(execution_device="cpu", io_same_device=False), True),
+                       (AlignDevicesHook(execution_device="cpu", offload=True), False),
+                       (AlignDevicesHook(execution_device="meta"), False),
+                       (SequentialHook(AlignDevicesHook(execution_device="cpu"), AlignDevicesHook(offload=True,
+                                                                                                   execution_device="cpu")), False)):
+        layer.mlp.down_proj._hf_hook = hook
+        layer.__dict__.pop("_tamd_placement")
+        assert _placement_ok(layer, cpu, *probe) is want, hook
+    del layer.mlp.down_proj._hf_hook
+    layer.__dict__.pop("_tamd_placement")
     # offload replaces the parameter object (meta) -- that alone invalidates the cached verdict
     layer.mlp.down_proj.weight = torch.nn.Parameter(torch.empty_like(layer.mlp.down_proj.weight, device="meta"))
     probe = (layer.self_attn.q_proj.weight, layer.mlp.down_proj.weight)
@@ -220,6 +234,7 @@ def test_weight_gradient_cut_packs_the_dispatch_rounds():
     assert _native.dw_cut(128256, 4096, t) == (0, 126976)    # 31 rounds | 80 tiles
     for m, n in ((28672, 4096), (4096, 4096), (2048, 4096), (4096, 11008), (2304, 768)):
         assert _native.dw_cut(m, n, t)[0] == -1, (m, n)      # whole rounds, at most one round, or no cut of <= half a round
+    assert _native.dw_cut(6144, 4096, t, cus=304) == (0, 4864)  # (a round is the DEVICE's CU count -- MI300X: 304 tiles | 80)
     assert _native.dw_cut(6144, 4096, 1000)[0] == -1         # ragged token counts (the ping-pong kernel): untouched
     assert _native.dw_cut(6100, 4096, t)[0] == -1            # ragged outputs: untouched
     for m, n in ((6144, 4096), (4096, 14336), (128256, 4096)):

@@ -576,6 +576,25 @@ def test_attention_copies_views_the_kernels_cannot_address(env):
     g1 = torch.autograd.grad(o1, (q, v), do)
     g2 = torch.autograd.grad(o2, (q, v), do)
     assert all(torch.equal(a, b_) for a, b_ in zip(g1, g2))
+    # a K / V expanded over HEADS (MQA written as `k.expand(b, s, H, d)`) or over the BATCH passes every stride
+    # check but overlaps itself -- the backward would allocate dK with those strides and every head / batch entry would write
+    # the same memory.  Copied like the row-expanded one: gradients with respect to k equal the contiguous call's, bit for bit
+    # (autograd sums them over the expanded dimension on both sides).
+    b, hq = 2, 2
+    q = torch.randn(b, s, hq, d).bfloat16().to(dev).requires_grad_(True)
+    for shape in ((b, s, 1, d), (1, s, hq, d)):
+        k0 = torch.randn(shape).bfloat16().to(dev).requires_grad_(True)
+        v0 = torch.randn(shape).bfloat16().to(dev).requires_grad_(True)
+        k1, v1 = (t.detach().clone().requires_grad_(True) for t in (k0, v0))
+        kv, vv = k0.expand(b, s, hq, d), v0.expand(b, s, hq, d)
+        assert 0 in kv.stride()
+        oa = ops.attention(q, kv, vv, scale, True)
+        ob = ops.attention(q, k1.expand(b, s, hq, d).contiguous(), v1.expand(b, s, hq, d).contiguous(), scale, True)
+        assert torch.equal(oa, ob)
+        do = torch.randn_like(oa)
+        ga = torch.autograd.grad(oa, (q, k0, v0), do)
+        gb = torch.autograd.grad(ob, (q, k1, v1), do)
+        assert all(torch.equal(x, y) for x, y in zip(ga, gb)), shape
 
 
 DROPOUT_CASES_SMALL = [(1, 130, 130, 2, 1, 64, True, False, 0.1), (2, 96, 160, 2, 2, 128, False, True, 0.5),

@@ -119,6 +119,10 @@ if __name__ == "__main__":
     if "generate" in which:
         arm = os.environ.get("DECODE_BENCH_ARM")
         if arm:
+            if "TAMD_GEMM" in os.environ:  # (schedule switches exist only in the diagnostic library since round 6)
+                import _diag
+
+                _diag.use_diag()
             generate(arm)
         else:
             # (TAMD_GEMM=x keeps the M = batch projections on the 256 x 256 MFMA tiles instead of csrc/gemv.hip)

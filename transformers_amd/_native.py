@@ -43,7 +43,10 @@ def load():
     dll.tamd_torch_last_error.restype = ctypes.c_char_p
     dll.tamd_torch_bound_path.restype = ctypes.c_char_p
     dll.tamd_torch_dw_cut.restype = ctypes.c_int
-    dll.tamd_torch_dw_cut.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]
+    dll.tamd_torch_dw_cut.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong),
+                                      ctypes.c_int]
+    dll.tamd_torch_set_dw_balance.restype = ctypes.c_int
+    dll.tamd_torch_set_dw_balance.argtypes = [ctypes.c_int]
     dll.tamd_torch_gemm_log.argtypes = [ctypes.c_int]
     dll.tamd_torch_gemm_log_summary.restype = ctypes.c_int
     dll.tamd_torch_gemm_log_summary.argtypes = [ctypes.POINTER(ctypes.c_double)]
@@ -62,12 +65,17 @@ def bound_path() -> str:
     return load().tamd_torch_bound_path().decode()
 
 
-def dw_cut(m: int, n: int, k: int):
+def dw_cut(m: int, n: int, k: int, cus: int = 256):
     """(axis, at) of the cut `gemm_dw_balanced` (csrc/torch_binding.cpp) makes in a weight-gradient product dW[m, n] over k
-    tokens: axis 0 = rows [0, at) / [at, m) as two launches, 1 = columns, -1 = one launch."""
+    tokens on a device of `cus` compute units: axis 0 = rows [0, at) / [at, m) as two launches, 1 = columns, -1 = one launch."""
     at = ctypes.c_longlong(0)
-    axis = load().tamd_torch_dw_cut(m, n, k, ctypes.byref(at))
+    axis = load().tamd_torch_dw_cut(m, n, k, ctypes.byref(at), cus)
     return axis, at.value
+
+
+def set_dw_balance(on: bool) -> bool:
+    """A/B switch of the weight-gradient cut (tools/gemm_dw_cut_ab.py); returns the previous setting."""
+    return bool(load().tamd_torch_set_dw_balance(int(bool(on))))
 
 
 def gemm_log(on: bool) -> None:

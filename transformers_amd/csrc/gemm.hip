@@ -1357,15 +1357,20 @@ static int gemm_check(const void* A, const void* B, const void* C, const void* b
 }
 
 // kernel selection for a filled GemmArgs: split-K (when a workspace allows it), the 128 x 128 tile for small row-major
-// grids, the full-line kernel whenever K % 64 == 0, else the ping-pong kernel.  TAMD_GEMM=pp in the environment or a
+// grids, the full-line kernel whenever K % 64 == 0, else the ping-pong kernel.  TAMD_GEMM=pp in the environment (diagnostic
+// build only) or a
 // TAMD_GEMM_SCHED_* hint in `flags` forces one (A/B measurements, tests).
 static int gemm_run(GemmArgs& g, int flags, int epilogue, int act, int dtype, void* workspace, size_t workspace_bytes,
                     tamd_stream_t stream) {
   const int64_t M = g.M, N = g.N, K = g.K;
+#ifdef TAMD_DIAG  // (libtamd_diag.so only: the product library reads no schedule from the environment)
   static const int forced = [] {
     const char* e = getenv("TAMD_GEMM");
     return !e ? 0 : (e[0] == 'p' ? 1 : (e[0] == 'x' ? 3 : (e[0] == 's' ? 2 : 0)));
   }();
+#else
+  constexpr int forced = 0;
+#endif
   const int sched = (flags >> 8) & 7 ? (flags >> 8) & 7 : forced;  // per-call hint wins over the environment
   flags &= 0xff;
   // a cached decode step's projections (M = batch <= 8, row-major weight): streamed by the VALU kernel of gemv.hip -- bound by

@@ -291,14 +291,18 @@ static int gemv_mfma_launch(const GemvArgs& g, int epilogue, bool swiglu, hipStr
   if (wgs1 >= 2 * 512) return gemv_mfma_launch_rb<T, 2>(g, epilogue, swiglu, s);
   return gemv_mfma_launch_rb<T, 1>(g, epilogue, swiglu, s);
 }
-// rows up to which the VALU kernel runs (TAMD_GEMV_VALU_ROWS in the environment: A/B of the two kernels)
+// rows up to which the VALU kernel runs (libtamd_diag.so: TAMD_GEMV_VALU_ROWS in the environment, A/B of the two kernels)
 static int gemv_valu_rows() {
+#ifdef TAMD_DIAG
   static const int v = [] {
     const char* e = getenv("TAMD_GEMV_VALU_ROWS");
     const int n = e ? atoi(e) : kGemvValuRows;
     return n < 0 ? 0 : (n > 4 ? 4 : n);
   }();
   return v;
+#else
+  return kGemvValuRows;
+#endif
 }
 
 // Which kernel (profiles/r04s_gemv_bench*.jsonl, cold weights): one row -- the VALU kernel everywhere (q|k|v 12.8 vs 12.9 us,

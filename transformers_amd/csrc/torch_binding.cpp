@@ -611,9 +611,10 @@ struct DwCut {
   int axis;
   int64_t at;
 };
-DwCut dw_balanced_cut(int64_t m, int64_t n, int64_t k) {
-  constexpr int64_t kT = 256, kCUs = 256;
-  if (m % kT || n % kT || k % 64) return {-1, 0};
+// `cus`: compute units of the device the product runs on (a dispatch round = one 256 x 256 tile per CU; MI355X: 256)
+DwCut dw_balanced_cut(int64_t m, int64_t n, int64_t k, int64_t kCUs = 256) {
+  constexpr int64_t kT = 256;
+  if (kCUs < 2 || m % kT || n % kT || k % 64) return {-1, 0};
   const int64_t tm = m / kT, tn = n / kT, tiles = tm * tn;
   if (tiles <= kCUs || tiles % kCUs == 0 || tiles > 64 * kCUs) return {-1, 0};
   for (int64_t r = tm - 1; r >= 1; --r)  // the largest main part first
@@ -622,13 +623,31 @@ DwCut dw_balanced_cut(int64_t m, int64_t n, int64_t k) {
     if ((c * tm) % kCUs == 0 && (tn - c) * tm <= kCUs / 2) return {1, c * kT};
   return {-1, 0};
 }
-static const bool kDwBalance = [] { const char* e = getenv("TAMD_DW_BALANCE"); return e == nullptr || std::string(e) != "0"; }();
+// A/B switch of the cut (tools/gemm_dw_cut_ab.py through _native.set_dw_balance): not an environment read of the product
+std::atomic<bool> g_dw_balance{true};
+// compute units of the tensor's device (the CPU execution model of the test-suite stands for an MI355X)
+int64_t cus_of(const Tensor& t) {
+  if (!t.is_cuda()) return 256;
+  hipDeviceProp_t prop;
+  static std::mutex mu;
+  static std::vector<int> cache;  // by device index
+  std::lock_guard<std::mutex> lock(mu);
+  const int dev = t.device().index();
+  if ((int)cache.size() <= dev) cache.resize(dev + 1, 0);
+  if (cache[dev] == 0) cache[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  return cache[dev];
+}
+// the cut pays for the 16-bit MFMA products it was measured on; fp32 operands keep one launch
+DwCut dw_cut_for(const Tensor& dy, int64_t m, int64_t n, int64_t k) {
+  if (!g_dw_balance.load(std::memory_order_relaxed) || dy.scalar_type() == at::kFloat) return DwCut{-1, 0};
+  return dw_balanced_cut(m, n, k, cus_of(dy));
+}
 
 // dW[M, N] = dy[K, M]^T . x[K, N] (both operands k-major) as one launch or as the two of dw_balanced_cut; `out` (optional): the
 // destination ([M, N] row-major view, e.g. a DDP bucket view)
 Tensor gemm_dw_balanced(const Tensor& dy, const Tensor& x, const OptTensor& out_ = {}) {
   const int64_t k = dy.size(0), m = dy.size(1), n = x.size(1);
-  const DwCut cut = kDwBalance ? dw_balanced_cut(m, n, k) : DwCut{-1, 0};
+  const DwCut cut = dw_cut_for(dy, m, n, k);
   if (cut.axis < 0) return k_gemm(dy, x, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, out_, 0);
   Tensor out = out_ ? *out_ : at::empty({m, n}, dy.options());
   if (cut.axis == 0) {
@@ -965,12 +984,15 @@ std::tuple<Tensor, Tensor> op_gemm_swiglu(const Tensor& x2, const Tensor& wgu, b
   return {gu.defined() ? gu : nothing(x2), act};
 }
 // An attention operand as the C ABI takes it (include/tamd.h): head_dim contiguous, rows following each other upwards at most
-// 2^24 elements apart, strides multiples of 8 elements.  A caller's view that is something else -- an expanded (stride 0) or
-// flipped tensor -- is copied once; the layer ops never pass such views.
+// 2^24 elements apart, strides multiples of 8 elements.  A caller's view that is something else -- a flipped tensor, or one
+// expanded over rows, heads or batch (stride 0 with size > 1: `k.expand(b, s, H, d)` for MQA) -- is copied once; the layer ops
+// never pass such views.  The expanded ones matter for the backward: it allocates dK / dV with the operand's strides, and an
+// operand that overlaps itself would have every head (or batch entry) write the same gradient memory.
 Tensor attn_operand(const Tensor& t) {
   const int64_t d = t.size(3);
   const bool rows_ok = t.size(1) <= 1 || (t.stride(1) >= d && t.stride(1) <= ((int64_t)1 << 24));
-  const bool ok = t.stride(3) == 1 && rows_ok && t.stride(0) % 8 == 0 && t.stride(1) % 8 == 0 && t.stride(2) % 8 == 0;
+  bool ok = t.stride(3) == 1 && rows_ok && t.stride(0) % 8 == 0 && t.stride(1) % 8 == 0 && t.stride(2) % 8 == 0;
+  for (int i = 0; i < 3; ++i) ok = ok && (t.size(i) <= 1 || t.stride(i) != 0);
   return ok ? t : t.contiguous();
 }
 std::tuple<Tensor, Tensor> op_attn_fwd(const Tensor& q_, const Tensor& k_, const Tensor& v_, double scale, bool causal,
@@ -1298,7 +1320,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   Tensor dwqkv;  // [(Hq+2Hkv)D, hd]
   if (to_dst) {
     const int64_t nq = hq * d, nkv = 2 * hkv * d;
-    const DwCut cut = kDwBalance ? dw_balanced_cut(nq + nkv, hd, t) : DwCut{-1, 0};
+    const DwCut cut = dw_cut_for(d_qkv, nq + nkv, hd, t);
     if (cut.axis == 0 && cut.at == nq) {  // the cut falls on the q | k|v boundary: q as one product, k|v as a segmented one
       k_gemm(d_qkv.narrow(1, 0, nq), xn, true, true, {}, {}, TAMD_EPI_NONE, TAMD_ACT_NONE, *dst_q, 0);
       gemm_dw_segments(d_qkv.narrow(1, nq, nkv), xn, {*dst_k, *dst_v});
@@ -1632,11 +1654,13 @@ const char* tamd_torch_bound_path(void) {
 
 // where gemm_dw_balanced cuts a weight-gradient product dW[m, n] over k tokens (host logic, for the tests): returns the axis
 // (0 rows, 1 columns, -1 one launch) and the cut position in *at
-int tamd_torch_dw_cut(long long m, long long n, long long k, long long* at) {
-  const DwCut c = dw_balanced_cut(m, n, k);
+int tamd_torch_dw_cut(long long m, long long n, long long k, long long* at, int cus) {
+  const DwCut c = dw_balanced_cut(m, n, k, cus > 0 ? cus : 256);
   if (at) *at = c.at;
   return c.axis;
 }
+// A/B switch of the cut (on by default); returns the previous setting
+int tamd_torch_set_dw_balance(int on) { return g_dw_balance.exchange(on != 0) ? 1 : 0; }
 
 // GEMM event log (bench.py `roofline`): on / off; the summary synchronises the recorded events and clears the log.
 //   out[0] launches, out[1] sum of algorithmic FLOPs, out[2] sum of event durations (ms), out[3] sum of algorithmic bytes

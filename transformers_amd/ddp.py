@@ -23,7 +23,9 @@ these takes the ordinary path.  `tests/test_ddp_gloo.py` checks reduced = mean o
 """
 from __future__ import annotations
 
+import functools
 import os
+import warnings
 import weakref
 from typing import Optional, Sequence
 
@@ -113,6 +115,7 @@ def install_trainer_dropin() -> None:
 
     orig_init = DDP.__init__
 
+    @functools.wraps(orig_init)  # (signature / doc introspection of DistributedDataParallel keeps working)
     def __init__(self, module, *args, **kwargs):
         # ours: a marked module whose caller did not choose the flag (accelerate's `DistributedDataParallelKwargs.to_kwargs()`
         # only passes what differs from the defaults).  A caller who passes it -- bench.py, the tests, the README's by-hand
@@ -132,6 +135,10 @@ def install_trainer_dropin() -> None:
                     mod._tamd_hook_state = enable_zero_copy(mod)
                 except RuntimeError:  # a communication hook is registered already (the user's): the ordinary hand-over stays
                     mod._tamd_hook_state = None
+                    warnings.warn("transformers_amd: DistributedDataParallel was built with gradient_as_bucket_view=True for "
+                                  "the zero-copy gradient hand-over, but a communication hook is already registered (yours "
+                                  "wins): gradients alias the all-reduce buckets, torch copies them in as usual.  Set "
+                                  "TAMD_DDP_ZERO_COPY=0 to keep DistributedDataParallel's own defaults.", stacklevel=2)
 
             handle.append(self.register_forward_pre_hook(_first_forward))
 

@@ -98,12 +98,35 @@ def _has_hooks(*mods: nn.Module) -> bool:
     return False
 
 
+def _hook_moves_weights(hook, device) -> bool:
+    """Does bypassing this accelerate forward wrapper change what the child computes on?  `dispatch_model` attaches an
+    `AlignDevicesHook` to EVERY submodule of a multi-device `device_map`, also to layers that sit wholly on one GPU: those only
+    move inputs to `execution_device` (the layer's own wrapper has done that already) and are safe to bypass.  Unsafe: a hook
+    that offloads (weights on `meta` / CPU until the wrapper runs), one that executes elsewhere, and anything unknown."""
+    inner = getattr(hook, "hooks", None)  # SequentialHook
+    if inner is not None:
+        return any(_hook_moves_weights(h, device) for h in inner)
+    if not hasattr(hook, "offload") or hook.offload:
+        return True
+    ed = getattr(hook, "execution_device", None)
+    if ed is None:
+        return False
+    try:
+        ed = torch.device("cuda", ed) if isinstance(ed, int) else torch.device(ed)
+    except (RuntimeError, TypeError):
+        return True
+    if ed.type == "cuda" and ed.index is None and device.type == "cuda":
+        return False
+    return ed != device
+
+
 def _placement_ok(layer: nn.Module, device, *probe: torch.Tensor) -> bool:
     """A fused layer path reads its children's weights directly instead of calling the children, so it bypasses the forward
     wrappers accelerate installs for `device_map` / CPU / disk offload (`_hf_hook`: accelerate replaces `forward`, it does not
     register a hook, so `_has_hooks` cannot see it) -- with offload a leaf's weight sits on `meta` until its wrapper runs.
-    True when no CHILD of `layer` carries such a wrapper and every parameter is on `device` (a wrapper on `layer` itself
-    has already run by the time its forward is entered).  Cached on the identity of the `probe` weights: materialising or
+    True when no CHILD of `layer` carries a wrapper that offloads or executes elsewhere (`_hook_moves_weights`: the plain
+    execution-device hooks of a multi-GPU `device_map="auto"` do not count) and every parameter is on `device` (a wrapper on
+    `layer` itself has already run by the time its forward is entered).  Cached on the identity of the `probe` weights: materialising or
     moving a weight replaces the parameter object, which invalidates the entry."""
     key = (device,) + tuple(id(t) for t in probe)
     cached = layer.__dict__.get("_tamd_placement")
@@ -111,7 +134,7 @@ def _placement_ok(layer: nn.Module, device, *probe: torch.Tensor) -> bool:
         return cached[1]
     ok = True
     for m in layer.modules():
-        if m is not layer and "_hf_hook" in m.__dict__:
+        if m is not layer and "_hf_hook" in m.__dict__ and _hook_moves_weights(m.__dict__["_hf_hook"], device):
             ok = False
             break
     if ok:
