@@ -892,8 +892,10 @@ def test_gemm_piece_placements_are_bit_identical(env):
         for args, kw in layouts:
             plain = ops.raw_gemm(*args, sched="fl", **kw)
             assert rel_err(plain, ref) < 0.0036
-            for dbg in (32, 128, 64, 256, 512):  # (64 / 256 / 512: the round-5 placements, row-major A only -- the split hand-off
-                lib.tamd_gemm_set_dbg(dbg)         # of 512 is what the adversarial LDS-DMA timing of the CPU model is for)
+            # (64 / 256 / 512: the round-5 placements, row-major A only -- the split hand-off of 512 is what the adversarial LDS-DMA
+            # timing of the CPU model is for; 1024: round 6, hipBLASLt's three-barrier loop structure, every layout)
+            for dbg in (32, 128, 64, 256, 512, 1024):
+                lib.tamd_gemm_set_dbg(dbg)
                 assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
                 lib.tamd_gemm_set_dbg(0)
     finally:

@@ -30,6 +30,8 @@ ap.add_argument("--shapes", default="qkv,o_proj,gate_up,down,lm_head")
 ap.add_argument("--legs", default="fwd,dX,dW")
 ap.add_argument("--no-diag", action="store_true", help="product library only (no early / late arms)")
 ap.add_argument("--placements", action="store_true", help="also the round-5 placements (tamd_gemm_set_dbg 64 / 256 / 512)")
+ap.add_argument("--three-barrier", action="store_true", help="round 6: hipBLASLt's loop structure (tamd_gemm_set_dbg 1024), every layout")
+ap.add_argument("--only", default="", help="comma-separated arms to keep beside fl (e.g. b3)")
 args = ap.parse_args()
 lib = None if args.no_diag else _diag.use_diag()
 be = ops.backend()
@@ -78,12 +80,16 @@ for name in args.shapes.split(","):
                 arms.append("early")  # (forward layout: the product schedule until round 5; dX: still the product schedule)
             if lay != 3 and args.placements:  # round 5: pieces behind the even pairs / pieces first / pieces first + split hand-off
                 arms += ["p1", "p2", "p3"]
+            if args.three_barrier:
+                arms.append("b3")
+            if args.only:
+                arms = ["fl"] + [c for c in arms[1:] if c in args.only.split(",")]
         res = {c: [] for c in arms}
         ref = None
         for rnd in range(args.rounds):
             for c in arms:
                 if lib is not None:
-                    lib.tamd_gemm_set_dbg({"late": 128, "early": 32, "p1": 64, "p2": 256, "p3": 512}.get(c, 0))
+                    lib.tamd_gemm_set_dbg({"late": 128, "early": 32, "p1": 64, "p2": 256, "p3": 512, "b3": 1024}.get(c, 0))
                 flags = lay
                 fn = lambda: gemm(a, b, flags, gm, gn, gk, out, ws)  # noqa: E731
                 res[c].append(round(2.0 * gm * gn * gk / time_ms(fn) / 1e9))

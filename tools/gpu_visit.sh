@@ -13,6 +13,7 @@ exec < /dev/null
 #   attn_pmc                 rocprofv3 --pmc passes over the attention kernels of this tree (tools/attn_pmc.py)
 #   attn_prof                per-kernel times of the attention kernels at the Llama-3-8B shape (rocprofv3)
 #   bert / bert_graph / llava   the other BASELINE configurations' bench lines
+#   train                    bench.py --train-step (fwd+bwd+clip+AdamW), TamdAdamW then torch's clip + fused AdamW
 #   ddp                      bench.py --force-ddp over RCCL at world size 1: zero-copy on / off / collective forced / --verify-ddp
 #   ddp2                     (boxes with >= 2 GPUs only) bench.py --gpus 2 under torchrun, both gradient hand-overs
 #   py <script> [args]       any tools/ script, stdout to <tag>_<script>.jsonl
@@ -36,13 +37,14 @@ step_smoke() {
   tail -3 $out/${tag}_smoke.log
 }
 step_bench() {
-  timeout 400 python bench.py "$@" > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+  timeout 900 python bench.py "$@" > $out/${tag}_bench.json 2> $out/${tag}_bench.err
   echo "bench exit $?"; cut -c1-400 $out/${tag}_bench.json; tail -2 $out/${tag}_bench.err
   python - <<PY
 import json
 try:
     d = json.load(open("$out/${tag}_bench.json"))
     print("ms_per_step", d["ms_per_step"], "roofline.frac", d["roofline"]["frac"], "layer_forward", d.get("layer_forward"))
+    print("secondary", json.dumps(d.get("secondary"))[:1500])
 except Exception as e:
     print("bench line unreadable:", e)
 PY
@@ -123,6 +125,10 @@ bench_line() {  # <file suffix> <bench.py args...>
 step_bert() { bench_line bert --config bert-base --steps 20 --warmup 5 "$@"; }
 step_bert_graph() { bench_line bert_graph --config bert-base --steps 20 --warmup 5 --hip-graph --no-cpu-baseline; }
 step_llava() { bench_line llava --config llava --steps 20 --warmup 5; }
+step_train() {  # the whole optimizer step of Trainer: ours, then torch's clip_grad_norm_ + fused AdamW
+  bench_line train --train-step --steps 3 --warmup 2 --no-cpu-baseline --no-secondary
+  bench_line train --train-step --optimizer torch --steps 3 --warmup 2 --no-cpu-baseline --no-secondary
+}
 step_ddp() {
   for arm in "" "--no-ddp-zero-copy" "--verify-ddp"; do
     bench_line ddp --force-ddp --steps 4 --warmup 3 --no-cpu-baseline $arm

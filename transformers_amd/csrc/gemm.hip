@@ -758,7 +758,16 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   // +-0.2 % of the product schedule on the five forward shapes over five rounds (the first box's +0...2.6 % over three rounds
   // was noise), 2 -1 ... -2.5 %, 3 -2 ... -4 %: back-to-back LDS-DMA issues and a barrier inside the MFMA stream cost more
   // than the longer lead buys.  The product schedule stays EARLY; the three stay selectable in the diagnostic library.
-  constexpr int PLACE = (DBG & 64) ? 1 : ((DBG & 256) ? 2 : ((DBG & 512) ? 3 : 0));
+  // 4 (round 6, DBG 1024) = the loop STRUCTURE of hipBLASLt's MT256x256x64_MI16x16x1 kernel, read off its disassembly
+  // (profiles/r06_hipblaslt_loop.md): LDS double-buffered by whole stages (A_s, B_s in half-slots 2(s&1), 2(s&1)+1), three
+  // barriers per stage, each in the middle of an MFMA run behind a wait that is long satisfied --
+  //   k-step 0: the 8 A fragments of k-step 1 behind MFMAs 1,3..15 | lgkmcnt(0) 21, BARRIER 22: A_s is read by everybody |
+  //             A_{s+2} pieces 0..4 behind 23,26..35 with the 8 B fragments of k-step 1 behind 25,28,31,34,37,39,41,43 |
+  //             lgkmcnt(0) 51, BARRIER 52: B_s is read | A_{s+2} pieces 5..7 behind 53,56,59 | B_{s+2} piece 0 behind 62
+  //   k-step 1: B_{s+2} pieces 1..4 behind 1,22,24,26 | vmcnt(13) 28, BARRIER 29: stage s+1 has landed for everybody |
+  //             the 16 fragments of k-step 0 of stage s+1 behind 30..60, B_{s+2} pieces 5..7 behind 33,37,61 | lgkmcnt(0) 63
+  // Same MFMA order, same summation order: bit-identical to the product schedule.
+  constexpr int PLACE = (DBG & 64) ? 1 : ((DBG & 256) ? 2 : ((DBG & 512) ? 3 : ((DBG & 1024) ? 4 : 0)));
   auto kstep = [&](int buf, int ra, int rb, int rq, int pb, int ps) __attribute__((always_inline)) {
     kstep_open();
 #pragma unroll
@@ -788,6 +797,61 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
       sched_fence();
     }
   };
+  // ---- PLACE 4: one MFMA per slot, the feed instruction (if any) behind it
+  auto mfma_at = [&](int buf, int i) __attribute__((always_inline)) {
+    const int nb = i >> 3, mb = i & 7;
+    acc[nb][mb] = mfma16<T>(fw[buf][nb], fx[buf][mb], acc[nb][mb]);
+    sched_fence();
+  };
+  // k-step 0 of the stage in LDS buffer b (half-slots 2b, 2b+1): fragments of its k-step 1 into register buffer 1, the pieces of
+  // stage s+2 into the same LDS buffer as the two barriers release its halves
+  auto kstep3_0 = [&](int b) __attribute__((always_inline)) {
+    const int sa = 2 * b, sb = 2 * b + 1;
+    kstep_open();
+#pragma unroll
+    for (int i = 1; i <= 64; ++i) {
+      mfma_at(0, i - 1);
+      if (i <= 15 && (i & 1)) fx[1][(i - 1) >> 1] = frag_a(sa, 1, (i - 1) >> 1);
+      if (i == 21) wait_lgkmcnt0();
+      if (i == 22) raw_barrier();
+      if (i >= 23 && i <= 35 && (i - 23) % 3 == 0) issue((i - 23) / 3, sa);
+      if (i >= 25 && i <= 37 && (i - 25) % 3 == 0) fw[1][(i - 25) / 3] = frag_b(sb, 1, (i - 25) / 3);
+      if (i == 39 || i == 41 || i == 43) fw[1][5 + (i - 39) / 2] = frag_b(sb, 1, 5 + (i - 39) / 2);
+      if (i == 51) wait_lgkmcnt0();
+      if (i == 52) raw_barrier();
+      if (i == 53 || i == 56 || i == 59) issue(5 + (i - 53) / 3, sa);
+      if (i == 62) issue(8, sb);
+      sched_fence();
+    }
+  };
+  // k-step 1: the rest of B_{s+2}; once stage s+1 has landed (LDS buffer b ^ 1) the fragments of its k-step 0 into register buffer 0
+  auto kstep3_1 = [&](int b) __attribute__((always_inline)) {
+    const int sb = 2 * b + 1, na = 2 * (b ^ 1), nbs = 2 * (b ^ 1) + 1;
+    kstep_open();
+#pragma unroll
+    for (int i = 1; i <= 64; ++i) {
+      mfma_at(1, i - 1);
+      if (i == 1) issue(9, sb);
+      if (i == 22 || i == 24 || i == 26) issue(10 + (i - 22) / 2, sb);
+      if (i == 28) wait_vmcnt<13>();  // everything but this stage's 8 + 5 pieces: stage s+1 is in LDS
+      if (i == 29) raw_barrier();
+      if (i == 30 || i == 31 || i == 32) fx[0][i - 30] = frag_a(na, 0, i - 30);
+      if (i == 33) issue(13, sb);
+      if (i == 34 || i == 35) fx[0][i - 31] = frag_a(na, 0, i - 31);
+      if (i == 37) issue(14, sb);
+      if (i == 39 || i == 40 || i == 41) fx[0][i - 34] = frag_a(na, 0, i - 34);
+      if (i == 42 || i == 43) fw[0][i - 42] = frag_b(nbs, 0, i - 42);
+      if (i == 46) fw[0][2] = frag_b(nbs, 0, 2);
+      if (i == 49) fw[0][3] = frag_b(nbs, 0, 3);
+      if (i == 51) fw[0][4] = frag_b(nbs, 0, 4);
+      if (i == 54) fw[0][5] = frag_b(nbs, 0, 5);
+      if (i == 57) fw[0][6] = frag_b(nbs, 0, 6);
+      if (i == 60) fw[0][7] = frag_b(nbs, 0, 7);
+      if (i == 61) issue(15, sb);
+      if (i == 63) wait_lgkmcnt0();
+      sched_fence();
+    }
+  };
   // prologue: A_0 B_0 A_1 B_1 into half-slots 0..3
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -795,6 +859,25 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
 #pragma unroll
     for (int p = 0; p < 16; ++p) issue(p, 2 * j + (p >> 3));
   }
+  if (PLACE == 4) {
+    wait_vmcnt<16>();  // stage 0 has landed; stage 1 stays in flight (the first vmcnt(13) + barrier covers it)
+    raw_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rd1(0, 1, 0, 0, r);
+    wait_lgkmcnt0();
+    for (int s0 = 0; s0 < nst; s0 += 2) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int s = s0 + b;
+        if (s < nst) {
+          sched_fence();
+          if (s + 2 == nst) park();
+          kstep3_0(b);
+          kstep3_1(b);
+        }
+      }
+    }
+  } else {
   wait_vmcnt<0>();
   raw_barrier();
 #pragma unroll
@@ -821,6 +904,7 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
       }
     }
   }
+  }  // PLACE != 4
   wait_vmcnt<0>();
   wait_lgkmcnt0();
   raw_barrier();
@@ -1125,6 +1209,10 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 32>), grid, block, (size_t)kXSmem, s, g);
     else
       hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 128>), grid, block, (size_t)kXSmem, s, g);
+    return launch_status();
+  }
+  if (dbg == 1024 && epilogue == TAMD_EPI_NONE) {  // round 6: hipBLASLt's three-barrier loop structure (bit-identical results)
+    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 1024>), grid, block, (size_t)kXSmem, s, g);
     return launch_status();
   }
   if constexpr (!A_KM) {  // round-5 placements (forward and dX layouts; correct, bit-identical results)
