@@ -882,7 +882,7 @@ def test_gemm_piece_placements_are_bit_identical(env):
         pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
     torch.manual_seed(61)
     dev = env.device
-    m, n, k = (1536, 1024, 1280) if env.big else (512, 520, 640)
+    m, n, k = (1536, 1024, 1280) if env.big else (512, 520, 768)  # (a multiple of four 64-deep stages: DBG 1024)
     x = torch.randn(m, k).bfloat16().to(dev)
     w = (torch.randn(n, k) * k ** -0.5).bfloat16().to(dev)
     layouts = [((x, w), {}), ((x, w.t().contiguous()), {"b_kn": True}),
@@ -894,7 +894,7 @@ def test_gemm_piece_placements_are_bit_identical(env):
             assert rel_err(plain, ref) < 0.0036
             # (64 / 256 / 512: the round-5 placements, row-major A only -- the split hand-off of 512 is what the adversarial LDS-DMA
             # timing of the CPU model is for; 1024: round 6, hipBLASLt's three-barrier loop structure, every layout)
-            for dbg in (32, 128, 64, 256, 512, 1024):
+            for dbg in (32, 128, 64, 256, 512, 1024, 2048):  # (2048: the one-barrier ring forced where three barriers are the product)
                 lib.tamd_gemm_set_dbg(dbg)
                 assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
                 lib.tamd_gemm_set_dbg(0)

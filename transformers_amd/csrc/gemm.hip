@@ -577,6 +577,40 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_pp_kernel(GemmArgs g) {
 // stores); requires K % 64 == 0 (host dispatch).
 constexpr int kFlThreads = 256;
 constexpr int kXK = 64;
+// compile-time loop: f(IntC<B>{}), ..., f(IntC<E-1>{}) -- every iteration its own instantiation, `if constexpr` on the index
+// (a 64-slot schedule table is more than `#pragma unroll` folds: the unroller gave up and indexed the accumulators at run time)
+// acc += A . B with the accumulator named as an AGPR tuple in the instruction itself (`+a`: ONE register tuple, read and
+// written in place).  The three-barrier loop issues its MFMAs this way: through the builtin the register allocator rotated the
+// accumulators of that loop through VGPRs (s_nop 6 + v_accvgpr_read / _write groups behind every other MFMA pair, a 450-move
+// permutation on the back edge).  The compiler does not know this is an MFMA: the caller keeps the result away from other
+// instructions for the pipeline's depth (the K loop only feeds accumulators back into MFMAs; `mfma_drain` before the way out).
+template <typename T>
+__device__ __forceinline__ void mfma16_inplace(f32x4& c, const u32x4& a, const u32x4& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (sizeof(T) == 2 && __is_same(T, bf16_t))
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+#else
+  c = mfma16<T>(a, b, c);
+#endif
+}
+__device__ __forceinline__ void mfma_drain() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+template <int N>
+struct IntC {
+  static constexpr int value = N;
+};
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(IntC<B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 constexpr unsigned kXHalf = 256u * kXK * 2u;  // one operand of one stage: 32 KiB
 constexpr int kXSlots = 5;
 constexpr int kXSmem = kXSlots * (int)kXHalf;  // 163840 = the whole LDS of a CU
@@ -672,7 +706,7 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
     voff[8 + i] = (unsigned)(ob * 2 + 4096 - (i & 3) * 1024);
   }
   // past the last stage: keep the load counts uniform and re-read the last valid stage (idempotent)
-  auto park = [&]() {
+  auto park = [&]() __attribute__((always_inline)) {
     base_a -= kinc_a;
     base_b -= kinc_b;
     kinc_a = 0;
@@ -680,7 +714,7 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   };
   const unsigned piece0 = (unsigned)wave * 8192u;  // this wave's first piece inside an operand stage
   bool dma_on = true;
-  auto issue = [&](int p, int slot) {  // piece p (0..15) of this wave into half-slot `slot`
+  auto issue = [&](int p, int slot) __attribute__((always_inline)) {  // piece p (0..15) of this wave into half-slot `slot`
     if ((DBG & 1) && !dma_on) return;
     const unsigned dst = (unsigned)slot * kXHalf + piece0 + (unsigned)((p & 7) >> 2) * 4096u;  // + immediate
     const char* base = (p < 8) ? base_a : base_b;
@@ -711,27 +745,27 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   }
   // k-major fragments: two transposing 8-byte reads (k rows +0..3 and +4..7), issued untracked (tamd_device.h:
   // the compiler would drain vmcnt in front of each); every k-step therefore opens with an explicit lgkmcnt(0)
-  auto frag_km = [&](unsigned off, int imm) -> u32x4 {
+  auto frag_km = [&](unsigned off, int imm) __attribute__((always_inline)) -> u32x4 {
     const u32x2 lo = lds_read8_tr16_untracked(smem, off, imm);
     const u32x2 h2 = lds_read8_tr16_untracked(smem, off, imm + 4 * 512);
     return u32x4{lo[0], lo[1], h2[0], h2[1]};
   };
-  auto frag_a = [&](int slot, int q, int t) -> u32x4 {
+  auto frag_a = [&](int slot, int q, int t) __attribute__((always_inline)) -> u32x4 {
     if (A_KM) return frag_km((unsigned)slot * kXHalf + offx[A_KM ? t : 0], q * 16384);
     return lds_read16(smem, (unsigned)slot * kXHalf + offx[A_KM ? 0 : q] + (unsigned)t * 2048u);
   };
-  auto frag_b = [&](int slot, int q, int t) -> u32x4 {
+  auto frag_b = [&](int slot, int q, int t) __attribute__((always_inline)) -> u32x4 {
     if (B_KN) return frag_km((unsigned)slot * kXHalf + offw[B_KN ? t : 0], q * 16384);
     return lds_read16(smem, (unsigned)slot * kXHalf + offw[B_KN ? 0 : q] + (unsigned)t * 2048u);
   };
-  auto kstep_open = [&]() {  // fragments of this k-step (read during the previous one) are in registers
+  auto kstep_open = [&]() __attribute__((always_inline)) {  // fragments of this k-step (read during the previous one) are in registers
     if (A_KM || B_KN) wait_lgkmcnt0();
     sched_fence();
   };
   u32x4 fx[2][8], fw[2][8];  // [buffer][mb / nb]
   // fragment read number r (0..15) of k-step q of stage slots (sa, sb) into buffer buf, in the order the MFMAs of the
   // next k-step want them: w0 x0 x1 .. x7 w1 .. w7
-  auto rd1 = [&](int sa, int sb, int q, int buf, int r) {
+  auto rd1 = [&](int sa, int sb, int q, int buf, int r) __attribute__((always_inline)) {
     if ((DBG & 2) && !dma_on) return;
     if (r == 0)
       fw[buf][0] = frag_b(sb, q, 0);
@@ -767,7 +801,11 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   //   k-step 1: B_{s+2} pieces 1..4 behind 1,22,24,26 | vmcnt(13) 28, BARRIER 29: stage s+1 has landed for everybody |
   //             the 16 fragments of k-step 0 of stage s+1 behind 30..60, B_{s+2} pieces 5..7 behind 33,37,61 | lgkmcnt(0) 63
   // Same MFMA order, same summation order: bit-identical to the product schedule.
-  constexpr int PLACE = (DBG & 64) ? 1 : ((DBG & 256) ? 2 : ((DBG & 512) ? 3 : ((DBG & 1024) ? 4 : 0)));
+  // Measured on MI355X against the one-barrier schedule, interleaved, bit-identical (profiles/r06b_gemm_piece_ab.jsonl): forward
+  // q|k|v +2.9 %, o_proj +2.3 %, gate|up +1.8 %, down -0.1 %; dW o_proj +1.9 %, gate|up +2.8 %; dX -1.2 ... +1.0 %.  It is the
+  // product schedule of the forward layout (both operands row-major) and of dW (both k-major) since round 6; dX (row-major A,
+  // k-major B) keeps the one-barrier ring.  DBG 1024 forces it in every layout, DBG 2048 forces the one-barrier ring.
+  constexpr int PLACE = (DBG & 64) ? 1 : ((DBG & 256) ? 2 : ((DBG & 512) ? 3 : (((DBG & 1024) || (A_KM == B_KN && !(DBG & (2048 | 32 | 128 | 15)))) ? 4 : 0)));
   auto kstep = [&](int buf, int ra, int rb, int rq, int pb, int ps) __attribute__((always_inline)) {
     kstep_open();
 #pragma unroll
@@ -797,58 +835,91 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
       sched_fence();
     }
   };
-  // ---- PLACE 4: one MFMA per slot, the feed instruction (if any) behind it
-  auto mfma_at = [&](int buf, int i) __attribute__((always_inline)) {
-    const int nb = i >> 3, mb = i & 7;
-    acc[nb][mb] = mfma16<T>(fw[buf][nb], fx[buf][mb], acc[nb][mb]);
-    sched_fence();
+  // ---- PLACE 4 (their instruction positions rounded to our MFMA pairs: a slot = behind MFMA 2p + 2)
+  // Fragment reads behind the compiler's back in every layout (`=v` pins the fragments to the VGPR half: with tracked reads the
+  // allocator put fragments into AGPRs and accumulators into VGPRs -- a copy in front of every MFMA, 56 spilled registers)
+  auto frag_a4 = [&](int slot, int q, int t) __attribute__((always_inline)) -> u32x4 {
+    if (A_KM) return frag_km((unsigned)slot * kXHalf + offx[A_KM ? t : 0], q * 16384);
+    return lds_read16_untracked(smem, (unsigned)slot * kXHalf + offx[A_KM ? 0 : q], t * 2048);
+  };
+  auto frag_b4 = [&](int slot, int q, int t) __attribute__((always_inline)) -> u32x4 {
+    if (B_KN) return frag_km((unsigned)slot * kXHalf + offw[B_KN ? t : 0], q * 16384);
+    return lds_read16_untracked(smem, (unsigned)slot * kXHalf + offw[B_KN ? 0 : q], t * 2048);
   };
   // k-step 0 of the stage in LDS buffer b (half-slots 2b, 2b+1): fragments of its k-step 1 into register buffer 1, the pieces of
   // stage s+2 into the same LDS buffer as the two barriers release its halves
   auto kstep3_0 = [&](int b) __attribute__((always_inline)) {
     const int sa = 2 * b, sb = 2 * b + 1;
-    kstep_open();
+    wait_lgkmcnt0();  // (the fragments of this k-step: read behind the compiler's back)
+    sched_fence();
 #pragma unroll
-    for (int i = 1; i <= 64; ++i) {
-      mfma_at(0, i - 1);
-      if (i <= 15 && (i & 1)) fx[1][(i - 1) >> 1] = frag_a(sa, 1, (i - 1) >> 1);
-      if (i == 21) wait_lgkmcnt0();
-      if (i == 22) raw_barrier();
-      if (i >= 23 && i <= 35 && (i - 23) % 3 == 0) issue((i - 23) / 3, sa);
-      if (i >= 25 && i <= 37 && (i - 25) % 3 == 0) fw[1][(i - 25) / 3] = frag_b(sb, 1, (i - 25) / 3);
-      if (i == 39 || i == 41 || i == 43) fw[1][5 + (i - 39) / 2] = frag_b(sb, 1, 5 + (i - 39) / 2);
-      if (i == 51) wait_lgkmcnt0();
-      if (i == 52) raw_barrier();
-      if (i == 53 || i == 56 || i == 59) issue(5 + (i - 53) / 3, sa);
-      if (i == 62) issue(8, sb);
+    for (int p = 0; p < 32; ++p) {
+      const int nb = p >> 2, mb = (p & 3) * 2;
+      mfma16_inplace<T>(acc[nb][mb], fw[0][nb], fx[0][mb]);
+      mfma16_inplace<T>(acc[nb][mb + 1], fw[0][nb], fx[0][mb + 1]);
+      sched_fence();
+      if (p < 8) fx[1][p] = frag_a4(sa, 1, p);
+      if (p == 10) {  // A_s is read by everybody
+        wait_lgkmcnt0();
+        raw_barrier();
+      }
+      if (p == 11) issue(0, sa);
+      if (p == 12) fw[1][0] = frag_b4(sb, 1, 0);
+      if (p == 12) issue(1, sa);
+      if (p == 13) fw[1][1] = frag_b4(sb, 1, 1);
+      if (p == 14) issue(2, sa);
+      if (p == 15) fw[1][2] = frag_b4(sb, 1, 2);
+      if (p == 15) issue(3, sa);
+      if (p == 16) fw[1][3] = frag_b4(sb, 1, 3);
+      if (p == 17) issue(4, sa);
+      if (p >= 18 && p <= 21) fw[1][p - 14] = frag_b4(sb, 1, p - 14);
+      if (p == 25) {  // B_s is read by everybody
+        wait_lgkmcnt0();
+        raw_barrier();
+      }
+      if (p == 26) issue(5, sa);
+      if (p == 27) issue(6, sa);
+      if (p == 29) issue(7, sa);
+      if (p == 30) issue(8, sb);
       sched_fence();
     }
   };
   // k-step 1: the rest of B_{s+2}; once stage s+1 has landed (LDS buffer b ^ 1) the fragments of its k-step 0 into register buffer 0
   auto kstep3_1 = [&](int b) __attribute__((always_inline)) {
     const int sb = 2 * b + 1, na = 2 * (b ^ 1), nbs = 2 * (b ^ 1) + 1;
-    kstep_open();
+    wait_lgkmcnt0();  // (the fragments of this k-step: read behind the compiler's back)
+    sched_fence();
 #pragma unroll
-    for (int i = 1; i <= 64; ++i) {
-      mfma_at(1, i - 1);
-      if (i == 1) issue(9, sb);
-      if (i == 22 || i == 24 || i == 26) issue(10 + (i - 22) / 2, sb);
-      if (i == 28) wait_vmcnt<13>();  // everything but this stage's 8 + 5 pieces: stage s+1 is in LDS
-      if (i == 29) raw_barrier();
-      if (i == 30 || i == 31 || i == 32) fx[0][i - 30] = frag_a(na, 0, i - 30);
-      if (i == 33) issue(13, sb);
-      if (i == 34 || i == 35) fx[0][i - 31] = frag_a(na, 0, i - 31);
-      if (i == 37) issue(14, sb);
-      if (i == 39 || i == 40 || i == 41) fx[0][i - 34] = frag_a(na, 0, i - 34);
-      if (i == 42 || i == 43) fw[0][i - 42] = frag_b(nbs, 0, i - 42);
-      if (i == 46) fw[0][2] = frag_b(nbs, 0, 2);
-      if (i == 49) fw[0][3] = frag_b(nbs, 0, 3);
-      if (i == 51) fw[0][4] = frag_b(nbs, 0, 4);
-      if (i == 54) fw[0][5] = frag_b(nbs, 0, 5);
-      if (i == 57) fw[0][6] = frag_b(nbs, 0, 6);
-      if (i == 60) fw[0][7] = frag_b(nbs, 0, 7);
-      if (i == 61) issue(15, sb);
-      if (i == 63) wait_lgkmcnt0();
+    for (int p = 0; p < 32; ++p) {
+      const int nb = p >> 2, mb = (p & 3) * 2;
+      mfma16_inplace<T>(acc[nb][mb], fw[1][nb], fx[1][mb]);
+      mfma16_inplace<T>(acc[nb][mb + 1], fw[1][nb], fx[1][mb + 1]);
+      sched_fence();
+      if (p == 0) issue(9, sb);
+      if (p >= 10 && p <= 12) issue(p, sb);
+      if (p == 13) {  // everything but this stage's 8 + 5 pieces: stage s+1 is in LDS, for everybody
+        wait_vmcnt<13>();
+        raw_barrier();
+      }
+      if (p == 14) fx[0][0] = frag_a4(na, 0, 0);
+      if (p == 15) fx[0][1] = frag_a4(na, 0, 1);
+      if (p == 15) fx[0][2] = frag_a4(na, 0, 2);
+      if (p == 16) fx[0][3] = frag_a4(na, 0, 3);
+      if (p == 16) issue(13, sb);
+      if (p == 17) fx[0][4] = frag_a4(na, 0, 4);
+      if (p == 18) issue(14, sb);
+      if (p == 19) fx[0][5] = frag_a4(na, 0, 5);
+      if (p == 19) fx[0][6] = frag_a4(na, 0, 6);
+      if (p == 20) fx[0][7] = frag_a4(na, 0, 7);
+      if (p == 20) fw[0][0] = frag_b4(nbs, 0, 0);
+      if (p == 21) fw[0][1] = frag_b4(nbs, 0, 1);
+      if (p == 22) fw[0][2] = frag_b4(nbs, 0, 2);
+      if (p == 24) fw[0][3] = frag_b4(nbs, 0, 3);
+      if (p == 25) fw[0][4] = frag_b4(nbs, 0, 4);
+      if (p == 26) fw[0][5] = frag_b4(nbs, 0, 5);
+      if (p == 28) fw[0][6] = frag_b4(nbs, 0, 6);
+      if (p == 29) fw[0][7] = frag_b4(nbs, 0, 7);
+      if (p == 30) issue(15, sb);
       sched_fence();
     }
   };
@@ -863,19 +934,24 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
     wait_vmcnt<16>();  // stage 0 has landed; stage 1 stays in flight (the first vmcnt(13) + barrier covers it)
     raw_barrier();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rd1(0, 1, 0, 0, r);
-    wait_lgkmcnt0();
-    for (int s0 = 0; s0 < nst; s0 += 2) {
+    for (int t = 0; t < 8; ++t) {
+      fx[0][t] = frag_a4(0, 0, t);
+      fw[0][t] = frag_b4(1, 0, t);
+    }
+    const int nst2 = nst & ~1;
+    for (int s0 = 0; s0 < nst2; s0 += 2) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        const int s = s0 + b;
-        if (s < nst) {
-          sched_fence();
-          if (s + 2 == nst) park();
-          kstep3_0(b);
-          kstep3_1(b);
-        }
+        sched_fence();
+        if (s0 + b + 2 == nst) park();
+        kstep3_0(b);
+        kstep3_1(b);
       }
+    }
+    if (nst & 1) {  // the last stage of an odd count (its parity is even: LDS buffer 0); stage s+2 is parked since s = nst - 2
+      sched_fence();
+      kstep3_0(0);
+      kstep3_1(0);
     }
   } else {
   wait_vmcnt<0>();
@@ -905,6 +981,7 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
     }
   }
   }  // PLACE != 4
+  if (PLACE == 4) mfma_drain();
   wait_vmcnt<0>();
   wait_lgkmcnt0();
   raw_barrier();
@@ -1211,8 +1288,11 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
       hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 128>), grid, block, (size_t)kXSmem, s, g);
     return launch_status();
   }
-  if (dbg == 1024 && epilogue == TAMD_EPI_NONE) {  // round 6: hipBLASLt's three-barrier loop structure (bit-identical results)
-    hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 1024>), grid, block, (size_t)kXSmem, s, g);
+  if ((dbg == 1024 || dbg == 2048) && epilogue == TAMD_EPI_NONE) {  // round 6: the three-barrier loop / the one-barrier ring, forced
+    if (dbg == 1024)
+      hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 1024>), grid, block, (size_t)kXSmem, s, g);
+    else
+      hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 2048>), grid, block, (size_t)kXSmem, s, g);
     return launch_status();
   }
   if constexpr (!A_KM) {  // round-5 placements (forward and dX layouts; correct, bit-identical results)
