@@ -457,12 +457,15 @@ def ddp_report(args, net, model, fwd, dev, world, ddp_ms):
     return out
 
 
-def secondary_legs(timeout_s=300):
+SECONDARY_LEGS = {"bert_base": ["--config", "bert-base", "--steps", "20", "--warmup", "5"],
+                  "llava": ["--config", "llava", "--steps", "20", "--warmup", "5"],
+                  "train_step": ["--config", "llama3-8b", "--train-step", "--steps", "3", "--warmup", "2"]}
+
+
+def secondary_legs(timeout_s=300, legs=None):
     """BASELINE.json configs 2 and 5 and one end-to-end training step, each as a child process running this script (the
     parent has released its GPU memory): a crash, a hang (timeout) or an out-of-memory in a leg becomes an `error` entry."""
-    legs = {"bert_base": ["--config", "bert-base", "--steps", "20", "--warmup", "5"],
-            "llava": ["--config", "llava", "--steps", "20", "--warmup", "5"],
-            "train_step": ["--config", "llama3-8b", "--train-step", "--steps", "3", "--warmup", "2"]}
+    legs = SECONDARY_LEGS if legs is None else legs
     out = {}
     for name, extra in legs.items():
         t0 = time.perf_counter()

@@ -473,3 +473,26 @@ def test_trainer_dropin_only_touches_accelerated_models(tmp_path):
     assert res == {"plain_views": False, "marked_views": True, "explicit_false": False, "hook_registered": True,
                    "buckets_reduced": res["buckets_reduced"], "their_hook_kept": True, "env_off": False}, res
     assert res["buckets_reduced"] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_train_step_and_secondary_legs_on_the_gpu():
+    """`bench.py --train-step` (forward, backward, gradient-norm clip and AdamW on the kernels) prints the
+    optimizer's share, and the `secondary` legs of the headline run are child processes whose failure cannot touch the parent:
+    a leg that works, one that crashes and one that times out, through the same function the headline run calls."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    tiny = ["--config", "llama-tiny", "--steps", "2", "--warmup", "1"]
+    out = bench.secondary_legs(timeout_s=600, legs={"train_step": tiny + ["--train-step"], "crash": ["--config", "no-such-config"]})
+    ts = out["train_step"]
+    assert "error" not in ts and ts["fallback_calls"] == 0, ts
+    assert ts["optimizer_ms"] > 0 and ts["grad_norm"] > 0 and ts["ms_per_step"] > ts["optimizer_ms"], ts
+    assert "TamdAdamW" in ts["optimizer"] and ts["metric"].startswith("training-step")
+    assert "error" in out["crash"] and out["crash"]["leg_wall_s"] >= 0
+    slow = bench.secondary_legs(timeout_s=1, legs={"hang": tiny})
+    assert "timeout" in slow["hang"]["error"]
+    # the A/B arm: torch's clip + fused AdamW through the same step
+    ref = _run([sys.executable, "bench.py", *tiny, "--train-step", "--optimizer", "torch", "--no-cpu-baseline", "--no-secondary"])
+    assert ref["train_step"]["optimizer"].startswith("torch.nn.utils.clip_grad_norm_") and ref["train_step"]["optimizer_ms"] > 0

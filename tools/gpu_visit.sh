@@ -12,7 +12,7 @@ exec < /dev/null
 #   attn_variants            ... and every tools/ab/libtamd_[p-z]*.so (tools/build_variant.py), attention entry points
 #   attn_pmc                 rocprofv3 --pmc passes over the attention kernels of this tree (tools/attn_pmc.py)
 #   attn_prof                per-kernel times of the attention kernels at the Llama-3-8B shape (rocprofv3)
-#   bert / bert_graph / llava   the other BASELINE configurations' bench lines
+#   bert / bert_graph / llava   the other BASELINE configurations' bench lines      prof_cfg <config>   their rocprofv3 kernel stats
 #   train                    bench.py --train-step (fwd+bwd+clip+AdamW), TamdAdamW then torch's clip + fused AdamW
 #   ddp                      bench.py --force-ddp over RCCL at world size 1: zero-copy on / off / collective forced / --verify-ddp
 #   ddp2                     (boxes with >= 2 GPUs only) bench.py --gpus 2 under torchrun, both gradient hand-overs
@@ -121,6 +121,14 @@ bench_line() {  # <file suffix> <bench.py args...>
   local name=$1
   shift
   timeout 300 python bench.py "$@" 2> $out/${tag}_bench_${name}.err | grep -m1 '^{"metric' | tee -a $out/${tag}_bench_${name}.jsonl | cut -c1-330
+}
+step_prof_cfg() {  # rocprofv3 kernel stats of one of the other BASELINE configurations: prof_cfg bb | lv  (bert-base | llava)
+  local cfg=$1
+  [ "$cfg" = lv ] && cfg=llava
+  [ "$cfg" = bb ] && cfg=bert-base
+  ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag/stats_$cfg -o bench -- python $R/bench.py --config $cfg --steps 10 --warmup 3 --no-cpu-baseline --gemm-timer off > $out/${tag}_prof_${cfg}.log 2>&1 )
+  cp $(find $out/$tag/stats_$cfg -name "*kernel_stats.csv" | head -1) $out/${tag}_${cfg}_kernel_stats.csv 2>/dev/null
+  head -14 $out/${tag}_${cfg}_kernel_stats.csv | cut -c1-170
 }
 step_bert() { bench_line bert --config bert-base --steps 20 --warmup 5 "$@"; }
 step_bert_graph() { bench_line bert_graph --config bert-base --steps 20 --warmup 5 --hip-graph --no-cpu-baseline; }
