@@ -894,7 +894,7 @@ def test_gemm_piece_placements_are_bit_identical(env):
             assert rel_err(plain, ref) < 0.0036
             # (64 / 256 / 512: the round-5 placements, row-major A only -- the split hand-off of 512 is what the adversarial LDS-DMA
             # timing of the CPU model is for; 1024: round 6, hipBLASLt's three-barrier loop structure, every layout)
-            for dbg in (32, 128, 64, 256, 512, 1024, 2048):  # (2048: the one-barrier ring forced where three barriers are the product)
+            for dbg in (32, 128, 64, 256, 512, 1024, 2048, 1024 + 4096, 1024 + 8192, 1024 + 16384):  # (2048: the one-barrier ring forced where three barriers are the product)
                 lib.tamd_gemm_set_dbg(dbg)
                 assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
                 lib.tamd_gemm_set_dbg(0)

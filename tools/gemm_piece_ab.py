@@ -81,7 +81,7 @@ for name in args.shapes.split(","):
             if lay != 3 and args.placements:  # round 5: pieces behind the even pairs / pieces first / pieces first + split hand-off
                 arms += ["p1", "p2", "p3"]
             if args.three_barrier:
-                arms += ["b3", "b1"]  # (three barriers / the one-barrier ring, forced: one of them is what "fl" runs)
+                arms += ["b3", "b1", "b3p", "b3s", "b3c"]  # (three barriers (vendor table, one MFMA per gap) / the one-barrier ring, forced: one of them is what "fl" runs; the table rounded to MFMA pairs / SPREAD)
             if args.only:
                 arms = ["fl"] + [c for c in arms[1:] if c in args.only.split(",")]
         res = {c: [] for c in arms}
@@ -89,7 +89,7 @@ for name in args.shapes.split(","):
         for rnd in range(args.rounds):
             for c in arms:
                 if lib is not None:
-                    lib.tamd_gemm_set_dbg({"late": 128, "early": 32, "p1": 64, "p2": 256, "p3": 512, "b3": 1024, "b1": 2048}.get(c, 0))
+                    lib.tamd_gemm_set_dbg({"late": 128, "early": 32, "p1": 64, "p2": 256, "p3": 512, "b3": 1024, "b1": 2048, "b3p": 1024 + 4096, "b3c": 1024 + 16384, "b3s": 1024 + 8192}.get(c, 0))
                 flags = lay
                 fn = lambda: gemm(a, b, flags, gm, gn, gk, out, ws)  # noqa: E731
                 res[c].append(round(2.0 * gm * gn * gk / time_ms(fn) / 1e9))
