@@ -73,7 +73,7 @@ CONFIGS = {
 }
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-GEMM_TRAFFIC_FILES = ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
+GEMM_TRAFFIC_FILES = ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json")
 
 
 def llama_flops_per_token(m, seq, backward=True) -> float:
@@ -474,8 +474,7 @@ def secondary_legs(timeout_s=300, legs=None):
                                 "--no-secondary", *extra], capture_output=True, text=True, timeout=timeout_s)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
-                out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
-                continue
+                raise RuntimeError(f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}")
             d = json.loads(lines[-1])
             rf = d.get("roofline") or {}
             leg = {"workload": d["config"]["workload"], "metric": d["metric"], "ms_per_step": d["ms_per_step"],
