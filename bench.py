@@ -424,7 +424,10 @@ def ddp_report(args, net, model, fwd, dev, world, ddp_ms):
     out["gradient_bytes"] = gbytes
     out["buckets_per_step"] = None
     if tamd_ddp.STATS.get("buckets_reduced"):
-        out["buckets_per_step"] = tamd_ddp.STATS["buckets_reduced"] / max(args.steps + args.warmup, 1)
+        # (every step that reduced buckets so far: warm-up, the timed ones, the two of the verification and the two warm steps
+        # of its fall-back)
+        extra = getattr(args, "_untimed_ddp_steps", 0)
+        out["buckets_per_step"] = tamd_ddp.STATS["buckets_reduced"] / max(args.steps + args.warmup + extra, 1)
 
     def one_step(sync=True):
         ctx = net.no_sync() if not sync else torch.enable_grad()
@@ -718,9 +721,11 @@ def main():
         # own copies into the buckets, same batch.  Not bit-identical (or the check itself fails): the hand-over is switched off
         # on every rank -- the verdict is all-reduced -- and the run is timed on torch's copies; the line says so.
         ddp_preverify = ddp_verify_or_fall_back(args, net, model, fwd, dev, world)
+        args._untimed_ddp_steps = 2
         if ddp_preverify.get("disabled_zero_copy"):
             for _ in range(2):  # (warm the ordinary hand-over: its first step re-points the gradients at the buckets)
                 loss = step()
+            args._untimed_ddp_steps = 4
         barrier()
     run = step
     if args.hip_graph:
