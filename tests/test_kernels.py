@@ -4,6 +4,7 @@ unless the op's output rounding dominates (then 2^-8 relative = one bf16 ulp); i
 (embedding gather, label handling) are bit-exact.  Each test runs twice: under the CPU execution model
 (`emu`, not gpu) and on the MI355X (`hip`, gpu)."""
 import math
+import os
 
 import pytest
 import torch
@@ -880,6 +881,8 @@ def test_gemm_piece_placements_are_bit_identical(env):
     lib = ops.backend().lib
     if not hasattr(lib, "tamd_gemm_set_dbg"):
         pytest.skip("needs the diagnostic entry points (CPU execution model or libtamd_diag.so)")
+    if not env.big:
+        os.environ["TAMD_PERSIST_GRID"] = "2"  # (read once by the diagnostic build: three tiles per workgroup of the persistent walk)
     torch.manual_seed(61)
     dev = env.device
     m, n, k = (1536, 1024, 1280) if env.big else (512, 520, 768)  # (a multiple of four 64-deep stages: DBG 1024)
@@ -894,7 +897,7 @@ def test_gemm_piece_placements_are_bit_identical(env):
             assert rel_err(plain, ref) < 0.0036
             # (64 / 256 / 512: the round-5 placements, row-major A only -- the split hand-off of 512 is what the adversarial LDS-DMA
             # timing of the CPU model is for; 1024: round 6, hipBLASLt's three-barrier loop structure, every layout)
-            for dbg in (32, 128, 64, 256, 512, 1024, 2048, 1024 + 4096, 1024 + 8192, 1024 + 16384):  # (2048: the one-barrier ring forced where three barriers are the product)
+            for dbg in (32, 128, 64, 256, 512, 1024, 2048, 1024 + 4096, 1024 + 8192, 1024 + 16384, 32768):  # (32768: the persistent walk)  # (2048: the one-barrier ring forced where three barriers are the product)
                 lib.tamd_gemm_set_dbg(dbg)
                 assert torch.equal(ops.raw_gemm(*args, sched="fl", **kw), plain), (kw, dbg)
                 lib.tamd_gemm_set_dbg(0)

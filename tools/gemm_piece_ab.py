@@ -81,7 +81,7 @@ for name in args.shapes.split(","):
             if lay != 3 and args.placements:  # round 5: pieces behind the even pairs / pieces first / pieces first + split hand-off
                 arms += ["p1", "p2", "p3"]
             if args.three_barrier:
-                arms += ["b3", "b1", "b3p", "b3s", "b3c"]  # (three barriers (vendor table, one MFMA per gap) / the one-barrier ring, forced: one of them is what "fl" runs; the table rounded to MFMA pairs / SPREAD)
+                arms += ["b3", "b1", "b3p", "b3s", "b3c", "pw"]  # (three barriers (vendor table, one MFMA per gap) / the one-barrier ring, forced: one of them is what "fl" runs; the table rounded to MFMA pairs / SPREAD)
             if args.only:
                 arms = ["fl"] + [c for c in arms[1:] if c in args.only.split(",")]
         res = {c: [] for c in arms}

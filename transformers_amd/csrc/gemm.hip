@@ -654,7 +654,15 @@ __device__ __forceinline__ unsigned fl_frag_off_km(int c16, int lane) {
 // (the kernel body: `vbid` = the workgroup's index inside ITS product -- blockIdx.x for gemm_fl_kernel, the index behind the
 // product's first workgroup for gemm_fl_group_kernel)
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG>
-__device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) {
+// `pstride` (PERSIST instantiations, DBG bit 32768): the workgroup walks the tiles vbid, vbid + pstride, ... and requests stage 0 of
+// its NEXT tile before it starts the way out of the current one, so that the first-stage latency of a tile (and the dispatch of a
+// fresh workgroup) hides under the way out: the two-point fit of profiles/r06d_gemm_vs_hipblaslt_pmc.md prices prologue + way out
+// at ~4 stage-times per tile -- 6 % of a 64-stage tile.  The way out then stages above the first LDS buffer (offset 64 KiB).
+// Measured (profiles/r06m_gemm_piece_ab.jsonl; bit-identical; CPU model: three tiles per workgroup under adversarial LDS-DMA
+// timing): forward q|k|v +0.9 %, o_proj -1.4 %, gate|up +0.2 %, down -0.2 %; dW o_proj +1.2 %, gate|up +0.5 % -- level, like the
+// persistent walks of rounds 2 and 3.  Under the board's power cap (profiles/r06j_gemm_power.jsonl) an idle gap between tiles is
+// not lost time: the cycles it frees come back as clock.  Diagnostic library only (tamd_gemm_set_dbg(32768)).
+__device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid, const int pstride = 0) {
   TAMD_DYN_SMEM(smem);
   const int lane = threadIdx.x & 63;
   const int wave = wave_id_uniform();
@@ -662,10 +670,12 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   const int g4 = lane >> 4, l15 = lane & 15;
   TAMD_TIMELINE_BEGIN
   TAMD_CLOCK_BEGIN
+  constexpr bool PERSIST = (DBG & 32768) != 0;
+  static_assert(!PERSIST || (EPI != kEpiSplitK && EPI != kEpiSwiGLU && A_KM == B_KN), "persistent walk: three-barrier layouts, plain ways out");
   int tile_m, tile_n;
   const int split = (EPI == kEpiSplitK) ? (int)((unsigned)vbid % (unsigned)g.splits) : 0;
   gemm_tile_of_block(g, (EPI == kEpiSplitK) ? (int)((unsigned)vbid / (unsigned)g.splits) : vbid, &tile_m, &tile_n);
-  const int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
+  int64_t m0 = (int64_t)tile_m * kBM, n0 = (int64_t)tile_n * kBN;
   const T* A = reinterpret_cast<const T*>(g.A);
   const T* B = reinterpret_cast<const T*>(g.B);
 
@@ -687,12 +697,15 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   // Feed: buffer_load ... lds (tamd_device.h glds16_buf).  Wave-uniform operand base stepped per stage, loop-invariant
   // 32-bit lane offsets, one M0 per 4 pieces through the shared immediate.
   unsigned voff[16];  // byte offset from the operand base + 4096 - 1024*(piece & 3)
-  int64_t kinc_a = A_KM ? (int64_t)kXK * g.lda * 2 : kXK * 2;  // bytes per stage; 0 once parked
-  int64_t kinc_b = B_KN ? (int64_t)kXK * g.ldb * 2 : kXK * 2;
+  int64_t kinc_a, kinc_b;  // bytes per stage; 0 once parked
+  const char *base_a, *base_b;
+  auto tile_sources = [&]() __attribute__((always_inline)) {  // bases and lane offsets of the tile at (m0, n0)
+  kinc_a = A_KM ? (int64_t)kXK * g.lda * 2 : kXK * 2;
+  kinc_b = B_KN ? (int64_t)kXK * g.ldb * 2 : kXK * 2;
   // operand bases (tile origin - 4096 B so that no lane offset goes negative after the immediate is taken out)
-  const char* base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096 + (int64_t)st0 * kinc_a;
+  base_a = (const char*)(A_KM ? A + m0 : A + m0 * g.lda) - 4096 + (int64_t)st0 * kinc_a;
   const int64_t nb0 = (EPI == kEpiSwiGLU) ? 0 : n0;  // SwiGLU: per-lane offsets address the whole fused weight
-  const char* base_b = (const char*)(B_KN ? B + n0 : B + nb0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
+  base_b = (const char*)(B_KN ? B + n0 : B + nb0 * g.ldb) - 4096 + (int64_t)st0 * kinc_b;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int row = (wave * 8 + i) * 8 + (lane >> 3);
@@ -713,6 +726,8 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
     voff[i] = (unsigned)(oa * 2 + 4096 - (i & 3) * 1024);
     voff[8 + i] = (unsigned)(ob * 2 + 4096 - (i & 3) * 1024);
   }
+  };
+  tile_sources();
   // past the last stage: keep the load counts uniform and re-read the last valid stage (idempotent)
   auto park = [&]() __attribute__((always_inline)) {
     base_a -= kinc_a;
@@ -1051,12 +1066,23 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
       sched_fence();
     }
   };
+  int vb = vbid;     // PERSIST: the tile this workgroup is on
+  bool pre = false;  // PERSIST: stage 0 of the current tile was requested during the previous tile's way out
+  for (;;) {
+  if (PERSIST) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   // prologue: A_0 B_0 A_1 B_1 into half-slots 0..3
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     if (j == nst) park();
+    if (!(PERSIST && j == 0 && pre)) {
 #pragma unroll
-    for (int p = 0; p < 16; ++p) issue(p, 2 * j + (p >> 3));
+      for (int p = 0; p < 16; ++p) issue(p, 2 * j + (p >> 3));
+    }
   }
   if (PLACE == 4) {
     wait_vmcnt<16>();  // stage 0 has landed; stage 1 stays in flight (the first vmcnt(13) + barrier covers it)
@@ -1136,38 +1162,66 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid) 
   // (checked per instantiation with tools/gemm_isa.sh and tests/test_isa_lint.py: since the buffer-addressed way out of round 5 no
   // full-line instantiation has scratch -- the k-major residual / accumulate ones used to spill 5-17 registers)
   const int elane = lane_id_mbcnt();
+  // PERSIST: the way out is for the tile at (em0, en0); the sources move on to the next tile first and its stage 0 is requested
+  // into LDS buffer 0 (half-slots 0, 1), which every wave has finished reading (the barrier above); the way out stages above it
+  const int64_t em0 = m0, en0 = n0;
+  constexpr unsigned kStageBase = PERSIST ? 2u * kXHalf : 0u;
+  if (PERSIST) {
+    const int nxt = vb + pstride;
+    pre = nxt < g.tiles_m * g.tiles_n;
+    if (pre) {
+      gemm_tile_of_block(g, nxt, &tile_m, &tile_n);
+      m0 = (int64_t)tile_m * kBM;
+      n0 = (int64_t)tile_n * kBN;
+      tile_sources();
+#pragma unroll
+      for (int p = 0; p < 16; ++p) issue(p, p >> 3);
+    }
+    vb = nxt;
+  }
   if (EPI == kEpiSplitK) {  // fp32 partial tile: lane = output row, 4 consecutive columns per accumulator block
     float* ws = g.ws + (int64_t)split * g.M * g.N;
     const int l15 = elane & 15, g4 = elane >> 4;
 #pragma unroll
     for (int mb = 0; mb < 8; ++mb) {
-      const int64_t m = m0 + wm * 128 + mb * 16 + l15;
+      const int64_t m = em0 + wm * 128 + mb * 16 + l15;
 #pragma unroll
       for (int nb = 0; nb < 8; ++nb) {
-        const int64_t n = n0 + wn * 128 + nb * 16 + 4 * g4;
+        const int64_t n = en0 + wn * 128 + nb * 16 + 4 * g4;
         if (m < g.M && n < g.N)
           st16(ws + m * g.N + n, u32x4{f32_as_u32(acc[nb][mb][0]), f32_as_u32(acc[nb][mb][1]), f32_as_u32(acc[nb][mb][2]),
                                        f32_as_u32(acc[nb][mb][3])});
       }
     }
   } else if (EPI == kEpiSwiGLU) {
-    gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), m0 + wm * 128,
-                            (n0 >> 1) + wn * 64, elane);
+    gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), em0 + wm * 128,
+                            (en0 >> 1) + wn * 64, elane);
   } else {
     constexpr int E2 = (EPI == kEpiSplitK || EPI == kEpiSwiGLU) ? TAMD_EPI_NONE : EPI;
     if (A_KM && B_KN && (EPI == TAMD_EPI_NONE || EPI == TAMD_EPI_ACCUM)) {  // dW: the tile's segment (wave-uniform selects;
       GemmArgs gs = g;                                                        // ONE epilogue instance: a second one spills)
-      gs.C = gemm_seg_base<T>(g, m0);
-      gemm_epilogue16<T, E2, ACT>(gs, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+      gs.C = gemm_seg_base<T>(g, em0);
+      gemm_epilogue16<T, E2, ACT>(gs, acc, smem, kStageBase + (unsigned)wave * (64u * (4 * 32 * 2 + 16)), em0 + wm * 128, en0 + wn * 128,
+                                  elane);
     } else {
-      gemm_epilogue16<T, E2, ACT>(g, acc, smem, (unsigned)wave * (64u * (4 * 32 * 2 + 16)), m0 + wm * 128, n0 + wn * 128, elane);
+      gemm_epilogue16<T, E2, ACT>(g, acc, smem, kStageBase + (unsigned)wave * (64u * (4 * 32 * 2 + 16)), em0 + wm * 128, en0 + wn * 128,
+                                  elane);
     }
   }
+  if (!PERSIST || !pre) break;
+  wait_lgkmcnt0();  // every wave is done with its staging area before stage 1 of the next tile lands in half-slots 2, 3
+  raw_barrier();
+  }  // for (;;)
   TAMD_TIMELINE_END
 }
 template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
 __global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_kernel(GemmArgs g) {
   gemm_fl_body<T, A_KM, B_KN, EPI, ACT, DBG>(g, (int)blockIdx.x);
+}
+// the persistent walk: one workgroup per CU (grid = the device's CU count, a multiple of 8 so that blockIdx & 7 stays the XCD)
+template <typename T, bool A_KM, bool B_KN, int EPI, int ACT, int DBG = 0>
+__global__ __launch_bounds__(kFlThreads, 1) void gemm_fl_persist_kernel(GemmArgs g) {
+  gemm_fl_body<T, A_KM, B_KN, EPI, ACT, DBG | 32768>(g, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ============================================================================================ grouped launch
@@ -1421,6 +1475,7 @@ static int gemm_pp_launch(const GemmArgs& g, int flags, int epilogue, int act, h
   return gemm_pp_launch_epi<T, true, false>(g, epilogue, act, s);
 }
 
+constexpr int kPersistGrid = 256;  // one workgroup per CU of an MI355X (the split-K policy below counts the same 256)
 template <typename T, bool A_KM, bool B_KN>
 static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStream_t s) {
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
@@ -1432,6 +1487,21 @@ static int gemm_fl_launch_epi(const GemmArgs& g, int epilogue, int act, hipStrea
     else
       hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 128>), grid, block, (size_t)kXSmem, s, g);
     return launch_status();
+  }
+  if constexpr (A_KM == B_KN) {
+    if (dbg == 32768 && (epilogue == TAMD_EPI_NONE || epilogue == TAMD_EPI_RESIDUAL)) {  // the persistent walk (prefetch under the way out), forced
+      const int tiles = g.tiles_m * g.tiles_n;
+      static const int want = [] {  // (TAMD_PERSIST_GRID: the CPU model's test walks several tiles per workgroup on a 6-tile product)
+        const char* e = getenv("TAMD_PERSIST_GRID");
+        return e ? atoi(e) : kPersistGrid;
+      }();
+      dim3 pgrid((unsigned)(tiles < want ? tiles : want));
+      if (epilogue == TAMD_EPI_NONE)
+        hipLaunchKernelGGL((gemm_fl_persist_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE>), pgrid, block, (size_t)kXSmem, s, g);
+      else
+        hipLaunchKernelGGL((gemm_fl_persist_kernel<T, A_KM, B_KN, TAMD_EPI_RESIDUAL, TAMD_ACT_NONE>), pgrid, block, (size_t)kXSmem, s, g);
+      return launch_status();
+    }
   }
   if (dbg == 1024 + 16384 && epilogue == TAMD_EPI_NONE) {  // the vendor table with a counted wait at the stage boundary
     hipLaunchKernelGGL((gemm_fl_kernel<T, A_KM, B_KN, TAMD_EPI_NONE, TAMD_ACT_NONE, 1024 + 16384>), grid, block, (size_t)kXSmem, s, g);
