@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TAMD_ABI_VERSION 10
+#define TAMD_ABI_VERSION 11
 
 typedef void* tamd_stream_t; /* hipStream_t */
 
@@ -298,6 +298,15 @@ int tamd_gemm_colscale(const void* A, const void* B, void* C, const void* bias, 
  * GU may be NULL (inference: the projection outputs are never written to HBM).  K % 64 == 0, I % 8 == 0. */
 int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* ACT, int64_t M, int64_t I, int64_t K, int64_t ldx,
                      int64_t ldw, int64_t ldgu, int64_t ldact, int dtype, tamd_stream_t stream);
+
+/* ABI 11.  The backward of the same product as the way out of the down projection's dX GEMM (the derivative of
+ * models/llama/modeling_llama.py:174-176 with respect to gate_proj(x) and up_proj(x)):
+ *   d_act[M, I] = dY[M, K] . Wd[K, I]          Wd = down_proj.weight ([hidden = K, I] row-major), dY = the MLP output's gradient
+ *   dGU[M, 2I]  = [ d_act * up * silu'(gate) | d_act * silu(gate) ]      GU = the forward's gate | up columns (tamd_gemm_swiglu)
+ * rounded exactly as tamd_gemm(TAMD_GEMM_B_KN) followed by tamd_swiglu_bwd -- d_act never reaches memory (0.94 GB written and
+ * read back per Llama-3-8B layer at 8 x 4096 otherwise).  K % 64 == 0, I % 8 == 0; dGU must not alias GU. */
+int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* dGU, int64_t M, int64_t I, int64_t K,
+                         int64_t lddy, int64_t ldw, int64_t ldgu, int64_t lddgu, int dtype, tamd_stream_t stream);
 
 /* ------------------------------------------------------------------ attention (MFMA, flash-style) */
 

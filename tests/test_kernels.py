@@ -785,6 +785,39 @@ def test_gemm_swiglu_epilogue_is_bit_identical_to_unfused(env, dtype):
     assert torch.equal(o, gu_ref) and torch.equal(a, act_ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_swiglu_bwd_epilogue_is_bit_identical_to_unfused(env, dtype):
+    """The down projection's dX GEMM with the SiLU*up backward as its way out (tamd_gemm_swiglu_bwd) against the two kernels it
+    replaces in the fused Llama layer's backward (tamd_gemm with a k-major B, tamd_swiglu_bwd): same fp32 k-order, d_act rounded
+    at the same point, the same expressions -> same bits for d_gate and d_up; ragged token counts (a partial last row tile, a
+    wave whose rows lie wholly past M) and feature counts that are not a multiple of the tile.  Then against the fp32 derivative
+    of the reference's expression (modeling_llama.py:174-176) on the same rounded inputs."""
+    torch.manual_seed(37)
+    shapes = [(4096, 14336, 4096), (1000, 2816, 1024), (333, 1000, 512)] if env.big else [(130, 200, 64), (70, 72, 128)]
+    for t, inter, k in shapes:
+        dy = torch.randn(t, k).to(dtype).to(env.device)
+        wd = (torch.randn(k, inter) * k ** -0.5).to(dtype).to(env.device)
+        gu = torch.randn(t, 2 * inter).to(dtype).to(env.device)
+        assert ops.gemm_swiglu_bwd_supported(dy, wd, gu)
+        d_act = ops.raw_gemm(dy, wd, b_kn=True)
+        dgu_ref, _ = ops.raw_swiglu_bwd(gu, d_act)
+        gu_before = gu.clone()
+        dgu = ops.raw_gemm_swiglu_bwd(dy, wd, gu)
+        assert torch.equal(gu, gu_before)  # (the saved activations are read, never written)
+        assert torch.equal(dgu[:, :inter], dgu_ref[:, :inter]), (t, inter, k)
+        assert torch.equal(dgu[:, inter:], dgu_ref[:, inter:]), (t, inter, k)
+        gf = gu[:, :inter].float().requires_grad_(True)
+        uf = gu[:, inter:].float().requires_grad_(True)
+        (torch.nn.functional.silu(gf) * uf).backward(dy.float() @ wd.float())
+        eg, eu = rel_err(dgu[:, :inter], gf.grad), rel_err(dgu[:, inter:], uf.grad)
+        record("gemm_swiglu_bwd", f"{dtype}:{t}x{inter}x{k}:dgate", eg)
+        record("gemm_swiglu_bwd", f"{dtype}:{t}x{inter}x{k}:dup", eu)
+        assert eg < 8e-3 and eu < 8e-3, (eg, eu)
+    # a grid the library's policy would split along K (or a decode-sized product) stays on the two kernels
+    few = torch.randn(8, 64).to(dtype).to(env.device)
+    assert not ops.gemm_swiglu_bwd_supported(few, wd[:64], gu[:8])
+
+
 @pytest.mark.parametrize("cols", [128, 768, 1024])
 def test_dropout_add_layernorm(env, cols):
     """LayerNorm(dropout(x, p) + residual) with the mask drawn inside the norm kernel (BertSelfOutput / BertOutput in train

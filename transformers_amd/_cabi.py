@@ -14,7 +14,7 @@ TAMD_BF16, TAMD_F16, TAMD_F32 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_QUICK_GELU, ACT_SILU = 0, 1, 2, 3, 4
 GEMM_A_KM, GEMM_B_KN = 1, 2
 EPI_NONE, EPI_BIAS, EPI_RESIDUAL, EPI_BIAS_ACT, EPI_ACCUM = 0, 1, 2, 3, 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 P = c_void_p
 I64 = c_int64
@@ -89,6 +89,7 @@ SIGNATURES = {
     "tamd_gemm_group": (c_int, [P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "tamd_gemm_colscale": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, c_int, I64, c_float, c_int, P]),
     "tamd_gemm_swiglu": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
+    "tamd_gemm_swiglu_bwd": (c_int, [P, P, P, P, I64, I64, I64, I64, I64, I64, I64, c_int, P]),
     "tamd_dropout_hash": (ctypes.c_uint32, [ctypes.c_uint64, ctypes.c_uint64]),
     "tamd_attn_dropout_field": (ctypes.c_uint32, [ctypes.c_uint64] * 6),
     "tamd_attn_fwd": (c_int, [POINTER(AttnParams), P]),

@@ -103,6 +103,7 @@ struct GemmArgs {
   // [M, 2*n_half] gate|up output or nullptr when nothing will be differentiated
   void* C2;
   int64_t ldc2, n_half;
+  // SwiGLU-backward epilogue (kEpiSwiGLUBwd): N = n_half = I, R = the saved gate|up [M, 2I] (ldr), C = d_gate|d_up [M, 2I] (ldc)
   // column-scale epilogue (kEpiColScale): C[m, n] = round((acc + bias[n]) * (n < scale_cols ? col_scale : 1)) -- the query
   // columns of a q|k|v projection leave carrying the attention kernels' scale*log2(e) (tamd_attn_params.q_prescaled)
   int64_t scale_cols;
@@ -124,6 +125,7 @@ __device__ __forceinline__ void* gemm_seg_base(const GemmArgs& g, int64_t m0) {
 constexpr int kEpiSplitK = 100;
 constexpr int kEpiSwiGLU = 101;
 constexpr int kEpiColScale = 104;
+constexpr int kEpiSwiGLUBwd = 105;
 
 // the LlamaMLP inner product (models/llama/modeling_llama.py:174-176; same expression as swiglu_fwd_kernel in
 // elementwise.hip, so the fused epilogue and the stand-alone kernel agree bit for bit)
@@ -455,6 +457,84 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&
       const u32x4 v = lds_read16(smem, st_off + ACT_OFF + (unsigned)(it * 8 + (lane >> 3)) * ACT_ROWB + (unsigned)(lane & 7) * 16u);
       buf_store16_rng(C2w, act_bytes, ao, v);
       ao += act_step;
+    }
+    wave_lockstep_point();
+  }
+}
+
+// Backward of the SiLU*up product as the way out of the down projection's dX GEMM (gemm_fl_kernel<..., kEpiSwiGLUBwd>;
+// models/llama/modeling_llama.py:174-176 differentiated): the product is d_act[M, I] = dY . W_down, and instead of storing it
+// (0.94 GB at Llama-3-8B 8 x 4096) for swiglu_bwd_kernel to read back beside gate and up, the wave that holds a 128 x 128 piece
+// of it reads the same piece of gate and of up (R = the saved [M, 2I] gate|up matrix) and stores
+//     d_up   = round(d * round(silu(g)))          d_gate = round(round(d * u) * silu'(g))           d = round(acc)
+// to C = d_gate|d_up [M, 2I] -- the expressions and roundings of swiglu_bwd_kernel (elementwise.hip) on the rounded d_act, so
+// the two paths agree bit for bit.  Per 64 rows: all 32 gate / up loads of the half are in flight (32 KiB per wave) while the
+// accumulators are rounded and staged; then per wave instruction 4 rows x 16 slots of 8 features.
+__device__ __forceinline__ float gemm_dsilu(float x) {  // = dsilu_f of elementwise.hip
+  const float s = fast_sigmoid(x);
+  return s * (1.f + x * (1.f - s));
+}
+template <typename T>
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x4 (&acc)[8][8], char* smem, unsigned st_off,
+                                                         int64_t row0, int64_t col0, int lane) {
+  constexpr int ROWB = 128 * 2 + 16;
+  constexpr int NIT = 16;  // 64 rows, 4 per wave instruction
+  const int g4 = lane >> 4, l15 = lane & 15;
+  const int64_t I = g.n_half;
+  const int64_t rows_left = g.M - row0;  // (<= 0: this wave's rows lie wholly past a ragged M -- empty buffers)
+  const unsigned nrows = rows_left <= 0 ? 0u : (unsigned)(rows_left < 128 ? rows_left : 128);
+  const int lrow = lane >> 4, slot = lane & 15;
+  const bool col_ok = col0 + slot * 8 < I;
+  // (addressing as in gemm_epilogue_rows: wave-uniform buffer bases -- the up halves are the gate bases + I columns with the same
+  // byte count, so a row past M is out of range for both -- 32-bit lane offsets, the hardware's range check for the matrix edge)
+  const T* Gw = reinterpret_cast<const T*>(g.R) + row0 * g.ldr + col0;
+  const T* Uw = Gw + I;
+  T* DGw = reinterpret_cast<T*>(g.C) + row0 * g.ldc + col0;
+  T* DUw = DGw + I;
+  const unsigned r_bytes = nrows * (unsigned)g.ldr * 2u, r_step = col_ok ? 4u * (unsigned)g.ldr * 2u : 0u;
+  const unsigned r_off0 = col_ok ? ((unsigned)lrow * (unsigned)g.ldr + (unsigned)slot * 8u) * 2u : 0xfffffff0u;
+  const unsigned c_bytes = nrows * (unsigned)g.ldc * 2u, c_step = col_ok ? 4u * (unsigned)g.ldc * 2u : 0u;
+  const unsigned c_off0 = col_ok ? ((unsigned)lrow * (unsigned)g.ldc + (unsigned)slot * 8u) * 2u : 0xfffffff0u;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    u32x4 pg[NIT], pu[NIT];
+    unsigned ro = r_off0 + (unsigned)half * (unsigned)NIT * r_step;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      pg[it] = buf_load16_rng(Gw, r_bytes, ro);  // (outside the matrix: zeros)
+      pu[it] = buf_load16_rng(Uw, r_bytes, ro);
+      ro += r_step;
+    }
+    sched_fence();
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      const int nl = nb * 16 + 4 * g4;  // first of 4 consecutive local columns
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        const f32x4 a = acc[nb][half * 4 + m4];
+        lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
+                   u32x2{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3])});
+      }
+      sched_fence();  // (one column block at a time: see gemm_epilogue16)
+    }
+    wave_lockstep_point();  // wave-private region: this wave's writes are ordered before its reads
+    unsigned co = c_off0 + (unsigned)half * (unsigned)NIT * c_step;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const u32x4 v = lds_read16(smem, st_off + (unsigned)(it * 4 + lrow) * ROWB + (unsigned)slot * 16u);
+      float d[8], gg[8], uu[8], dg[8], du[8];
+      unpack16<T>(v, d);
+      unpack16<T>(pg[it], gg);
+      unpack16<T>(pu[it], uu);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float s = round_through<T>(gemm_silu(gg[e]));
+        du[e] = d[e] * s;
+        dg[e] = round_through<T>(d[e] * uu[e]) * gemm_dsilu(gg[e]);
+      }
+      buf_store16_rng(DGw, c_bytes, co, pack16<T>(dg));  // (outside the matrix: nothing is stored)
+      buf_store16_rng(DUw, c_bytes, co, pack16<T>(du));
+      co += c_step;
     }
     wave_lockstep_point();
   }
@@ -1196,8 +1276,11 @@ __device__ __forceinline__ void gemm_fl_body(const GemmArgs& g, const int vbid, 
   } else if (EPI == kEpiSwiGLU) {
     gemm_epilogue_swiglu<T>(g, acc, smem, (unsigned)wave * (64u * (128 * 2 + 16) + 64u * (64 * 2 + 16)), em0 + wm * 128,
                             (en0 >> 1) + wn * 64, elane);
+  } else if (EPI == kEpiSwiGLUBwd) {
+    gemm_epilogue_swiglu_bwd<T>(g, acc, smem, kStageBase + (unsigned)wave * (64u * (4 * 32 * 2 + 16)), em0 + wm * 128, en0 + wn * 128,
+                                elane);
   } else {
-    constexpr int E2 = (EPI == kEpiSplitK || EPI == kEpiSwiGLU) ? TAMD_EPI_NONE : EPI;
+    constexpr int E2 = (EPI == kEpiSplitK || EPI == kEpiSwiGLU || EPI == kEpiSwiGLUBwd) ? TAMD_EPI_NONE : EPI;
     if (A_KM && B_KN && (EPI == TAMD_EPI_NONE || EPI == TAMD_EPI_ACCUM)) {  // dW: the tile's segment (wave-uniform selects;
       GemmArgs gs = g;                                                        // ONE epilogue instance: a second one spills)
       gs.C = gemm_seg_base<T>(g, em0);
@@ -2021,6 +2104,30 @@ extern "C" int tamd_gemm_swiglu(const void* X, const void* Wgu, void* GU, void* 
   dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
   TAMD_DISPATCH_HALF(dtype, {
     hipLaunchKernelGGL((gemm_fl_kernel<T, false, false, kEpiSwiGLU, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
+                       TAMD_STREAM(stream), g);
+    return launch_status();
+  });
+  return TAMD_E_DTYPE;
+}
+
+// dX of the down projection of LlamaMLP with the SiLU*up backward as its way out (models/llama/modeling_llama.py:174-176
+// differentiated):   d_act = dY[M,K] . Wd[K,I]  (Wd = down_proj.weight, [hidden, I] row-major: the k-major B operand),
+//   dGU[M, 2I] = [ round(round(d_act * up) * silu'(gate)) | round(d_act * round(silu(gate))) ]      GU = the forward's gate|up
+// with the roundings of the unfused path (tamd_gemm with TAMD_GEMM_B_KN, then tamd_swiglu_bwd): results are bit-identical to it,
+// d_act never reaches memory.
+extern "C" int tamd_gemm_swiglu_bwd(const void* dY, const void* Wd, const void* GU, void* dGU, int64_t M, int64_t I, int64_t K,
+                                    int64_t lddy, int64_t ldw, int64_t ldgu, int64_t lddgu, int dtype, tamd_stream_t stream) {
+  if (!dY || !Wd || !GU || !dGU) return TAMD_E_NULL;
+  if (M <= 0 || I <= 0 || K <= 0) return TAMD_E_SHAPE;
+  if ((K % kXK) || (I % 8) || (lddy % 8) || (ldw % 8) || (ldgu % 8) || (lddgu % 8)) return TAMD_E_SHAPE;
+  if (!aligned16(dY) || !aligned16(Wd) || !aligned16(GU) || !aligned16(dGU)) return TAMD_E_ALIGN;
+  if ((int64_t)128 * ldgu * 2 >= ((int64_t)1 << 31) || (int64_t)128 * lddgu * 2 >= ((int64_t)1 << 31)) return TAMD_E_SHAPE;  // 32-bit buffer offsets
+  GemmArgs g;
+  gemm_fill_args(&g, dY, Wd, dGU, nullptr, GU, M, I, K, lddy, ldw, lddgu, ldgu);
+  g.n_half = I;
+  dim3 grid((unsigned)(g.tiles_m * g.tiles_n)), block(kFlThreads);
+  TAMD_DISPATCH_HALF(dtype, {
+    hipLaunchKernelGGL((gemm_fl_kernel<T, false, true, kEpiSwiGLUBwd, TAMD_ACT_NONE>), grid, block, (size_t)kXSmem,
                        TAMD_STREAM(stream), g);
     return launch_status();
   });

@@ -43,7 +43,7 @@ using OptTensor = std::optional<at::Tensor>;
   X(tamd_bert_embeddings_fwd) X(tamd_swiglu_fwd) X(tamd_swiglu_bwd) X(tamd_bias_act_fwd) X(tamd_bias_act_bwd)         \
   X(tamd_add) X(tamd_adamw_step) X(tamd_mt_sumsq) X(tamd_mt_norm_finish) X(tamd_mt_scale) X(tamd_mt_adamw_step) X(tamd_colsum_workspace_bytes) X(tamd_colsum) X(tamd_transpose)                      \
   X(tamd_cross_entropy_fwd) X(tamd_cross_entropy_bwd) X(tamd_gemm) X(tamd_gemm_workspace_bytes) X(tamd_gemm_ws)       \
-  X(tamd_gemm_swiglu) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_gemm_group_workspace_bytes) X(tamd_gemm_group) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
+  X(tamd_gemm_swiglu) X(tamd_gemm_swiglu_bwd) X(tamd_gemm_colscale) X(tamd_gemm_seg) X(tamd_gemm_group_workspace_bytes) X(tamd_gemm_group) X(tamd_attn_fwd) X(tamd_attn_bwd)   \
   X(tamd_attn_decode_workspace_bytes) X(tamd_attn_decode)
 
 struct Api {
@@ -767,6 +767,28 @@ std::tuple<Tensor, Tensor> k_gemm_swiglu(const Tensor& x2, const Tensor& wgu, bo
   return {gu, act};
 }
 
+// shapes the down projection's dX GEMM + SiLU*up backward epilogue takes (csrc/gemm.hip tamd_gemm_swiglu_bwd): full 256 x 256
+// grids only -- where the library's policy would split K or stream the product (few rows), the plain product + swiglu_bwd kernel
+bool gemm_swiglu_bwd_supported(const Tensor& dy, const Tensor& wd, const Tensor& gu) {
+  const int64_t k = wd.size(0), inter = wd.size(1), t = dy.size(0);
+  return half_type(dy) && wd.scalar_type() == dy.scalar_type() && gu.scalar_type() == dy.scalar_type() && k % 64 == 0 &&
+         inter % 8 == 0 && dy.stride(1) == 1 && wd.stride(1) == 1 && dy.stride(0) % 8 == 0 && wd.stride(0) % 8 == 0 &&
+         gu.is_contiguous() && gu.size(0) == t && gu.size(1) == 2 * inter && 128 * 2 * inter * 2 < ((int64_t)1 << 31) && t > 16 &&
+         api().tamd_gemm_workspace_bytes(t, inter, k, TAMD_GEMM_B_KN, TAMD_EPI_NONE) == 0;
+}
+
+// dy [T, K] (the MLP output's gradient), wd [K, I] = down_proj.weight, gu [T, 2I] = the forward's gate | up  ->  d_gu [T, 2I]
+Tensor k_gemm_swiglu_bwd(const Tensor& dy, const Tensor& wd, const Tensor& gu) {
+  Launch L({&dy, &wd, &gu});
+  const int64_t t = dy.size(0), k = dy.size(1), inter = wd.size(1);
+  Tensor dgu = at::empty({t, 2 * inter}, dy.options());
+  GemmTimerScope timer(2.0 * (double)t * (double)inter * (double)k,
+                       2.0 * ((double)t * k + (double)inter * k + (double)t * 2 * inter * 2.0), L.stream);
+  check(api().tamd_gemm_swiglu_bwd(ptr(dy), ptr(wd), ptr(gu), mptr(dgu), t, inter, k, dy.stride(0), wd.stride(0), 2 * inter,
+                                   2 * inter, code_of(dy), L.stream),
+        "tamd_gemm_swiglu_bwd");
+  return dgu;
+}
 
 // ---- attention
 void fill_attn_params(tamd_attn_params* ap, const Tensor& q, const Tensor& k, const Tensor& v, const Tensor& o,
@@ -1205,6 +1227,9 @@ bool env_flag(const char* name, bool dflt) {
 }
 const bool kFuseRopeBwd = env_flag("TAMD_FUSE_ROPE_BWD", true);
 const bool kSaveSwigluAct = env_flag("TAMD_SAVE_SWIGLU_ACT", true);
+//   TAMD_FUSE_SWIGLU_BWD=0 the SiLU*up backward as its own kernel behind the down projection's dX GEMM instead of that GEMM's way
+//                          out (A/B switch; +0.94 GB written and read back per layer)
+const bool kFuseSwigluBwd = env_flag("TAMD_FUSE_SWIGLU_BWD", true);
 // the rotary kernel hands the attention kernels queries that already carry scale*log2(e), applied before its one rounding
 // (include/tamd.h q_prescaled; 0: the attention kernels scale and re-round their operand themselves)
 const bool kRopePrescale = env_flag("TAMD_ROPE_PRESCALE", true);
@@ -1280,15 +1305,20 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   Tensor x = contig(h_in).view({t, hd});
   Tensor dh = contig(d_hout).view({t, hd});
   // ---- MLP
-  Tensor d_act = gemm_plain(dh, wd, false, true);  // [T, I]
   Tensor d_gu, act;
-  if (act_saved.numel()) {
-    d_gu = std::get<0>(k_swiglu_bwd(gu, d_act, false));
+  if (kFuseSwigluBwd && act_saved.numel() && gemm_swiglu_bwd_supported(dh, wd, gu)) {
+    // the SiLU*up backward as the way out of the dX GEMM: d_act [T, I] is never written (same bits as the two kernels below)
+    d_gu = k_gemm_swiglu_bwd(dh, wd, gu);
     act = act_saved;
   } else {
-    std::tie(d_gu, act) = k_swiglu_bwd(gu, d_act, true);
+    Tensor d_act = gemm_plain(dh, wd, false, true);  // [T, I]
+    if (act_saved.numel()) {
+      d_gu = std::get<0>(k_swiglu_bwd(gu, d_act, false));
+      act = act_saved;
+    } else {
+      std::tie(d_gu, act) = k_swiglu_bwd(gu, d_act, true);
+    }
   }
-  d_act = Tensor();
   // (the weight gradients whose tile grids end in a mostly empty dispatch round -- down_proj 3.5 rounds, q|k|v 1.5 -- go out as a
   // whole-rounds part + a split-K remainder: gemm_dw_balanced)
   Tensor dwd = to_dst ? (gemm_dw_balanced(dh, act, *dst_d), nothing(h_in)) : gemm_dw_balanced(dh, act);  // [hd, I]
@@ -1480,6 +1510,7 @@ TORCH_LIBRARY(tamd, m) {
   m.def("gemm_out(Tensor(a!) out, Tensor a, Tensor b, bool a_km=False, bool b_kn=False, Tensor? bias=None, "
         "Tensor? residual=None, int epilogue=0, int act=0, int sched=0) -> ()");
   m.def("gemm_swiglu(Tensor x2, Tensor wgu, bool need_gu=True) -> (Tensor, Tensor)");
+  m.def("gemm_swiglu_bwd(Tensor dy, Tensor wd, Tensor gu) -> Tensor");
   m.def("gemm_dw_segments(Tensor dy, Tensor x, Tensor(a!)[] segs) -> ()");
   m.def("gemm_dw_group(Tensor[] dy, Tensor[] x) -> Tensor[]");
   m.def("gemm_colscale(Tensor x2, Tensor w, Tensor? bias, int scale_cols, float col_scale) -> Tensor");
@@ -1571,6 +1602,7 @@ TORCH_LIBRARY(tamd, m) {
   m.impl("gemm", &op_gemm);                                          \
   m.impl("gemm_out", &op_gemm_out);                                  \
   m.impl("gemm_swiglu", &op_gemm_swiglu);                            \
+  m.impl("gemm_swiglu_bwd", &k_gemm_swiglu_bwd);                     \
   m.impl("attn_fwd", &op_attn_fwd);                                  \
   m.impl("attn_bwd", &op_attn_bwd);                                  \
   m.impl("attn_bwd_out", &op_attn_bwd_out);                          \

@@ -278,6 +278,23 @@ def raw_gemm_swiglu(x2, wgu, need_gu=True):
     return (gu if need_gu else None), act
 
 
+def gemm_swiglu_bwd_supported(dy, wd, gu) -> bool:
+    """Shapes the down projection's dX GEMM takes with the SiLU*up backward as its way out (csrc/gemm.hip tamd_gemm_swiglu_bwd):
+    full 256 x 256 grids; elsewhere the plain product + `raw_swiglu_bwd`.  Mirrored in torch_binding.cpp."""
+    k, inter = wd.shape
+    t = dy.shape[0]
+    return (dy.dtype in (torch.bfloat16, torch.float16) and wd.dtype == dy.dtype and gu.dtype == dy.dtype and k % 64 == 0
+            and inter % 8 == 0 and dy.stride(1) == 1 and wd.stride(1) == 1 and dy.stride(0) % 8 == 0 and wd.stride(0) % 8 == 0
+            and gu.is_contiguous() and tuple(gu.shape) == (t, 2 * inter) and 128 * 2 * inter * 2 < 2 ** 31 and t > 16
+            and gemm_workspace_bytes(t, inter, k, EPI_NONE, 2) == 0)  # (flags 2 = TAMD_GEMM_B_KN)
+
+
+def raw_gemm_swiglu_bwd(dy, wd, gu):
+    """dy [T, K], wd [K, I] = down_proj.weight, gu [T, 2I] = the forward's gate | up  ->  d_gu [T, 2I]; d_act = dy . wd is never
+    written.  Bit-identical to `raw_gemm(dy, wd, b_kn=True)` followed by `raw_swiglu_bwd`."""
+    return T.gemm_swiglu_bwd(dy, wd, gu)
+
+
 def raw_attn_fwd(q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None, seed_dev=None):
     """q [B,Sq,Hq,D], k/v [B,Sk,Hkv,D] (strided views fine) -> o [B,Sq,Hq,D] contiguous, lse [B,Hq,Sq] fp32."""
     o, lse = T.attn_fwd(q, k, v, float(scale), bool(causal), key_valid, need_lse, float(dropout_p),
@@ -385,6 +402,7 @@ register("gemm", lambda a, b, a_km=False, b_kn=False, bias=None, residual=None, 
 register("gemm_out", lambda out, a, b, a_km=False, b_kn=False, bias=None, residual=None, epilogue=0, act=0, sched=0: None)
 register("gemm_swiglu", lambda x2, wgu, need_gu=True: (x2.new_empty(x2.shape[0], wgu.shape[0]) if need_gu else _nothing(x2),
                                                        x2.new_empty(x2.shape[0], wgu.shape[0] // 2)))
+register("gemm_swiglu_bwd", lambda dy, wd, gu: torch.empty_like(gu))
 register("attn_fwd", lambda q, k, v, scale, causal, key_valid=None, need_lse=True, dropout_p=0.0, seed=0, q_start=None, seed_dev=None: (
     q.new_empty(q.shape), _f32(q, q.shape[0], q.shape[2], q.shape[1]) if need_lse else _nothing(q)))
 register("attn_bwd", lambda q, k, v, o, lse, dout, scale, causal, key_valid=None, dropout_p=0.0, seed=0, q_start=None,
