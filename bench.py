@@ -117,6 +117,31 @@ def gemm_traffic():
     return None
 
 
+def _swiglu_bwd_choices():
+    try:
+        from transformers_amd import _native
+
+        return _native.swiglu_bwd_choices()
+    except Exception as e:  # (never take the line down)
+        return f"unavailable: {e}"
+
+
+def fused_ways_out(gs, steps):
+    """The launches of the log that carry elementwise work of the backward in their way out (tamd_gemm_swiglu_bwd: the SiLU*up
+    backward inside the down projection's dX GEMM, one per decoder layer -- 3.76 GB of gate / up / d_gate / d_up traffic and ~18
+    VALU instructions per element where a plain way out stores 0.94 GB): `achieved` above counts their whole duration against the
+    product's FLOPs only; `frac_of_the_other_launches` is the same figure without them."""
+    n = gs.get("fused_bwd_launches", 0)
+    if not n:
+        return None
+    rest_ms, rest_fl = gs["ms"] - gs["fused_bwd_ms"], gs["flops"] - gs["fused_bwd_flops"]
+    return {"what": "SiLU*up backward in the way out of the down projection's dX GEMM (replaces swiglu_bwd_kernel, 0.87-0.94 ms "
+                    "per layer, and the d_act round trip through HBM)",
+            "launches_per_step": n // steps, "avg_launch_ms": gs["fused_bwd_ms"] / n,
+            "achieved_on_the_product_flops": gs["fused_bwd_flops"] / (gs["fused_bwd_ms"] * 1e-3) / 1e12,
+            "frac_of_the_other_launches": rest_fl / (rest_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS}
+
+
 class GemmTimer:
     """HIP-event timing of every MFMA-GEMM launch inside the timed region.  The launches are issued by the compiled ops
     (csrc/torch_binding.cpp), so the event pairs are recorded there -- on the launch stream, around each tamd_gemm /
@@ -797,6 +822,7 @@ def main():
                             avg_launch_tflop=gs["flops"] / gs["launches"] / 1e12,
                             avg_launch_algorithmic_bytes=gs["bytes"] / gs["launches"],
                             gemm_share_of_step_time=(gs["ms"] / roofline_steps) / (dt / args.steps * 1e3),
+                            fused_ways_out=fused_ways_out(gs, roofline_steps),
                             measured_on=("the timed steps" if use_timer else
                                          f"{roofline_steps} extra untimed steps after the timed region (event records off "
                                          "inside it)"))
@@ -816,6 +842,9 @@ def main():
             # GPU tensors served by a reference module's own forward (ATen / vendor kernels) inside the timed region
             "fallback_calls": sum(transformers_amd.fallback_calls().values()),
             "fallbacks": transformers_amd.fallback_calls(),
+            # the form of the SiLU*up backward the library MEASURED to be faster on this box, per shape (the dX GEMM's way out or
+            # GEMM + kernel: bit-identical; csrc/torch_binding.cpp swiglu_bwd_fused)
+            "swiglu_bwd": _swiglu_bwd_choices(),
             # forward-only decoder stacks replayed as one HIP graph (transformers_amd/graph_stack.py), whole run
             "stack_graph_replays": sum(m.__dict__["_tamd_stack"][0].replays for m in model.modules()
                                        if m.__dict__.get("_tamd_stack", (None, 1))[1] == 0),

@@ -12,5 +12,5 @@ for arm in "$a" "$b" "$a" "$b"; do
     grep -m1 '^{"metric' | python -c "
 import json, sys
 d = json.loads(sys.stdin.read())
-print(json.dumps({'$var': '$arm', 'ms_per_step': d['ms_per_step'], 'roofline_frac': d['roofline']['frac'], 'launches': d['roofline']['launches_per_step'], 'layer_forward_ms': (d.get('layer_forward') or {}).get('ms'), 'clock_GHz': d['roofline'].get('clock_probe', {}).get('clock_GHz'), 'loss': d['loss']}))" | tee -a $out/${tag}_ab.jsonl
+print(json.dumps({'$var': '$arm', 'ms_per_step': d['ms_per_step'], 'roofline_frac': d['roofline']['frac'], 'launches': d['roofline']['launches_per_step'], 'layer_forward_ms': (d.get('layer_forward') or {}).get('ms'), 'clock_GHz': d['roofline'].get('clock_probe', {}).get('clock_GHz'), 'loss': d['loss'], 'swiglu_bwd': d.get('swiglu_bwd'), 'fused_ways_out': d['roofline'].get('fused_ways_out')}))" | tee -a $out/${tag}_ab.jsonl
 done

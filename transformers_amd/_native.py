@@ -47,6 +47,8 @@ def load():
                                       ctypes.c_int]
     dll.tamd_torch_set_dw_balance.restype = ctypes.c_int
     dll.tamd_torch_set_dw_balance.argtypes = [ctypes.c_int]
+    dll.tamd_torch_swiglu_bwd_choice.restype = ctypes.c_int
+    dll.tamd_torch_swiglu_bwd_choice.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     dll.tamd_torch_gemm_log.argtypes = [ctypes.c_int]
     dll.tamd_torch_gemm_log_summary.restype = ctypes.c_int
     dll.tamd_torch_gemm_log_summary.argtypes = [ctypes.POINTER(ctypes.c_double)]
@@ -83,9 +85,22 @@ def gemm_log(on: bool) -> None:
     load().tamd_torch_gemm_log(int(bool(on)))
 
 
+def swiglu_bwd_choices():
+    """The measured choices between the two forms of the SiLU*up backward (csrc/torch_binding.cpp swiglu_bwd_fused), one dict per
+    shape seen: tokens, intermediate, hidden, form, and the two timings (0.0: pinned by TAMD_FUSE_SWIGLU_BWD or unmeasured)."""
+    dll, out, recs = load(), (ctypes.c_double * 6)(), []
+    for i in range(dll.tamd_torch_swiglu_bwd_choice(-1, None)):
+        dll.tamd_torch_swiglu_bwd_choice(i, out)
+        recs.append(dict(tokens=int(out[0]), intermediate=int(out[1]), hidden=int(out[2]),
+                         form="dX GEMM way out" if out[3] else "GEMM + swiglu_bwd kernel", fused_ms=out[4], two_kernels_ms=out[5]))
+    return recs
+
+
 def gemm_log_summary():
-    """-> dict(launches, flops, ms, bytes) of the recorded launches (synchronises their events, clears the log)."""
-    out = (ctypes.c_double * 4)()
+    """-> dict(launches, flops, ms, bytes; fused_bwd_launches / _flops / _ms: the launches among them that carry the SiLU*up
+    backward in their way out) of the recorded launches (synchronises their events, clears the log)."""
+    out = (ctypes.c_double * 8)()
     if load().tamd_torch_gemm_log_summary(out) != 0:
         raise TamdError("reading the GEMM event log failed")
-    return dict(launches=int(out[0]), flops=out[1], ms=out[2], bytes=out[3])
+    return dict(launches=int(out[0]), flops=out[1], ms=out[2], bytes=out[3], fused_bwd_launches=int(out[4]),
+                fused_bwd_flops=out[5], fused_bwd_ms=out[6])

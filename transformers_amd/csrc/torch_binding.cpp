@@ -119,6 +119,8 @@ Tensor f32_like(const Tensor& x, at::IntArrayRef shape) { return at::empty(shape
 struct GemmRecord {
   double flops, bytes;
   hipEvent_t start, stop;
+  bool fused_bwd;  // the launch carries the SiLU*up backward in its way out (tamd_gemm_swiglu_bwd): elementwise work, formerly a
+                   // kernel of its own, whose time the log counts and whose arithmetic it does not
 };
 std::atomic<bool> g_gemm_log{false};
 std::mutex g_gemm_log_mutex;
@@ -128,9 +130,10 @@ struct GemmTimerScope {
   bool on;
   GemmRecord rec{};
   hipStream_t s;
-  GemmTimerScope(double flops, double bytes, tamd_stream_t stream)
+  GemmTimerScope(double flops, double bytes, tamd_stream_t stream, bool fused_bwd = false)
       : on(g_gemm_log.load(std::memory_order_relaxed) && !api().emulated), s((hipStream_t)stream) {
     if (!on) return;
+    rec.fused_bwd = fused_bwd;
     // a launch being captured into a HIP graph (graph_stack.py, a user's torch.cuda.graph) has no duration of its own:
     // an event recorded there becomes a graph node and hipEventElapsedTime on it fails
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -783,11 +786,77 @@ Tensor k_gemm_swiglu_bwd(const Tensor& dy, const Tensor& wd, const Tensor& gu) {
   const int64_t t = dy.size(0), k = dy.size(1), inter = wd.size(1);
   Tensor dgu = at::empty({t, 2 * inter}, dy.options());
   GemmTimerScope timer(2.0 * (double)t * (double)inter * (double)k,
-                       2.0 * ((double)t * k + (double)inter * k + (double)t * 2 * inter * 2.0), L.stream);
+                       2.0 * ((double)t * k + (double)inter * k + (double)t * 2 * inter * 2.0), L.stream, true);
   check(api().tamd_gemm_swiglu_bwd(ptr(dy), ptr(wd), ptr(gu), mptr(dgu), t, inter, k, dy.stride(0), wd.stride(0), 2 * inter,
                                    2 * inter, code_of(dy), L.stream),
         "tamd_gemm_swiglu_bwd");
   return dgu;
+}
+
+// Which of the two bit-identical forms of the SiLU*up backward runs -- the dX GEMM's way out (tamd_gemm_swiglu_bwd) or GEMM +
+// swiglu_bwd_kernel -- is MEASURED, once per shape, on the operands of the first call.  Round 2 had this way out and retired it:
+// standalone and in a one-layer loop it was always ahead, inside the 32-layer model it ran 3.6 or 5.7 ms per launch depending on
+// the box and on what else had allocated memory (profiles/r02_regression_note.md: same ISA, same arguments; never explained).
+// The round-6 way out (buffer-addressed, four streams instead of five) was ahead on every box it has seen
+// (profiles/r06o_swiglu_bwd_ab.jsonl: 3.13 against 3.47 ms, Llama-3-8B step 1241.7 -> 1231.1 ms), but a kernel with a history
+// of a slow regime that only shows in the real model is chosen on the real model's tensors, not on faith: two HIP-event timings of
+// each form on the stream of the first backward (~25 ms, once; a stream being captured into a HIP graph, or the CPU execution
+// model, takes the fused form unmeasured).  TAMD_FUSE_SWIGLU_BWD=0 / 1 in the environment pins the choice.
+struct SwigluBwdChoice {
+  int64_t t, inter, k;
+  int dtype;
+  bool fused;
+  double fused_ms, two_ms;  // (0: pinned or unmeasured)
+};
+std::mutex g_swiglu_bwd_mutex;
+std::vector<SwigluBwdChoice> g_swiglu_bwd_choices;
+bool swiglu_bwd_fused(const Tensor& dy, const Tensor& wd, const Tensor& gu) {
+  static const int pinned = [] {
+    const char* e = getenv("TAMD_FUSE_SWIGLU_BWD");
+    return e == nullptr || *e == 0 ? -1 : (std::string(e) != "0" ? 1 : 0);
+  }();
+  if (pinned >= 0) return pinned == 1;
+  if (api().emulated) return true;
+  const int64_t t = dy.size(0), k = dy.size(1), inter = wd.size(1);
+  const int dtype = code_of(dy);
+  {
+    std::lock_guard<std::mutex> lock(g_swiglu_bwd_mutex);
+    for (const auto& c : g_swiglu_bwd_choices)
+      if (c.t == t && c.inter == inter && c.k == k && c.dtype == dtype) return c.fused;
+  }
+  Launch L({&dy, &wd, &gu});
+  hipStream_t s = (hipStream_t)L.stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return true;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return true;
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    return true;
+  }
+  const bool log_was = g_gemm_log.exchange(false);  // (the trial launches are not the step's GEMMs)
+  auto time_of = [&](auto&& run) {
+    double best = 1e30;
+    run();  // warm: code objects, workspace
+    for (int i = 0; i < 2; ++i) {
+      (void)hipEventRecord(e0, s);
+      run();
+      (void)hipEventRecord(e1, s);
+      float ms = 0.f;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.0;
+      best = ms < best ? ms : best;
+    }
+    return best;
+  };
+  const double fused_ms = time_of([&] { (void)k_gemm_swiglu_bwd(dy, wd, gu); });
+  const double two_ms = time_of([&] { (void)k_swiglu_bwd(gu, gemm_plain(dy, wd, false, true), false); });
+  g_gemm_log.store(log_was);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const bool fused = fused_ms < 0 || two_ms < 0 || fused_ms <= two_ms;
+  std::lock_guard<std::mutex> lock(g_swiglu_bwd_mutex);
+  g_swiglu_bwd_choices.push_back({t, inter, k, dtype, fused, fused_ms < 0 ? 0.0 : fused_ms, two_ms < 0 ? 0.0 : two_ms});
+  return fused;
 }
 
 // ---- attention
@@ -1227,9 +1296,8 @@ bool env_flag(const char* name, bool dflt) {
 }
 const bool kFuseRopeBwd = env_flag("TAMD_FUSE_ROPE_BWD", true);
 const bool kSaveSwigluAct = env_flag("TAMD_SAVE_SWIGLU_ACT", true);
-//   TAMD_FUSE_SWIGLU_BWD=0 the SiLU*up backward as its own kernel behind the down projection's dX GEMM instead of that GEMM's way
-//                          out (A/B switch; +0.94 GB written and read back per layer)
-const bool kFuseSwigluBwd = env_flag("TAMD_FUSE_SWIGLU_BWD", true);
+//   TAMD_FUSE_SWIGLU_BWD   0: the SiLU*up backward as its own kernel behind the down projection's dX GEMM; 1: as that GEMM's way
+//                          out; unset: MEASURED on first use per shape (swiglu_bwd_fused below)
 // the rotary kernel hands the attention kernels queries that already carry scale*log2(e), applied before its one rounding
 // (include/tamd.h q_prescaled; 0: the attention kernels scale and re-round their operand themselves)
 const bool kRopePrescale = env_flag("TAMD_ROPE_PRESCALE", true);
@@ -1306,7 +1374,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> op_llama_laye
   Tensor dh = contig(d_hout).view({t, hd});
   // ---- MLP
   Tensor d_gu, act;
-  if (kFuseSwigluBwd && act_saved.numel() && gemm_swiglu_bwd_supported(dh, wd, gu)) {
+  if (act_saved.numel() && gemm_swiglu_bwd_supported(dh, wd, gu) && swiglu_bwd_fused(dh, wd, gu)) {
     // the SiLU*up backward as the way out of the dX GEMM: d_act [T, I] is never written (same bits as the two kernels below)
     d_gu = k_gemm_swiglu_bwd(dh, wd, gu);
     act = act_saved;
@@ -1691,11 +1759,24 @@ int tamd_torch_dw_cut(long long m, long long n, long long k, long long* at, int 
   if (at) *at = c.at;
   return c.axis;
 }
+// The measured choices of swiglu_bwd_fused (bench.py reports them): record i -> out[0..5] = tokens, I, K, fused (1 / 0),
+// fused ms, two-kernel ms; returns the number of records
+int tamd_torch_swiglu_bwd_choice(int i, double* out) {
+  std::lock_guard<std::mutex> lock(g_swiglu_bwd_mutex);
+  const int n = (int)g_swiglu_bwd_choices.size();
+  if (i >= 0 && i < n && out != nullptr) {
+    const SwigluBwdChoice& c = g_swiglu_bwd_choices[(size_t)i];
+    out[0] = (double)c.t, out[1] = (double)c.inter, out[2] = (double)c.k, out[3] = c.fused ? 1.0 : 0.0;
+    out[4] = c.fused_ms, out[5] = c.two_ms;
+  }
+  return n;
+}
 // A/B switch of the cut (on by default); returns the previous setting
 int tamd_torch_set_dw_balance(int on) { return g_dw_balance.exchange(on != 0) ? 1 : 0; }
 
 // GEMM event log (bench.py `roofline`): on / off; the summary synchronises the recorded events and clears the log.
-//   out[0] launches, out[1] sum of algorithmic FLOPs, out[2] sum of event durations (ms), out[3] sum of algorithmic bytes
+//   out[0] launches, out[1] sum of algorithmic FLOPs, out[2] sum of event durations (ms), out[3] sum of algorithmic bytes;
+//   out[4..6] launches / FLOPs / ms of the launches among them that carry the SiLU*up backward in their way out
 void tamd_torch_gemm_log(int on) {
   if (on) {
     std::lock_guard<std::mutex> lock(g_gemm_log_mutex);
@@ -1709,7 +1790,7 @@ void tamd_torch_gemm_log(int on) {
 }
 int tamd_torch_gemm_log_summary(double* out) {
   std::lock_guard<std::mutex> lock(g_gemm_log_mutex);
-  out[0] = out[1] = out[2] = out[3] = 0.0;
+  for (int i = 0; i < 7; ++i) out[i] = 0.0;
   for (auto& r : g_gemm_records) {
     float ms = 0.f;
     if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) return -1;
@@ -1717,6 +1798,11 @@ int tamd_torch_gemm_log_summary(double* out) {
     out[1] += r.flops;
     out[2] += ms;
     out[3] += r.bytes;
+    if (r.fused_bwd) {
+      out[4] += 1.0;
+      out[5] += r.flops;
+      out[6] += ms;
+    }
     (void)hipEventDestroy(r.start);
     (void)hipEventDestroy(r.stop);
   }
