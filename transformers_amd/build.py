@@ -74,8 +74,26 @@ def _build(lib: Path, sources, obj_dir: Path, defines, force: bool, verbose: boo
     hipcc = _hipcc()
     obj_dir.mkdir(parents=True, exist_ok=True)
     objs = [obj_dir / (s.stem + ".o") for s in srcs]
+    # per object: recompiled when ITS source, any header / .inc (conservatively: all of them), the flags or the defines changed --
+    # gemm.hip alone takes ~13 minutes, and a change to norm.hip should not pay for it
+    shared = [d for d in deps if d not in srcs]
+
+    def obj_digest(src: Path) -> str:
+        extra = os.environ.get(f"TAMD_FLAGS_{src.stem}", None)
+        extra = extra.split() if extra is not None else PER_SOURCE_FLAGS.get(src.name, [])
+        return _digest([src] + shared) + " ".join(defines) + " ".join(extra)
+
+    def one(so) -> None:
+        src, obj = so
+        ostamp = obj.with_suffix(".stamp")
+        d = obj_digest(src)
+        if not force and obj.exists() and ostamp.exists() and ostamp.read_text() == d:
+            return
+        _compile(hipcc, src, obj, verbose, defines)
+        ostamp.write_text(d)
+
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        list(ex.map(lambda so: _compile(hipcc, so[0], so[1], verbose, defines), zip(srcs, objs)))
+        list(ex.map(one, zip(srcs, objs)))
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(lib), *map(str, objs)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
