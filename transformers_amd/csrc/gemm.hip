@@ -468,17 +468,92 @@ __device__ __forceinline__ void gemm_epilogue_swiglu(const GemmArgs& g, f32x4 (&
 // of it reads the same piece of gate and of up (R = the saved [M, 2I] gate|up matrix) and stores
 //     d_up   = round(d * round(silu(g)))          d_gate = round(round(d * u) * silu'(g))           d = round(acc)
 // to C = d_gate|d_up [M, 2I] -- the expressions and roundings of swiglu_bwd_kernel (elementwise.hip) on the rounded d_act, so
-// the two paths agree bit for bit.  Per 64 rows: all 32 gate / up loads of the half are in flight (32 KiB per wave) while the
-// accumulators are rounded and staged; then per wave instruction 4 rows x 16 slots of 8 features.
+// the two paths agree bit for bit.  Per 64 rows the accumulators are rounded and staged in the wave's LDS region; then per wave
+// instruction 4 rows x 16 slots of 8 features, in quarters of 32 rows whose gate / up loads run one quarter ahead.
 __device__ __forceinline__ float gemm_dsilu(float x) {  // = dsilu_f of elementwise.hip
   const float s = fast_sigmoid(x);
   return s * (1.f + x * (1.f - s));
+}
+// the SiLU*up backward of one packed pair (element 2i in the low half of the word, 2i + 1 in the high half): the scalar
+// expressions of swiglu_bwd_kernel per element, written on two-element vectors so that the multiplies and adds of a pair are ONE
+// packed instruction each and a word is unpacked and re-packed as a unit (left to itself the vectoriser paired element i of
+// word 0 with element i of word 1 and paid four shuffles per two words to put the halves back: 18 -> 14 instructions per element)
+template <typename T>
+__device__ __forceinline__ void gemm_swiglu_bwd_pair(unsigned dw, unsigned gw, unsigned uw, unsigned* dgw, unsigned* duw) {
+  float d0, d1, g0, g1, u0, u1, a0, a1, b0, b1;
+  unpack2<T>(dw, d0, d1);
+  unpack2<T>(gw, g0, g1);
+  unpack2<T>(uw, u0, u1);
+  const f32x2 d = {d0, d1}, g = {g0, g1}, u = {u0, u1};
+  const f32x2 t = g * -1.44269504088896340736f;  // fast_sigmoid (tamd_device.h), two at a time
+  const f32x2 den = 1.f + f32x2{fast_exp2(t.x), fast_exp2(t.y)};
+  const f32x2 sig = {fast_rcp(den.x), fast_rcp(den.y)};
+  const f32x2 sl = g * sig;                      // gemm_silu
+  unpack2<T>(pack2<T>(sl.x, sl.y), a0, a1);      // round(silu(g))
+  const f32x2 rs = {a0, a1};
+  const f32x2 du = d * rs;
+  const f32x2 tu = d * u;
+  unpack2<T>(pack2<T>(tu.x, tu.y), b0, b1);      // round(d * u)
+  const f32x2 rt = {b0, b1};
+  const f32x2 ds = sig * (1.f + g * (1.f - sig));  // gemm_dsilu
+  const f32x2 dg = rt * ds;
+  *dgw = pack2<T>(dg.x, dg.y);
+  *duw = pack2<T>(du.x, du.y);
+}
+// (plain functions with everything passed by value, not lambdas: through a by-reference closure hipcc lost the wave-uniformity
+// of the buffer bases and wrapped every load and store in a waterfall loop -- 259 v_readfirstlane, 65 exec-masked loops)
+constexpr int kSwbQIT = 8;  // a quarter = 32 rows = 8 wave instructions of 4 rows x 16 slots
+template <typename T>
+__device__ __forceinline__ void gemm_swb_request(u32x4 (&pg)[kSwbQIT], u32x4 (&pu)[kSwbQIT], const T* Gw, const T* Uw,
+                                                 unsigned r_bytes, unsigned ro, unsigned r_step) {
+#pragma unroll
+  for (int it = 0; it < kSwbQIT; ++it) {
+    pg[it] = buf_load16_rng(Gw, r_bytes, ro);  // (outside the matrix: zeros)
+    pu[it] = buf_load16_rng(Uw, r_bytes, ro);
+    ro += r_step;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void gemm_swb_finish(const u32x4 (&pg)[kSwbQIT], const u32x4 (&pu)[kSwbQIT], const char* smem,
+                                                unsigned lds_off, T* DGw, T* DUw, unsigned c_bytes, unsigned co,
+                                                unsigned c_step) {
+  constexpr int ROWB = 128 * 2 + 16;
+#pragma unroll
+  for (int it = 0; it < kSwbQIT; ++it) {
+    const u32x4 v = lds_read16(smem, lds_off + (unsigned)(it * 4) * ROWB);
+    u32x4 dgv, duv;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      unsigned a, b;
+      gemm_swiglu_bwd_pair<T>(v[w], pg[it][w], pu[it][w], &a, &b);
+      dgv[w] = a;
+      duv[w] = b;
+    }
+    buf_store16_rng(DGw, c_bytes, co, dgv);  // (outside the matrix: nothing is stored)
+    buf_store16_rng(DUw, c_bytes, co, duv);
+    co += c_step;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void gemm_swb_stage(f32x4 (&acc)[8][8], int half, char* smem, unsigned st_off, int g4, int l15) {
+  constexpr int ROWB = 128 * 2 + 16;
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb) {
+    const int nl = nb * 16 + 4 * g4;  // first of 4 consecutive local columns
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+      const f32x4 a = acc[nb][half * 4 + m4];
+      lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
+                 u32x2{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3])});
+    }
+    sched_fence();  // (one column block at a time: see gemm_epilogue16)
+  }
 }
 template <typename T>
 __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x4 (&acc)[8][8], char* smem, unsigned st_off,
                                                          int64_t row0, int64_t col0, int lane) {
   constexpr int ROWB = 128 * 2 + 16;
-  constexpr int NIT = 16;  // 64 rows, 4 per wave instruction
+  constexpr int QIT = kSwbQIT;
   const int g4 = lane >> 4, l15 = lane & 15;
   const int64_t I = g.n_half;
   const int64_t rows_left = g.M - row0;  // (<= 0: this wave's rows lie wholly past a ragged M -- empty buffers)
@@ -495,49 +570,34 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmArgs& g, f32x
   const unsigned r_off0 = col_ok ? ((unsigned)lrow * (unsigned)g.ldr + (unsigned)slot * 8u) * 2u : 0xfffffff0u;
   const unsigned c_bytes = nrows * (unsigned)g.ldc * 2u, c_step = col_ok ? 4u * (unsigned)g.ldc * 2u : 0u;
   const unsigned c_off0 = col_ok ? ((unsigned)lrow * (unsigned)g.ldc + (unsigned)slot * 8u) * 2u : 0xfffffff0u;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    u32x4 pg[NIT], pu[NIT];
-    unsigned ro = r_off0 + (unsigned)half * (unsigned)NIT * r_step;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      pg[it] = buf_load16_rng(Gw, r_bytes, ro);  // (outside the matrix: zeros)
-      pu[it] = buf_load16_rng(Uw, r_bytes, ro);
-      ro += r_step;
-    }
-    sched_fence();
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb) {
-      const int nl = nb * 16 + 4 * g4;  // first of 4 consecutive local columns
-#pragma unroll
-      for (int m4 = 0; m4 < 4; ++m4) {
-        const f32x4 a = acc[nb][half * 4 + m4];
-        lds_write8(smem, st_off + (unsigned)(m4 * 16 + l15) * ROWB + (unsigned)nl * 2u,
-                   u32x2{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3])});
-      }
-      sched_fence();  // (one column block at a time: see gemm_epilogue16)
-    }
-    wave_lockstep_point();  // wave-private region: this wave's writes are ordered before its reads
-    unsigned co = c_off0 + (unsigned)half * (unsigned)NIT * c_step;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const u32x4 v = lds_read16(smem, st_off + (unsigned)(it * 4 + lrow) * ROWB + (unsigned)slot * 16u);
-      float d[8], gg[8], uu[8], dg[8], du[8];
-      unpack16<T>(v, d);
-      unpack16<T>(pg[it], gg);
-      unpack16<T>(pu[it], uu);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float s = round_through<T>(gemm_silu(gg[e]));
-        du[e] = d[e] * s;
-        dg[e] = round_through<T>(d[e] * uu[e]) * gemm_dsilu(gg[e]);
-      }
-      buf_store16_rng(DGw, c_bytes, co, pack16<T>(dg));  // (outside the matrix: nothing is stored)
-      buf_store16_rng(DUw, c_bytes, co, pack16<T>(du));
-      co += c_step;
-    }
-    wave_lockstep_point();
-  }
+  const unsigned lds_q0 = st_off + (unsigned)lrow * ROWB + (unsigned)slot * 16u, lds_q1 = lds_q0 + 32u * ROWB;
+  // The 128 rows go out as four quarters, the gate / up loads of quarter q + 1 requested BEFORE quarter q is computed and stored
+  // (two register sets of 16 loads: 16 KiB per wave always in flight under ~900 VALU instructions).  Measured LEVEL with the first
+  // version (all 32 loads of a half issued and waited for together, 18 instructions per element): the launch costs the plain
+  // product + 0.47-0.50 ms either way (profiles/r06o_, r06r_gemm_swiglu_bwd_ab.jsonl) = the way out's extra 2.8 GB at ~6 TB/s --
+  // the 256 workgroups of a round reach their ways out together, so it is HBM time with no K loop beside it, not
+  // load latency or arithmetic.  Kept for the smaller code (4040 against 4600 instructions per wave).
+  u32x4 pga[QIT], pua[QIT], pgb[QIT], pub[QIT];
+  gemm_swb_request<T>(pga, pua, Gw, Uw, r_bytes, r_off0, r_step);
+  sched_fence();
+  gemm_swb_stage<T>(acc, 0, smem, st_off, g4, l15);  // d_act rounded as the plain way out stores it
+  wave_lockstep_point();  // wave-private region: this wave's writes are ordered before its reads
+  gemm_swb_request<T>(pgb, pub, Gw, Uw, r_bytes, r_off0 + (unsigned)QIT * r_step, r_step);
+  sched_fence();
+  gemm_swb_finish<T>(pga, pua, smem, lds_q0, DGw, DUw, c_bytes, c_off0, c_step);
+  sched_fence();
+  gemm_swb_request<T>(pga, pua, Gw, Uw, r_bytes, r_off0 + (unsigned)(2 * QIT) * r_step, r_step);
+  sched_fence();
+  gemm_swb_finish<T>(pgb, pub, smem, lds_q1, DGw, DUw, c_bytes, c_off0 + (unsigned)QIT * c_step, c_step);
+  wave_lockstep_point();
+  gemm_swb_stage<T>(acc, 1, smem, st_off, g4, l15);
+  wave_lockstep_point();
+  gemm_swb_request<T>(pgb, pub, Gw, Uw, r_bytes, r_off0 + (unsigned)(3 * QIT) * r_step, r_step);
+  sched_fence();
+  gemm_swb_finish<T>(pga, pua, smem, lds_q0, DGw, DUw, c_bytes, c_off0 + (unsigned)(2 * QIT) * c_step, c_step);
+  sched_fence();
+  gemm_swb_finish<T>(pgb, pub, smem, lds_q1, DGw, DUw, c_bytes, c_off0 + (unsigned)(3 * QIT) * c_step, c_step);
+  wave_lockstep_point();
 }
 
 // ============================================================================================ ping-pong kernel
