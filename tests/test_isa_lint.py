@@ -157,7 +157,7 @@ def test_untracked_lds_reads_are_not_touched_before_their_wait(src, flags, defin
         # and a third: scratch.  The 256 x 256 kernel runs 256 + 256 registers per lane; an instantiation that spills is
         # throttled in how many of its waves a CU runs (and a spilled untracked fragment is the hazard above).  Round 4 shipped
         # one for a day: a second copy of the epilogue for segmented outputs cost the Llama dW kernel 4 spilled VGPRs.
-        # Checked: the instantiations of the Llama step (plain / split-K / SwiGLU / rotary epilogues in every layout, the
+        # Checked: the instantiations of the Llama step (plain / split-K / SwiGLU forward and backward (105) / rotary epilogues in every layout, the
         # row-major residual one) and the grouped launches.  (The k-major residual / accumulate epilogues hold a half's
         # residual rows beside 256 accumulators and spill 5 .. 17 registers on the way out: known, outside the K loop.)
         usage = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", r.stderr, flags=re.S)
@@ -166,11 +166,12 @@ def test_untracked_lds_reads_are_not_touched_before_their_wait(src, flags, defin
         def must_be_clean(n):
             m = re.search(r"gemm_fl_kernelINS_\w+?_tELb([01])ELb([01])ELi(\d+)ELi\d+ELi0EEEvNS_8GemmArgs", n)
             if m:
-                return int(m.group(3)) in (0, 100, 101, 103) or (m.group(1) == "0" and m.group(2) == "0")
+                return int(m.group(3)) in (0, 100, 101, 103, 105) or (m.group(1) == "0" and m.group(2) == "0")
             m = re.search(r"gemm_fl_group_kernelINS_\w+?_tELb[01]ELb[01]ELi(\d+)EEEvNS_13GemmGroupArgs", n)
             return bool(m) and int(m.group(1)) in (0, 100)
 
         seen = [n for n, _ in usage if must_be_clean(n)]
         assert len(seen) >= 8, seen
         spilled = [f"{n}: {b} B/lane" for n, b in usage if must_be_clean(n) and int(b) > 0]
+        assert any("ELi105E" in n for n in seen), "the SiLU*up backward way out (tamd_gemm_swiglu_bwd) was not checked"
         assert not spilled, "full-line GEMM kernels with scratch:\n" + "\n".join(spilled)

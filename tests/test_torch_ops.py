@@ -202,6 +202,36 @@ def test_llama_layer_saved_swiglu_product_matches_rematerialised(env, monkeypatc
         assert torch.equal(grads[0][n], grads[1][n]), n
 
 
+def test_swiglu_bwd_form_is_measured_on_the_device(env):
+    """Which of the two bit-identical forms of the SiLU*up backward runs (the dX GEMM's way out or GEMM + kernel) is measured
+    on the operands of the first backward of each shape (torch_binding.cpp swiglu_bwd_fused; round 2's slow regime of the fused
+    form, profiles/r02_regression_note.md): on the GPU the record carries both timings and the faster form; the CPU execution
+    model has no clock and takes the fused form unrecorded."""
+    import os
+
+    import transformers_amd
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers_amd import _native
+
+    torch.manual_seed(5)
+    cfg = LlamaConfig(vocab_size=128, hidden_size=192, intermediate_size=320, num_hidden_layers=1, num_attention_heads=3,
+                      num_key_value_heads=1, head_dim=64, max_position_embeddings=64, attn_implementation="eager")
+    m = transformers_amd.accelerate(LlamaForCausalLM(cfg).bfloat16().to(env.device)).train()
+    ids = torch.randint(0, 128, (2, 40)).to(env.device)
+    before = len(_native.swiglu_bwd_choices())
+    m(input_ids=ids, labels=ids, use_cache=False).loss.backward()
+    recs = [r for r in _native.swiglu_bwd_choices() if (r["tokens"], r["intermediate"], r["hidden"]) == (80, 320, 192)]
+    if env.big and not os.environ.get("TAMD_FUSE_SWIGLU_BWD"):
+        assert len(recs) == 1 and recs[0]["fused_ms"] > 0 and recs[0]["two_kernels_ms"] > 0, recs
+        faster = "dX GEMM way out" if recs[0]["fused_ms"] <= recs[0]["two_kernels_ms"] else "GEMM + swiglu_bwd kernel"
+        assert recs[0]["form"] == faster
+        m.zero_grad(set_to_none=True)
+        m(input_ids=ids, labels=ids, use_cache=False).loss.backward()  # decided once per shape
+        assert len(_native.swiglu_bwd_choices()) == before + 1
+    elif not env.big:
+        assert not recs
+
+
 def test_padded_vocab_head_matches_fp32_autograd(env):
     """BERT's MLM head at a vocabulary that is not a multiple of 8 (modeling_bert.py:483-496, 970-975): scores, loss and
     the gradients of hidden / tied weight / bias against torch autograd in fp32 -- through the loss, through a custom
