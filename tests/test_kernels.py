@@ -812,7 +812,7 @@ def test_gemm_swiglu_bwd_epilogue_is_bit_identical_to_unfused(env, dtype):
         eg, eu = rel_err(dgu[:, :inter], gf.grad), rel_err(dgu[:, inter:], uf.grad)
         record("gemm_swiglu_bwd", f"{dtype}:{t}x{inter}x{k}:dgate", eg)
         record("gemm_swiglu_bwd", f"{dtype}:{t}x{inter}x{k}:dup", eu)
-        assert eg < 8e-3 and eu < 8e-3, (eg, eu)
+        assert eg < 6e-3 and eu < 6e-3, (eg, eu)
     # a grid the library's policy would split along K (or a decode-sized product) stays on the two kernels
     few = torch.randn(8, 64).to(dtype).to(env.device)
     assert not ops.gemm_swiglu_bwd_supported(few, wd[:64], gu[:8])
@@ -1151,7 +1151,9 @@ def test_gemv_decode_projections(env):
     for (n, k) in shapes:
         w = (torch.randn(n, k) * 0.05).bfloat16().to(dev)
         bias = torch.randn(n).bfloat16().to(dev)
-        for m in (1, 2, 3, 4, 5, 8, 13, 16):  # 1 .. 4: the VALU kernel, 5 .. 16: the MFMA one
+        # 1 .. 4: the VALU kernel, 5 .. 16: the MFMA one (the CPU model takes the edges of both ranges: every row count on the
+        # widest shapes was 100 s of the CPU suite)
+        for m in ((1, 2, 3, 4, 5, 8, 13, 16) if env.big or n < 16384 else (1, 4, 5, 16)):
             xbuf = torch.randn(m, 2 * k).bfloat16().to(dev)
             x = xbuf[:, :k]  # row stride 2k
             res = torch.randn(m, n).bfloat16().to(dev)

@@ -848,8 +848,16 @@ bool swiglu_bwd_fused(const Tensor& dy, const Tensor& wd, const Tensor& gu) {
     }
     return best;
   };
-  const double fused_ms = time_of([&] { (void)k_gemm_swiglu_bwd(dy, wd, gu); });
-  const double two_ms = time_of([&] { (void)k_swiglu_bwd(gu, gemm_plain(dy, wd, false, true), false); });
+  double fused_ms = -1.0, two_ms = -1.0;
+  try {  // (the trials allocate their outputs: out of memory in the middle of a first backward leaves the choice unmeasured)
+    fused_ms = time_of([&] { (void)k_gemm_swiglu_bwd(dy, wd, gu); });
+    two_ms = time_of([&] { (void)k_swiglu_bwd(gu, gemm_plain(dy, wd, false, true), false); });
+  } catch (const c10::Error&) {
+    g_gemm_log.store(log_was);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return true;
+  }
   g_gemm_log.store(log_was);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
