@@ -70,6 +70,32 @@ inline float shfl_xor_f32(float v, int mask) {
   memcpy(&r, hipemu::cur_wave().out[lane], 4);
   return r;
 }
+// v_mov_b32 with DPP quad_perm [0,0,2,2] / [1,1,3,3]: the even (odd) lane's value in both lanes of a pair
+inline unsigned int pair_pick_u32(unsigned int v, int odd) {
+  const int lane = hipemu::cur_lane();
+  memcpy(hipemu::cur_wave().in[lane], &v, 4);
+  hipemu::wave_collective([&](hipemu::WaveState& w, int n) {
+    for (int l = 0; l < n; ++l) {
+      const int src = (l & ~1) | odd;
+      memcpy(w.out[l], w.in[src < n ? src : l], 4);
+    }
+  });
+  unsigned int r;
+  memcpy(&r, hipemu::cur_wave().out[lane], 4);
+  return r;
+}
+inline unsigned int pair_swap_u32(unsigned int v) {
+  const int lane = hipemu::cur_lane();
+  memcpy(hipemu::cur_wave().in[lane], &v, 4);
+  hipemu::wave_collective([&](hipemu::WaveState& w, int n) {
+    for (int l = 0; l < n; ++l) memcpy(w.out[l], w.in[(l ^ 1) < n ? (l ^ 1) : l], 4);
+  });
+  unsigned int r;
+  memcpy(&r, hipemu::cur_wave().out[lane], 4);
+  return r;
+}
+inline unsigned int pair_even_u32(unsigned int v) { return pair_pick_u32(v, 0); }
+inline unsigned int pair_odd_u32(unsigned int v) { return pair_pick_u32(v, 1); }
 inline float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f32(v, m);
   return v;

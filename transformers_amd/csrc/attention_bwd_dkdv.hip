@@ -141,6 +141,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
   // (rows / keys past the end index blocks of other rows: their probabilities are zero anyway)
   const unsigned long long drop_lane = (unsigned long long)(krow >> 1) + (unsigned long long)(2 * hi) * drop.csk;
   const bool drop_kodd = (krow & 1) != 0;  // this lane's key: the first or the second word of each hash
+  // ... with the query pair this lane hashes for its key pair: the chunk's first (even key) or second (odd key)
+  const unsigned long long drop_lane_j = drop_lane + (drop_kodd ? drop.csk : 0ull);
   // PACKED: last query that sees this lane's key, and (wave-uniform) the last one that sees any key of the block
   const int* k_end = PACKED ? a.q_start + (int64_t)a.batch * a.seq_q + (int64_t)b * a.seq_k : nullptr;
   const int kend = PACKED ? k_end[krow < a.seq_k ? krow : a.seq_k - 1] : 0x3fffffff;
@@ -431,15 +433,20 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       const int ql = sub * 32 + 8 * qd + 4 * hi;  // 4 consecutive query rows (r&3)
       bool keep4[4] = {true, true, true, true};
       if (DROP) {  // rows ql + 2j, ql + 2j + 1 share a hash; this lane's key picks the word, the row its half
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          // block of query pair (qt0 + ql) / 2 + j: wave-uniform tile base and chunk term, the lane's part added once
-          unsigned w0, w1;
-          drop.words(drop_tile + (unsigned long long)(sub * 16 + 4 * qd + j) * drop.csk + drop_lane, w0, w1);
-          const unsigned w = drop_kodd ? w1 : w0;
-          keep4[2 * j] = drop.kept_lo(w);
-          keep4[2 * j + 1] = drop.kept_hi(w);
-        }
+        // block of query pair (qt0 + ql) / 2 + j: wave-uniform tile base and chunk term, the lane's part added once.
+        // The block's two keys sit in neighbouring lanes (lane ^ 1), which need the same 64 bits: the even key's lane hashes
+        // the chunk's first query pair (j = 0), the odd key's lane the second, and the words cross the pair through DPP moves
+        // (round 6; the forward kernel has the transposed arrangement) -- one hash per chunk and lane instead of two.
+        unsigned w0, w1;
+        drop.words(drop_tile + (unsigned long long)(sub * 16 + 4 * qd) * drop.csk + drop_lane_j, w0, w1);
+        // even key: its word of j = 0 is its own w0, of j = 1 the neighbour's w0; odd key: the neighbour's w1 and its own w1
+        const unsigned x0 = pair_swap_u32(w0), x1 = pair_swap_u32(w1);
+        const unsigned wa = drop_kodd ? x1 : w0;  // j = 0
+        const unsigned wb = drop_kodd ? w1 : x0;  // j = 1
+        keep4[0] = drop.kept_lo(wa);
+        keep4[1] = drop.kept_hi(wa);
+        keep4[2] = drop.kept_lo(wb);
+        keep4[3] = drop.kept_hi(wb);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {

@@ -49,6 +49,19 @@ __device__ __forceinline__ float swap32_f32(float v) {
   unsigned int o = (lane_id() < 32) ? r[1] : r[0];
   return __builtin_bit_cast(float, o);
 }
+// the value of the EVEN (ODD) lane of this lane's pair (l & ~1, l | 1), in both lanes of the pair: one v_mov_b32 with a DPP
+// quad_perm of [0,0,2,2] ([1,1,3,3]) -- VALU only, no LDS crossbar, and the DPP combiner folds it into its consumer where it can.
+// (attention dropout: the two query rows -- or keys -- of a 2 x 2 hash block sit in neighbouring lanes; one of them hashes.)
+__device__ __forceinline__ unsigned int pair_even_u32(unsigned int v) {
+  return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xA0, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned int pair_odd_u32(unsigned int v) {
+  return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xF5, 0xf, 0xf, false);
+}
+// ... and the value of the OTHER lane of the pair (l ^ 1): quad_perm [1,0,3,2]
+__device__ __forceinline__ unsigned int pair_swap_u32(unsigned int v) {
+  return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);
+}
 // Half exchange of two registers: after the call, for lanes 0-31  a = own a, b = upper lanes' a;
 // for lanes 32-63 a = lower lanes' b, b = own b.   (v_permlane32_swap vdst=a', src=b')
 __device__ __forceinline__ void permlane32_swap(unsigned int& a, unsigned int& b) {
