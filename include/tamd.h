@@ -353,7 +353,11 @@ struct tamd_attn_params {
    * packed_sequence_mask_function :182-188).  int32 [2, batch, seq] or NULL; requires causal = 1 and seq_q == seq_k:
    *   plane 0  q_start[b, q] = index of the first token of query q's sequence
    *   plane 1  k_end[b, k]   = index of the last token of key k's sequence
-   * key k is visible to query q iff q_start[b,q] <= k <= q (equivalently k <= q <= k_end[b,k]). */
+   * key k is visible to query q iff q_start[b,q] <= k <= q (equivalently k <= q <= k_end[b,k]).
+   * The kernels only rely on both planes being non-decreasing along the row with q_start[q] <= q and k_end[k] >= k, so the
+   * same planes carry the causal sliding window (masking_utils.py:92-101: q_start = max(0, q - w + 1), k_end = min(seq - 1,
+   * k + w - 1)), chunked attention (:104-113: chunk numbers as sequence ids) and any intersection of these (elementwise
+   * max of plane 0, min of plane 1). */
   const int32_t* q_start;
   /* ABI 7.  The kernels take the scores in the exp2 domain: they multiply their resident operand by scale*log2(e) and
    * round it again to the storage dtype (0).  A producer that rounds q once anyway can apply the factor before its own

@@ -69,11 +69,83 @@ def test_mask_function_decoder():
     assert np.array_equal(tamd_mask(2, 12, 12, mask_function=fn2).q_start.numpy(), m.q_start.numpy())
     # anything else is refused, as is packing with a KV cache
     with pytest.raises(ops.TamdError):
-        tamd_mask(2, 12, 12, mask_function=mu.and_masks(mu.causal_mask_function, mu.sliding_window_overlay(4)))
+        tamd_mask(2, 12, 12, mask_function=mu.and_masks(mu.causal_mask_function, mu.sliding_window_bidirectional_overlay(4)))
     with pytest.raises(ops.TamdError):
         tamd_mask(2, 12, 12, mask_function=lambda b, h, q, k: q >= k)
     with pytest.raises(ops.TamdError):
         tamd_mask(2, 4, 12, q_offset=8, mask_function=fn)
+
+
+def _reference_bool_mask(fn, batch, s):
+    """The reference's own evaluation of a mask function: [B, S, S] bool (masking_utils.py sdpa_mask, no skips)."""
+    from transformers import masking_utils as mu
+
+    m = mu.sdpa_mask(batch, s, s, 0, 0, mask_function=fn, attention_mask=None, allow_is_causal_skip=False)
+    return m[:, 0].numpy()
+
+
+def _bounds_as_bool(planes, s):
+    """The mask the kernels compute from the two planes -- both forms (the forward / dQ kernels use plane 0, dK/dV plane 1)."""
+    qi, ki = np.meshgrid(np.arange(s), np.arange(s), indexing="ij")
+    a = (planes[0][:, :, None] <= ki[None]) & (ki <= qi)[None]
+    b = (ki <= qi)[None] & (qi[None] <= planes[1][:, None, :])
+    return a, b
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(1, 40), st.integers(1, 48), st.integers(1, 3), st.integers(0, 2), st.integers(1, 17), st.integers(0, 9))
+def test_sliding_window_and_chunked_overlays_become_bounds(s, window, batch, mode, chunk, lp0):
+    """masking_utils.py:92-113, 134-138, 161-165: the causal sliding-window and chunked masks (alone, together, and AND-ed
+    with packed sequences) decoded by `tamd_mask` into the kernels' two bound planes describe exactly the mask the
+    reference evaluates from the same mask function; both planes are non-decreasing (what the kernels' tile skipping
+    relies on)."""
+    from transformers import masking_utils as mu
+
+    left = torch.tensor([(lp0 + 3 * i) % max(s, 1) for i in range(batch)])
+    if mode == 0:
+        fn = mu.sliding_window_causal_mask_function(window)
+    elif mode == 1:
+        fn = mu.chunked_causal_mask_function(chunk, left)
+    else:
+        ids = torch.div(torch.arange(s)[None].expand(batch, -1) + torch.arange(batch)[:, None], max(1, s // 3),
+                        rounding_mode="floor")
+        fn = mu.and_masks(mu.sliding_window_causal_mask_function(window), mu.chunked_overlay(chunk, left),
+                          mu.packed_sequence_mask_function(ids))
+    want = _reference_bool_mask(fn, batch, s)
+    m = tamd_mask(batch, s, s, mask_function=fn, device="cpu")
+    if m is None:  # a window that covers the row: the plain causal mask
+        assert mode == 0 and window >= s
+        assert np.array_equal(want, np.broadcast_to(np.tril(np.ones((s, s), bool)), want.shape))
+        return
+    assert isinstance(m, TamdMask) and m.key_valid is None and m.q_start.dtype == torch.int32
+    planes = m.q_start.numpy()
+    assert planes.shape == (2, batch, s)
+    a, b = _bounds_as_bool(planes, s)
+    assert np.array_equal(a, want) and np.array_equal(b, want)
+    assert (np.diff(planes, axis=-1) >= 0).all()
+    with pytest.raises(ops.TamdError):  # ... not with a KV cache
+        tamd_mask(batch, 1, s + 1, q_offset=s, mask_function=fn, device="cpu")
+
+
+def test_sliding_window_argument_of_the_attention_function():
+    """The `sliding_window` keyword (models/mistral/modeling_mistral.py: handed to every attention function) when the mask
+    does not carry the window: planes for the square causal case, nothing for decode steps and windows covering the row,
+    a refusal for a prefill over a longer cache."""
+    from transformers_amd.attention import window_q_start
+
+    dev = torch.device("cpu")
+    assert window_q_start(None, None, 2, 8, 8, True, dev) is None
+    assert window_q_start(None, 8, 2, 8, 8, True, dev) is None and window_q_start(None, 4, 2, 1, 8, True, dev) is None
+    qs = window_q_start(None, 3, 2, 8, 8, True, dev)
+    assert np.array_equal(qs.numpy(), ops.sliding_window_q_start(2, 8, 3, dev).numpy())
+    assert qs[0, 1].tolist() == [0, 0, 0, 1, 2, 3, 4, 5] and qs[1, 0].tolist() == [2, 3, 4, 5, 6, 7, 7, 7]
+    assert window_q_start(None, 3, 2, 8, 8, True, dev) is qs  # (one construction per forward, not per layer)
+    keep = torch.zeros(2, 2, 8, dtype=torch.int32)
+    assert window_q_start(keep, 3, 2, 8, 8, True, dev) is keep  # the mask already carried it
+    with pytest.raises(ops.TamdError):
+        window_q_start(None, 3, 2, 4, 8, True, dev)
+    with pytest.raises(ops.TamdError):
+        window_q_start(None, 3, 2, 8, 8, False, dev)
 
 
 def test_mask_for_cross_attention_is_the_padding_mask():

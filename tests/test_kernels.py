@@ -732,6 +732,59 @@ def test_attention_packed_sequences(env):
         ops.attention(q.detach(), k.detach(), v.detach(), scale, False, None, q_start=q_start)
 
 
+def test_attention_sliding_window_and_chunked(env):
+    """The causal sliding-window and chunked masks (masking_utils.py:92-113, 134-138, 161-165) through the kernels' bound
+    planes: forward and backward against eager attention with the explicit mask the reference's formulas give -- windows
+    shorter than a key tile, windows over several tiles (whole tiles left of the window are skipped), chunks that do not
+    align with the tiles, both overlays together, and a right-padded batch on top."""
+    dev = env.device
+    # (batch, seq, heads_q, heads_kv, head_dim, window, chunk, padded keys of row 0)
+    cases = ([(2, 1024, 8, 2, 128, 300, None, 0), (1, 777, 4, 4, 64, 37, None, 0), (2, 640, 4, 2, 128, None, 200, 0),
+              (2, 512, 4, 1, 64, 150, 96, 40)] if env.big
+             else [(2, 200, 4, 2, 64, 70, None, 0), (1, 150, 2, 1, 128, 9, None, 0), (2, 160, 2, 2, 64, None, 48, 0),
+                   (2, 136, 2, 1, 128, 50, 40, 11)])
+    for b, s, hq, hkv, d, window, chunk, pad in cases:
+        torch.manual_seed(37)
+        left = torch.tensor([(5 * i) % 7 for i in range(b)])
+        bounds = None
+        if window is not None:
+            bounds = ops.intersect_q_start(bounds, ops.sliding_window_q_start(b, s, window, dev))
+        if chunk is not None:
+            bounds = ops.intersect_q_start(bounds, ops.chunked_q_start(b, s, chunk, left, dev))
+        key_valid = None
+        if pad:
+            key_valid = torch.ones(b, s, dtype=torch.bool, device=dev)
+            key_valid[0, s - pad:] = False
+        q = torch.randn(b, s, hq, d).bfloat16().to(dev).requires_grad_(True)
+        k = torch.randn(b, s, hkv, d).bfloat16().to(dev).requires_grad_(True)
+        v = torch.randn(b, s, hkv, d).bfloat16().to(dev).requires_grad_(True)
+        scale = 1 / math.sqrt(d)
+        o = ops.attention(q, k, v, scale, True, key_valid, q_start=bounds)
+        qi, ki = torch.arange(s)[:, None], torch.arange(s)[None, :]
+        allow = (ki <= qi)[None].expand(b, -1, -1).clone()
+        if window is not None:
+            allow &= (ki > qi - window)[None]
+        if chunk is not None:
+            allow &= torch.div(ki[None] - left[:, None, None], chunk, rounding_mode="floor") == \
+                torch.div(qi[None] - left[:, None, None], chunk, rounding_mode="floor")
+        allow = allow.to(dev)
+        if pad:
+            allow = allow & key_valid[:, None, :]
+        qr, kr, vr = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        g = hq // hkv
+        qf = qr.float().permute(0, 2, 1, 3)
+        kf = kr.float().permute(0, 2, 1, 3).repeat_interleave(g, 1)
+        vf = vr.float().permute(0, 2, 1, 3).repeat_interleave(g, 1)
+        sc = (qf @ kf.transpose(-1, -2) * scale).masked_fill(~allow[:, None], float("-inf"))
+        ref = (torch.softmax(sc, -1) @ vf).permute(0, 2, 1, 3)
+        assert rel_err(o, ref) < 0.004, (b, s, d, window, chunk)
+        do = torch.randn_like(o)
+        o.backward(do)
+        ref.backward(do.float())
+        for name, x, r in (("dq", q.grad, qr.grad), ("dk", k.grad, kr.grad), ("dv", v.grad, vr.grad)):
+            assert rel_err(x, r) < 0.0062, (name, b, s, d, window, chunk)
+
+
 def test_attention_spike_forces_rescale(env):
     """Online-softmax rescale path: one key dominates late in the sequence (cdna guide rule 26)."""
     dev = env.device

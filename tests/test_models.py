@@ -486,12 +486,58 @@ def test_packed_sequences_match_reference_and_separate_runs(env):
             assert rel_err(only[:, st:st + n], alone) < 3e-2 < rel_err(single[:, st:st + n], alone)
             st += n
     # an overlay the kernels do not implement is refused loudly
-    from transformers.masking_utils import and_masks, causal_mask_function, sliding_window_overlay
+    from transformers.masking_utils import and_masks, causal_mask_function, sliding_window_bidirectional_overlay
     from transformers_amd.attention import tamd_mask
     from transformers_amd.ops import TamdError
 
     with pytest.raises(TamdError):
-        tamd_mask(1, 8, 8, mask_function=and_masks(causal_mask_function, sliding_window_overlay(4)))
+        tamd_mask(1, 8, 8, mask_function=and_masks(causal_mask_function, sliding_window_bidirectional_overlay(4)))
+
+
+@pytest.mark.parametrize("padded", [False, True])
+def test_sliding_window_model_through_the_attention_registry(env, padded):
+    """Boundary B1 alone on a model family this package has no modules for: a Mistral-shaped decoder with a sliding window
+    shorter than the sequence (masking_utils.py:1102-1239 `create_sliding_window_causal_mask` -> the registered mask
+    factory -> the kernels' bound planes).  Forward and backward against the reference's own fp32 / bf16 eager runs --
+    and the window is really applied: the run with the window differs from the run without it."""
+    from transformers import MistralConfig, MistralForCausalLM
+
+    torch.manual_seed(21)
+    window = 96 if env.big else 20
+    cfg = MistralConfig(vocab_size=512, hidden_size=512 if env.big else 128, intermediate_size=1024 if env.big else 256,
+                        num_hidden_layers=2, num_attention_heads=8 if env.big else 2, num_key_value_heads=2 if env.big else 1,
+                        head_dim=64, max_position_embeddings=1024, sliding_window=window, attn_implementation="eager")
+    ref = MistralForCausalLM(cfg).bfloat16().train()
+    ref32 = copy.deepcopy(ref).float()
+    fast = transformers_amd.accelerate(copy.deepcopy(ref).to(env.device))
+    assert fast.config._attn_implementation == "tamd"
+    s = 400 if env.big else 75
+    ids = torch.randint(0, cfg.vocab_size, (2, s))
+    am = None
+    if padded:
+        am = torch.ones(2, s, dtype=torch.long)
+        am[1, s - (50 if env.big else 13):] = 0
+    labels = ids.clone() if am is None else ids.masked_fill(am == 0, -100)
+    dev = env.device
+    kw = {} if am is None else {"attention_mask": am}
+    o32 = ref32(input_ids=ids, labels=labels, use_cache=False, **kw)
+    o32.loss.backward()
+    oref = ref(input_ids=ids, labels=labels, use_cache=False, **kw)
+    kwd = {} if am is None else {"attention_mask": am.to(dev)}
+    o = fast(input_ids=ids.to(dev), labels=labels.to(dev), use_cache=False, **kwd)
+    o.loss.backward()
+    keep = slice(None) if am is None else am.bool()
+    e_fast, e_ref = rel_err(o.logits[keep], o32.logits[keep]), rel_err(oref.logits[keep], o32.logits[keep])
+    assert e_fast <= 1.1 * e_ref + 1e-3, (e_fast, e_ref)
+    assert abs(o.loss.item() - o32.loss.item()) < 2e-3 * abs(o32.loss.item()) + 2e-3
+    g32 = dict(ref32.named_parameters())
+    for n, p in fast.named_parameters():
+        if "layers.0.self_attn.k_proj" in n or "layers.0.self_attn.q_proj" in n or "layers.1.self_attn.v_proj" in n:
+            assert rel_err(p.grad, g32[n].grad) < 0.03, n
+    ref32.config.sliding_window = None
+    with torch.no_grad():
+        full = ref32(input_ids=ids, use_cache=False, **kw).logits
+    assert rel_err(full[0, window:], o32.logits[0, window:]) > 10 * e_fast  # the window matters at this length
 
 
 def test_bert_post_ln_block_with_hidden_dropout_matches_reference(env):

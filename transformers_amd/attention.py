@@ -71,8 +71,9 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
     Same contract as `flash_attention_mask` (masking_utils.py:607-647) minus its host-side `.all()` sync: causality
     is a kernel flag, padding is the 2-D mask itself.  The reference describes everything else through
     `mask_function`: plain causal / bidirectional are the kernel flag; `and_masks(causal, packed_sequence_mask)`
-    (masking_utils.py:973-974, position_ids restarting inside a row) becomes `q_start`; any other mask function
-    (sliding window, chunked, user overlays) is refused instead of being silently ignored."""
+    (masking_utils.py:973-974, position_ids restarting inside a row), the causal sliding window (:134-138) and chunked
+    attention (:161-165) -- alone or AND-ed together -- become `q_start` (every one of them is `first[q] <= k <= q`); any
+    other mask function (bidirectional windows, blockwise, user overlays) is refused instead of being silently ignored."""
     from transformers import masking_utils as mu
 
     # 2-D padding mask over the kv window [kv_offset, kv_offset + kv_length), padded with zeros on the right when it
@@ -113,22 +114,48 @@ def tamd_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_fun
     plain = (None, mu.causal_mask_function, getattr(mu, "bidirectional_mask_function", None))
     if mask_function in plain:
         return padding  # (a static-cache prefill mask is [B, kv_len]: shorter than the cache, see _mask_kv_len)
-    packed_ids = None
+    packed_ids, window, chunk = None, None, None
     for leaf in _decompose_mask_function(mask_function):
         if leaf in plain:
             continue
-        ids = _closure_vars(leaf).get("packed_sequence_mask") if getattr(leaf, "__name__", "") == "inner_mask" else None
-        if torch.is_tensor(ids) and packed_ids is None:
-            packed_ids = ids
+        kind, cv = _overlay_kind(leaf), _closure_vars(leaf)
+        if kind == "packed" and torch.is_tensor(cv.get("packed_sequence_mask")) and packed_ids is None:
+            packed_ids = cv["packed_sequence_mask"]
             continue
-        raise TamdError("attn_implementation='tamd' supports causal / bidirectional masks, 2-D padding and packed "
-                        f"sequences; the mask function {getattr(leaf, '__qualname__', leaf)!r} is not one of them "
-                        "(sliding-window / chunked / custom overlays need attn_implementation='sdpa' or 'eager')")
-    if packed_ids is None:
+        if kind == "sliding" and isinstance(cv.get("sliding_window"), int) and not isinstance(cv["sliding_window"], bool):
+            window = cv["sliding_window"] if window is None else min(window, cv["sliding_window"])
+            continue
+        if kind == "chunked" and isinstance(cv.get("chunk_size"), int) and chunk is None:
+            chunk = (cv["chunk_size"], cv.get("left_padding"))
+            continue
+        raise TamdError("attn_implementation='tamd' supports causal / bidirectional masks, 2-D padding, packed sequences and "
+                        "the causal sliding-window / chunked overlays; the mask function "
+                        f"{getattr(leaf, '__qualname__', leaf)!r} is not one of them "
+                        "(bidirectional windows / blockwise / custom overlays need attn_implementation='sdpa' or 'eager')")
+    if packed_ids is None and window is None and chunk is None:
         return padding
     if not dynamic or q_offset != 0 or q_length != kv_length:
-        raise TamdError("packed sequences with a KV cache are not supported by attn_implementation='tamd'")
-    return TamdMask(padding, ops.packed_q_start(packed_ids[:, -q_length:]))
+        raise TamdError("packed sequences, sliding windows and chunked attention with a KV cache are not supported by "
+                        "attn_implementation='tamd' (use 'sdpa' or 'eager' for cached generation with these masks)")
+    # every one of these overlays AND-ed with the causal mask has the form `q_start[b, q] <= k <= q`: the kernels' two bound planes
+    dev = (packed_ids.device if packed_ids is not None else padding.device if padding is not None
+           else kwargs.get("device") or "cpu")
+    bounds = None if packed_ids is None else ops.packed_q_start(packed_ids[:, -q_length:])
+    if window is not None and window < kv_length:  # (a window as long as the row is the plain causal mask)
+        bounds = ops.intersect_q_start(bounds, ops.sliding_window_q_start(batch_size, q_length, window, dev))
+    if chunk is not None:
+        bounds = ops.intersect_q_start(bounds, ops.chunked_q_start(batch_size, q_length, chunk[0], chunk[1], dev))
+    return padding if bounds is None else TamdMask(padding, bounds)
+
+
+def _overlay_kind(leaf) -> Optional[str]:
+    """Which of the reference's mask overlays a leaf of the `and_masks` tree is, by the factory that made it
+    (masking_utils.py:92-101 sliding_window_overlay, :104-113 chunked_overlay, :182-190 packed_sequence_mask_function)."""
+    if getattr(leaf, "__name__", "") != "inner_mask":
+        return None
+    factory = getattr(leaf, "__qualname__", "").split(".<locals>")[0]
+    return {"packed_sequence_mask_function": "packed", "sliding_window_overlay": "sliding",
+            "chunked_overlay": "chunked"}.get(factory)
 
 
 def split_mask(attention_mask, batch: int, kv_len: int):
@@ -188,6 +215,27 @@ def varlen_q_start(q_start, kwargs, batch: int, sq: int, sk: int, causal: bool):
     if cacheable:
         _varlen_cache.entry = (cu_q, cu_k if cu_k is not None else cu_q, sq, qs, vers)
     return qs
+
+
+_window_cache = threading.local()  # the last (batch, seq, window, device) -> q_start of this thread
+
+
+def window_q_start(q_start, sliding_window, batch: int, sq: int, sk: int, causal: bool, device):
+    """The `sliding_window` argument the reference's sliding-window models hand to every attention function
+    (e.g. models/mistral/modeling_mistral.py `sliding_window=getattr(self.config, "sliding_window", None)`; its flash path
+    consumes it in modeling_flash_attention_utils.py `_process_flash_attention_kwargs`) when the mask did not already carry
+    the window (a mask built by another factory, or no mask at all).  Decode steps (one query) see the whole cropped cache;
+    a prefill on top of a cache longer than the window is refused, not computed with the wrong mask."""
+    if sliding_window is None or q_start is not None or sq == 1 or int(sliding_window) >= sk:
+        return q_start
+    if not causal or sq != sk:
+        raise TamdError("attn_implementation='tamd' implements sliding_window for causal attention without a KV cache "
+                        f"(got {sq} queries over {sk} keys, causal={causal}); use 'sdpa' or 'eager'")
+    key = (batch, sq, int(sliding_window), torch.device(device))
+    hit = getattr(_window_cache, "entry", None)
+    if hit is None or hit[0] != key:
+        hit = _window_cache.entry = (key, ops.sliding_window_q_start(batch, sq, int(sliding_window), device))
+    return hit[1]
 
 
 _kv_cache = threading.local()  # the last (mask tensor, batch, kv_len) -> key_valid of this thread
@@ -273,6 +321,7 @@ def tamd_attention_forward(module, query, key, value, attention_mask, dropout: f
         k, v = k[:, :sk], v[:, :sk]
     key_valid, q_start = split_mask(attention_mask, b, sk)
     q_start = varlen_q_start(q_start, kwargs, b, sq, sk, causal)
+    q_start = window_q_start(q_start, kwargs.get("sliding_window"), b, sq, sk, causal, q.device)
     if q.stride(3) != 1:
         q = q.contiguous()
     if k.stride(3) != 1:

@@ -977,6 +977,42 @@ def packed_q_start(seq_ids: torch.Tensor) -> torch.Tensor:
     return torch.stack((start, end)).to(torch.int32).contiguous()
 
 
+def sliding_window_q_start(batch: int, seq: int, window: int, device) -> torch.Tensor:
+    """The reference's sliding-window overlay on a causal mask (`kv_idx > q_idx - sliding_window`, masking_utils.py:92-101,
+    134-138) as the kernels' two bound planes, int32 [2, B, S]: query q sees keys max(0, q - window + 1) .. q, key k is seen
+    by queries k .. min(S - 1, k + window - 1).  Both planes are non-decreasing, which is all the kernels ask of them
+    (include/tamd.h q_start): tiles left of the window are neither loaded nor visited."""
+    if window < 1:
+        raise TamdError(f"sliding_window must be >= 1, got {window}")
+    pos = torch.arange(seq, device=device, dtype=torch.int64)
+    planes = torch.stack(((pos - (window - 1)).clamp(min=0), (pos + (window - 1)).clamp(max=seq - 1)))
+    return planes[:, None, :].expand(2, batch, seq).to(torch.int32).contiguous()
+
+
+def chunked_q_start(batch: int, seq: int, chunk_size: int, left_padding, device) -> torch.Tensor:
+    """The reference's chunked-attention overlay on a causal mask (`(kv_idx - left_padding[b]) // chunk_size ==
+    (q_idx - left_padding[b]) // chunk_size`, masking_utils.py:104-113, 161-165): a packed batch whose sequence ids are the
+    chunk numbers (floor division, so the left padding forms chunks of its own as in the reference)."""
+    if chunk_size < 1:
+        raise TamdError(f"chunk_size must be >= 1, got {chunk_size}")
+    pos = torch.arange(seq, device=device, dtype=torch.int64)[None, :]
+    lp = (torch.zeros(batch, dtype=torch.int64, device=device) if left_padding is None
+          else torch.as_tensor(left_padding, device=device).to(torch.int64).reshape(-1))
+    if lp.numel() == 1 and batch != 1:
+        lp = lp.expand(batch)
+    if lp.numel() != batch:
+        raise TamdError(f"chunked attention: left_padding has {lp.numel()} entries for a batch of {batch}")
+    return packed_q_start(torch.div(pos - lp[:, None], chunk_size, rounding_mode="floor"))
+
+
+def intersect_q_start(a: Optional[torch.Tensor], b: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Bound planes of the AND of two masks that each have the form `q_start[q] <= k <= q` (packed sequences, a sliding
+    window, chunks): the later first-visible key per query, the earlier last-seeing query per key."""
+    if a is None or b is None:
+        return a if b is None else b
+    return torch.stack((torch.maximum(a[0], b[0]), torch.minimum(a[1], b[1]))).contiguous()
+
+
 def q_start_from_cu_seqlens(cu_seq_lens: torch.Tensor, total: int) -> torch.Tensor:
     """The reference's varlen description of a flattened batch -- `cu_seq_lens_q` = cumulative sequence lengths [n + 1]
     (`FlashAttentionKwargs`, modeling_flash_attention_utils.py:575-590; DataCollatorWithFlattening) -- as the two bound
