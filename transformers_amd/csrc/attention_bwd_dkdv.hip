@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
         float x = s[sub][r];
         // branch-free: a branch here would cut the MFMA / VALU interleave into pieces; the test costs 2 VALU per
         // element on every tile (mask_lim is -2^30 on tiles that need no mask)
-        if (PACKED)
+        if (PACKED && !PLAIN)
           x = (mask_lim <= ql + e && ql + e <= mask_hi) ? x : -INFINITY;
         else if (!PLAIN)
           x = (mask_lim <= ql + e) ? x : -INFINITY;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       const int ql = sub * 32 + 8 * qd + 4 * hi;
       auto ex = [&](int e) {
         float x = s[sub][qd * 4 + e];
-        if (PACKED)
+        if (PACKED && !PLAIN)
           x = (mask_lim <= ql + e && ql + e <= mask_hi) ? x : -INFINITY;
         else if (!PLAIN)
           x = (mask_lim <= ql + e) ? x : -INFINITY;
@@ -765,7 +765,8 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
    }
   };
   int it_plain = 0;  // (even) leading tiles of this wave that take the body without the mask test
-  if (!PACKED && !(DBG & 32) && ballot64(key_ok) == ~0ull) {
+  int it_first = 0;  // PACKED: (even) tiles in front of them whose last rows lie behind the end of a key's sequence / window
+  if (!(DBG & 32) && ballot64(key_ok) == ~0ull) {
     int n = niter2;
     if (CAUSAL) {
       const int need = kw0 + 31 - off;                       // first query row that sees the wave's last key
@@ -774,9 +775,39 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
       n = tiles * group < niter2 ? tiles * group : niter2;
     }
     it_plain = n & ~1;
+    if (PACKED) {
+      // Round 6 (end): until then EVERY tile of a packed / windowed launch carried the two-sided test (4 VALU per element on a
+      // loop bound by instruction issue: 1.6-1.8x the plain kernel's time per visible pair, profiles/r06ad_attn_window_kernels.txt).
+      // A tile whose 64 query rows all lie at or before the sequence end of EVERY key of this wave (k_end is non-decreasing:
+      // the wave's minimum) and behind the causal diagonal needs no test at all -- the walk goes from the last visible
+      // q-tile down, so the tiles are: a few with the upper test, the plain ones, the diagonal ones.
+      const int kmin = -(int)wave_max(-(float)kend);
+      const int qt_ok = (kmin + 1 - off) / kQT - 1;  // last q-tile all of whose rows see every key of the wave
+      int lead = (nqt64 - 1 - qt_ok) * group;       // tiles walked before it
+      lead = lead < 0 ? 0 : lead;
+      it_first = (lead + 1) & ~1;
+      it_first = it_first < it_plain ? it_first : it_plain;
+    }
   }
   int it0 = 0;
-  if (FINE) {
+  if constexpr (PACKED) {
+    // one loop, a wave-uniform choice of the body per tile pair (two copies of the body, as in the other variants)
+    constexpr bool TWO = FINE || !(DROP && D > 64);  // (two bodies of the dropout variant at head_dim 128 do not fit the registers)
+    for (; it0 < niter2; it0 += 2) {
+      const bool plain = TWO && it0 >= it_first && it0 < it_plain;
+      if constexpr (FINE) {
+        if (plain)
+          tile_pair_fine(IntC<1>{}, it0);
+        else
+          tile_pair_fine(IntC<0>{}, it0);
+      } else {
+        if (plain)
+          tile_pair(IntC<(TWO ? 1 : 0)>{}, it0);
+        else
+          tile_pair(IntC<0>{}, it0);
+      }
+    }
+  } else if constexpr (FINE) {
     for (; it0 < it_plain; it0 += 2) tile_pair_fine(IntC<1>{}, it0);
     for (; it0 < niter2; it0 += 2) tile_pair_fine(IntC<0>{}, it0);
   } else {
