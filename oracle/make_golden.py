@@ -239,7 +239,31 @@ def make_adamw_clip():
          hyper=np.array([3e-3, 0.9, 0.95, 1e-8, 0.1, 1.0], dtype=np.float64))
 
 
+def make_window_chunk_mask():
+    """11c (round 6).  The reference's causal sliding-window and chunked mask functions (masking_utils.py:92-113, 134-138,
+    161-165), alone and AND-ed with each other and with a packed-sequence mask, evaluated densely by the reference itself.
+    `python oracle/make_golden.py window_chunk_mask` writes only this fixture."""
+    check_reference_identity()
+    from transformers import masking_utils as mu
+
+    s, b = 23, 2
+    left = torch.tensor([0, 3])
+    pos = torch.tensor([list(range(9)) + list(range(14)), list(range(16)) + list(range(7))])
+    pids = mu.find_packed_sequence_indices(pos)
+    cases = {"window5": mu.sliding_window_causal_mask_function(5),
+             "window1": mu.sliding_window_causal_mask_function(1),
+             "chunk6_left": mu.chunked_causal_mask_function(6, left),
+             "window7_chunk10_packed": mu.and_masks(mu.sliding_window_causal_mask_function(7), mu.chunked_overlay(10, left),
+                                                    mu.packed_sequence_mask_function(pids))}
+    bi, qi, ki = torch.meshgrid(torch.arange(b), torch.arange(s), torch.arange(s), indexing="ij")
+    out = {k: fn(bi, torch.zeros_like(bi), qi, ki).numpy() for k, fn in cases.items()}
+    save("window_chunk_mask", left_padding=left.numpy(), seq_ids=pids.numpy(), **out)
+    return 0
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["adamw_clip"]:
         sys.exit(make_adamw_clip())
+    if sys.argv[1:] == ["window_chunk_mask"]:
+        sys.exit(make_window_chunk_mask())
     sys.exit(main())

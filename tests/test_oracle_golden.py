@@ -310,6 +310,33 @@ def test_oracle_packed_mask_golden():
     assert np.array_equal(ops.packed_q_start(torch.from_numpy(ids)).numpy(), np.stack((lo, hi)))
 
 
+def test_oracle_window_and_chunk_mask_golden():
+    """The reference's causal sliding-window / chunked mask functions (alone, and AND-ed with a packed-sequence mask) evaluated
+    densely by the reference itself (oracle/make_golden.py window_chunk_mask), against the oracle's restatement of the two
+    formulas; every one of them is exactly `first[q] <= k <= q`, and the device-side constructions of the product path
+    (ops.sliding_window_q_start / chunked_q_start / packed_q_start / intersect_q_start) give those two arrays."""
+    g = load("window_chunk_mask")
+    left, ids = g["left_padding"], g["seq_ids"]
+    b, s = ids.shape
+    w5 = np.broadcast_to(orc.sliding_window_mask_bool(s, 5), (b, s, s))
+    assert np.array_equal(w5, g["window5"])
+    assert np.array_equal(np.broadcast_to(orc.sliding_window_mask_bool(s, 1), (b, s, s)), g["window1"])
+    assert np.array_equal(g["window1"][0], np.eye(s, dtype=bool))
+    c6 = orc.chunked_mask_bool(s, 6, left)
+    assert np.array_equal(c6, g["chunk6_left"])
+    combo = (np.broadcast_to(orc.sliding_window_mask_bool(s, 7), (b, s, s)) & orc.chunked_mask_bool(s, 10, left)
+             & orc.packed_attention_mask_bool(ids)[:, 0])
+    assert np.array_equal(combo, g["window7_chunk10_packed"])
+    dev = torch.device("cpu")
+    lt, it = torch.from_numpy(left), torch.from_numpy(ids)
+    assert np.array_equal(ops.sliding_window_q_start(b, s, 5, dev).numpy(), orc.mask_bounds(g["window5"]))
+    assert np.array_equal(ops.sliding_window_q_start(b, s, 1, dev).numpy(), orc.mask_bounds(g["window1"]))
+    assert np.array_equal(ops.chunked_q_start(b, s, 6, lt, dev).numpy(), orc.mask_bounds(g["chunk6_left"]))
+    both = ops.intersect_q_start(ops.intersect_q_start(ops.sliding_window_q_start(b, s, 7, dev), ops.chunked_q_start(b, s, 10, lt, dev)),
+                                 ops.packed_q_start(it))
+    assert np.array_equal(both.numpy(), orc.mask_bounds(g["window7_chunk10_packed"]))
+
+
 def test_kernel_packed_and_dropout_attention_vs_oracle(env):
     """Flash kernels with q_start (packed rows) and with in-kernel dropout against the oracle's exact restatements."""
     rng = np.random.default_rng(5)
@@ -324,6 +351,16 @@ def test_kernel_packed_and_dropout_attention_vs_oracle(env):
     o, _ = ops.raw_attn_fwd(q.to(dev), k.to(dev), v.to(dev), scale, True, q_start=qs)
     tr = lambda t: t.float().numpy().transpose(0, 2, 1, 3)  # [B,S,H,D] -> [B,H,S,D]
     want = orc.exact_attention(tr(q), tr(k), tr(v), scale, orc.packed_attention_mask_bool(ids))
+    assert nrel(o.float().cpu().numpy(), want) < 5e-3
+    # the same planes carry a sliding window and chunks (masking_utils.py:92-113): window AND chunks AND packing at once
+    window, chunk, left = (70, 96, np.array([0, 5])) if env.big else (20, 28, np.array([0, 5]))
+    dense = (orc.sliding_window_mask_bool(s, window)[None] & orc.chunked_mask_bool(s, chunk, left)
+             & orc.packed_attention_mask_bool(ids)[:, 0])
+    planes = ops.intersect_q_start(ops.intersect_q_start(ops.sliding_window_q_start(b, s, window, dev),
+                                                         ops.chunked_q_start(b, s, chunk, torch.from_numpy(left), dev)), qs)
+    assert np.array_equal(planes.cpu().numpy(), orc.mask_bounds(dense))
+    o, _ = ops.raw_attn_fwd(q.to(dev), k.to(dev), v.to(dev), scale, True, q_start=planes)
+    want = orc.exact_attention(tr(q), tr(k), tr(v), scale, dense[:, None])
     assert nrel(o.float().cpu().numpy(), want) < 5e-3
     # dropout: the keep mask is the exported hash; the oracle applies it after the softmax
     p, seed = 0.25, 0x5EED1234ABCD
