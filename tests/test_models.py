@@ -127,9 +127,19 @@ def test_generate_with_cache_uses_reference_modules(env):
             got = fast(input_ids=ids[:, t:t + 1].to(env.device), past_key_values=got.past_key_values, use_cache=True)
             assert got.logits.shape == (2, 1, cfg.vocab_size) and rel_err(got.logits, want.logits) < 0.02, t
     assert transformers_amd.fallback_calls() == {}
-    fast.train()  # (autograd on: the cached forward is the reference module's)
-    got = fast(input_ids=ids[:, :10].to(env.device), use_cache=True)
+    fast.train()  # (autograd on: the cached forward is the reference module's -- and the caller is told once how to avoid it)
+    import warnings
+
+    from transformers_amd.models import common
+
+    common._WARNED.clear()
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        got = fast(input_ids=ids[:, :10].to(env.device), use_cache=True)
+        fast(input_ids=ids[:, :10].to(env.device), use_cache=True)
     assert any("kv_cache" in k for k in transformers_amd.fallback_calls()), transformers_amd.fallback_calls()
+    told = [w for w in seen if "use_cache=False" in str(w.message)]
+    assert 1 <= len(told) <= 2, [str(w.message) for w in seen]  # (once per module class: layer, and the attention inside it)
 
 
 @pytest.mark.parametrize("padding_side", [None, "left"])

@@ -24,11 +24,24 @@ def _gpu(t: torch.Tensor) -> bool:
 _FALLBACKS: dict = {}
 
 
+_WARNED = set()
+
+
 def note_fallback(mod, x, reason: str = "unsupported") -> None:
     """Record that `mod` is about to serve the GPU tensor `x` through the reference's forward."""
     if x is not None and torch.is_tensor(x) and _gpu(x):
         key = f"{type(mod).__name__}:{reason}"
         _FALLBACKS[key] = _FALLBACKS.get(key, 0) + 1
+        if reason == "kv_cache" and key not in _WARNED and torch.is_grad_enabled():
+            # a training forward that left `use_cache` at the config's default (True): the reference builds a DynamicCache and
+            # hands it to every layer (modeling_llama.py:383-384); the fused layer does not feed a cache under autograd.  The
+            # reference's Trainer switches it off itself (trainer.py:616-617); a hand-written loop has to.
+            _WARNED.add(key)
+            import warnings
+
+            warnings.warn(f"transformers_amd: {type(mod).__name__} received a KV cache under autograd and runs the reference "
+                          "module around the kernels (slower than the fused layer): pass use_cache=False (or set "
+                          "model.config.use_cache = False) in training forwards", stacklevel=3)
 
 
 def fallback_calls(reset: bool = False) -> dict:
