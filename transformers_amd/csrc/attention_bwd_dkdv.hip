@@ -113,6 +113,30 @@ __global__ __launch_bounds__(kAttnThreads, 1) void attn_bwd_dkdv_kernel(AttnBwdA
     b = gi / a.heads_kv;
     hkv = gi % a.heads_kv;
     kvt = within;  // early key blocks see the most queries under a causal mask: they come first
+    if (PACKED && nkvt <= 64) {
+      // ... which is no longer true under bound planes: the blocks at the start of EVERY sequence / chunk are the long ones, and
+      // with the natural order a long block of the last (batch, head) group of an XCD starts when the others are done (list
+      // scheduling of 8 groups x 32 blocks on 32 CUs: 1.10x the balanced time for two chunks of 2048, 1.00x for the plain
+      // causal mask).  Longest first inside the group: block of rank `within` in descending number of visible q-tiles (ties:
+      // the earlier block) -- every wave derives the same permutation from the k_end plane (nkvt uniform loads).
+      const int* ke = a.q_start + (int64_t)a.batch * a.seq_q + (int64_t)b * a.seq_k;
+      auto visible_tiles = [&](int j) {
+        const int last = j * kKVB + kKVB - 1 < a.seq_k ? j * kKVB + kKVB - 1 : a.seq_k - 1;
+        return ke[last] / kQT - (j * kKVB) / kQT;
+      };
+      const int j = lane < nkvt ? lane : nkvt - 1;
+      const int wj = visible_tiles(j);
+      int rank = 0;
+      for (int i0 = 0; i0 < nkvt; i0 += 8) {  // eight independent loads per trip (one wait, not eight)
+        int wi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wi[u] = visible_tiles(i0 + u < nkvt ? i0 + u : nkvt - 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (i0 + u < nkvt && (wi[u] > wj || (wi[u] == wj && i0 + u < j))) ? 1 : 0;
+      }
+      const unsigned long long hit = ballot64(lane < nkvt && rank == within);
+      kvt = hit != 0ull ? (int)__builtin_ctzll(hit) : within;
+    }
   }
   const int k0 = kvt * kKVB, kw0 = k0 + wave * 32, krow = kw0 + l31;
   const int off = a.seq_k - a.seq_q;
